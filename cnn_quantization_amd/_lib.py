@@ -1,0 +1,74 @@
+"""ctypes binding of libcnnq_hip.so (include/cnnq_hip.h).  There is NO fallback: if the
+library is missing or a call fails the error is raised to the caller."""
+import ctypes
+import os
+
+from . import _build
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# rows of the device tables (mirrors the enums of include/cnnq_hip.h)
+STAT_MIN, STAT_MAX, STAT_MEAN, STAT_STD, STAT_B, STAT_KURT, STAT_STD_POS, NSTAT = 0, 1, 2, 3, 4, 5, 6, 7
+MOM_MIN, MOM_MAX, MOM_SUM, MOM_SUMSQ, MOM_COUNT, MOM_SUM_RELU, MOM_SUMSQ_RELU, NMOM = 0, 1, 2, 3, 4, 5, 6, 7
+DEV_ABS, DEV_Z4, NDEV = 0, 1, 2
+QP_SCALE, QP_ZP, QP_QMAX, NQP = 0, 1, 2, 3
+DIAG_BITS, DIAG_ALPHA, DIAG_DELTA, DIAG_OFFSET, NDIAG = 0, 1, 2, 3, 4
+
+
+class ParamsCfg(ctypes.Structure):
+    _fields_ = [('num_bits', ctypes.c_int32), ('positive', ctypes.c_int32), ('clip', ctypes.c_int32),
+                ('pstd', ctypes.c_float), ('bit_alloc', ctypes.c_int32), ('prior_is_b', ctypes.c_int32),
+                ('target', ctypes.c_double), ('round_mode', ctypes.c_int32), ('direct_range', ctypes.c_int32)]
+
+
+# every symbol include/cnnq_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'cnnq_version': (ctypes.c_char_p, []),
+    'cnnq_pc_groups': (_I, [_L, _L, _L, _I]),
+    'cnnq_pc_moments': (_I, [_P, _L, _L, _L, _I, _P, _P]),
+    'cnnq_pc_combine': (_I, [_P, _I, _L, _I, _P, _P, _P]),
+    'cnnq_pc_absdev': (_I, [_P, _L, _L, _L, _P, _I, _P, _P]),
+    'cnnq_pc_combine_dev': (_I, [_P, _I, _L, _P, _I, _P, _P, _P]),
+    'cnnq_pc_params': (_I, [_P, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P]),
+    'cnnq_pc_qdq': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
+    'cnnq_entropy': (_I, [_P, _I, _P, _P]),
+    'cnnq_pt_setup': (_I, [ctypes.POINTER(_F), _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'cnnq_pt_qdq': (_I, [_P, _P, _L, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class CnnqError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CnnqError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(hipcc --offload-arch=gfx950); there is no CPU fallback' % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: 'CNNQ_EINVAL', -2: 'CNNQ_ERANGE'}.get(rc, 'hipError %d' % rc)
+        raise CnnqError('%s failed: %s' % (what, kind))

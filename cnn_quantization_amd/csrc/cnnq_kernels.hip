@@ -1,0 +1,987 @@
+// cnnq_kernels.hip - gfx950 (MI355X / CDNA4) kernels behind include/cnnq_hip.h.
+//
+// Design: the whole path is HBM-bound elementwise + reduction work, so
+// nothing here is shaped for MFMA.  All streaming kernels share ONE decomposition of the
+// NCHW tensor x[N][C][HW]:
+//
+//   * the C*HW "plane" of one sample is cut into column blocks; a workgroup owns one column
+//     block and walks it down the batch (n = n0 .. n1), so every lane keeps the SAME channel(s)
+//     for its whole life: per-channel scale/zero-point are fetched once (staged through LDS)
+//     and live in registers, the hot loop is load(16 B) -> ALU -> store(16 B), fully coalesced,
+//     with no index division and no transposed copy;
+//   * column blocks are aligned to channel boundaries: either a slice of ONE channel (mode 1,
+//     large H*W) or k WHOLE channels (mode 2, small H*W), so reductions finish inside the
+//     workgroup (wave64 shuffles + LDS) and each (group, channel) partial is written by
+//     exactly one workgroup - no atomics, deterministic results;
+//   * three load shapes: VEC4 (H*W % 4 == 0), VEC4-straddle (H*W % 4 != 0 but C*H*W % 4 == 0,
+//     e.g. 7x7: a float4 may span two channels, per-element bookkeeping) and VEC1 (anything,
+//     incl. unaligned base pointers).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (division must stay an IEEE
+// divide followed by a separately rounded add: bit-exactness with the reference's aten ops).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "cnnq_hip.h"
+
+namespace {
+
+constexpr int TPB = 256;       // 4 wave64 per workgroup
+constexpr int MAXCH = 1024;    // max channels a workgroup can own (mode 2, H*W/VEC == 1)
+
+struct Geo {
+    int N, C, HW;
+    int P;      // C*HW, elements per sample plane (< 2^31)
+    int mode;   // 1: block = slice of one channel, 2: block = k whole channels
+    int nb, w;  // mode 1: blocks per channel, columns (loads) per block
+    int k;      // mode 2: channels per block
+    int ncb;    // column blocks per plane
+    int S;      // batch splits
+};
+
+struct Variant {
+    int vec, A, J;  // elements per load, accumulator sets per load, loads per thread per sample
+};
+
+struct Blk {
+    int c0, c1;      // channels [c0, c1)
+    int col0, col1;  // plane columns [col0, col1), in units of VEC elements
+    int n0, n1;      // samples [n0, n1)
+    int grp;         // partial group index
+};
+
+template <int VEC>
+__device__ __forceinline__ Blk blk_of(const Geo& g) {
+    Blk b;
+    const int cb = blockIdx.x % g.ncb;
+    const int s = blockIdx.x / g.ncb;
+    b.n0 = (int)(((int64_t)s * g.N) / g.S);
+    b.n1 = (int)(((int64_t)(s + 1) * g.N) / g.S);
+    if (g.mode == 1) {
+        const int cpc = g.HW / VEC;
+        const int c = cb / g.nb;
+        const int bb = cb - c * g.nb;
+        b.c0 = c;
+        b.c1 = c + 1;
+        b.col0 = c * cpc + bb * g.w;
+        b.col1 = min(b.col0 + g.w, (c + 1) * cpc);
+        b.grp = s * g.nb + bb;
+    } else {
+        b.c0 = cb * g.k;
+        b.c1 = min(g.C, b.c0 + g.k);
+        b.col0 = (int)(((int64_t)b.c0 * g.HW) / VEC);
+        b.col1 = (int)(((int64_t)b.c1 * g.HW) / VEC);
+        b.grp = s;
+    }
+    return b;
+}
+
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *p = v[0];
+    }
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+// ------------------------------------------------------------------------------------------
+// Pass A: per-channel min / max / sum / sumsq / count (+ relu sums)
+// ------------------------------------------------------------------------------------------
+struct Mom {
+    float mn, mx;
+    double s, ss, rs, rss;
+    __device__ __forceinline__ void init() {
+        mn = INFINITY; mx = -INFINITY; s = 0.; ss = 0.; rs = 0.; rss = 0.;
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void add(float v) {
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        const double d = (double)v;
+        s += d;
+        ss = fma(d, d, ss);
+        if constexpr (RELU) {
+            const double r = (double)fmaxf(v, 0.f);
+            rs += r;
+            rss = fma(r, r, rss);
+        }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void merge(const Mom& o) {
+        mn = fminf(mn, o.mn);
+        mx = fmaxf(mx, o.mx);
+        s += o.s;
+        ss += o.ss;
+        if constexpr (RELU) { rs += o.rs; rss += o.rss; }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void wave_reduce() {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            Mom o;
+            o.mn = shfl_xor_f(mn, m);
+            o.mx = shfl_xor_f(mx, m);
+            o.s = shfl_xor_d(s, m);
+            o.ss = shfl_xor_d(ss, m);
+            if constexpr (RELU) { o.rs = shfl_xor_d(rs, m); o.rss = shfl_xor_d(rss, m); }
+            merge<RELU>(o);
+        }
+    }
+};
+
+template <bool RELU>
+__device__ __forceinline__ void write_mom(double* __restrict__ part, int grp, int C, int ch, const Mom& m,
+                                          double count) {
+    double* p = part + (size_t)grp * CNNQ_NMOM * C + ch;
+    p[(size_t)CNNQ_MOM_MIN * C] = (double)m.mn;
+    p[(size_t)CNNQ_MOM_MAX * C] = (double)m.mx;
+    p[(size_t)CNNQ_MOM_SUM * C] = m.s;
+    p[(size_t)CNNQ_MOM_SUMSQ * C] = m.ss;
+    p[(size_t)CNNQ_MOM_COUNT * C] = count;
+    p[(size_t)CNNQ_MOM_SUM_RELU * C] = RELU ? m.rs : 0.;
+    p[(size_t)CNNQ_MOM_SUMSQ_RELU * C] = RELU ? m.rss : 0.;
+}
+
+template <int VEC, int A, int J, bool RELU>
+__global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, const Geo g,
+                                                 double* __restrict__ part) {
+    constexpr int NE = TPB * J * A;  // LDS entries (one per column, or per element when straddling)
+    __shared__ float l_mn[NE], l_mx[NE];
+    __shared__ double l_s[NE], l_ss[NE];
+    __shared__ double l_rs[RELU ? NE : 1], l_rss[RELU ? NE : 1];
+
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    int col[J];
+    bool ok[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;  // idle slots re-read the block's first column; results discarded
+    }
+    Mom acc[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc[j][a].init();
+
+    const float* row = x + (size_t)b.n0 * (size_t)g.P;
+#pragma unroll 2
+    for (int n = b.n0; n < b.n1; ++n, row += g.P) {
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[j][A == 1 ? 0 : e].template add<RELU>(v[j][e]);
+    }
+
+    const double rows = (double)(b.n1 - b.n0);
+    if (g.mode == 1) {
+        // one channel per workgroup: registers -> wave shuffle -> 4 LDS entries
+        Mom t;
+        t.init();
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (ok[j]) t.template merge<RELU>(acc[j][0]);
+        t.template wave_reduce<RELU>();
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) {
+            l_mn[wv] = t.mn; l_mx[wv] = t.mx; l_s[wv] = t.s; l_ss[wv] = t.ss;
+            if constexpr (RELU) { l_rs[wv] = t.rs; l_rss[wv] = t.rss; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Mom r;
+            r.init();
+            for (int i = 0; i < TPB / 64; ++i) {
+                Mom o;
+                o.mn = l_mn[i]; o.mx = l_mx[i]; o.s = l_s[i]; o.ss = l_ss[i];
+                if constexpr (RELU) { o.rs = l_rs[i]; o.rss = l_rss[i]; }
+                r.template merge<RELU>(o);
+            }
+            write_mom<RELU>(part, b.grp, g.C, b.c0, r, (double)(b.col1 - b.col0) * VEC * rows);
+        }
+        return;
+    }
+    // k whole channels per workgroup: per-column results to LDS, then one wave per channel
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (ok[j]) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int e = (j * TPB + tid) * A + a;
+                l_mn[e] = acc[j][a].mn; l_mx[e] = acc[j][a].mx; l_s[e] = acc[j][a].s; l_ss[e] = acc[j][a].ss;
+                if constexpr (RELU) { l_rs[e] = acc[j][a].rs; l_rss[e] = acc[j][a].rss; }
+            }
+        }
+    }
+    __syncthreads();
+    const int epc = g.HW * A / VEC;  // LDS entries per channel
+    const int wv = tid >> 6, lane = tid & 63;
+    const double count = (double)g.HW * rows;
+    if (epc <= 16) {
+        // tiny rows: one lane per channel, serial over its few entries
+        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
+            const int lo = (ch - b.c0) * epc;
+            Mom r;
+            r.init();
+            for (int e = lo; e < lo + epc; ++e) {
+                Mom o;
+                o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
+                if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
+                r.template merge<RELU>(o);
+            }
+            write_mom<RELU>(part, b.grp, g.C, ch, r, count);
+        }
+        return;
+    }
+    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
+        const int lo = (ch - b.c0) * epc;
+        Mom r;
+        r.init();
+        for (int e = lo + lane; e < lo + epc; e += 64) {
+            Mom o;
+            o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
+            if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
+            r.template merge<RELU>(o);
+        }
+        r.template wave_reduce<RELU>();
+        if (lane == 0) write_mom<RELU>(part, b.grp, g.C, ch, r, count);
+    }
+}
+
+// merge G records per channel; one wave64 per channel, lanes stride over the groups
+__global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part, int G, int C, int has_relu,
+                                                 double* __restrict__ mom, float* __restrict__ stats) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + wv;
+    if (c >= C) return;
+    double mn = INFINITY, mx = -INFINITY, s = 0., ss = 0., cnt = 0., rs = 0., rss = 0.;
+    for (int gi = lane; gi < G; gi += 64) {
+        const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
+        mn = fmin(mn, p[(size_t)CNNQ_MOM_MIN * C]);
+        mx = fmax(mx, p[(size_t)CNNQ_MOM_MAX * C]);
+        s += p[(size_t)CNNQ_MOM_SUM * C];
+        ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
+        cnt += p[(size_t)CNNQ_MOM_COUNT * C];
+        if (has_relu) {
+            rs += p[(size_t)CNNQ_MOM_SUM_RELU * C];
+            rss += p[(size_t)CNNQ_MOM_SUMSQ_RELU * C];
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mn = fmin(mn, shfl_xor_d(mn, m));
+        mx = fmax(mx, shfl_xor_d(mx, m));
+        s += shfl_xor_d(s, m);
+        ss += shfl_xor_d(ss, m);
+        cnt += shfl_xor_d(cnt, m);
+        rs += shfl_xor_d(rs, m);
+        rss += shfl_xor_d(rss, m);
+    }
+    if (lane != 0) return;
+    if (mom) {
+        mom[(size_t)CNNQ_MOM_MIN * C + c] = mn;
+        mom[(size_t)CNNQ_MOM_MAX * C + c] = mx;
+        mom[(size_t)CNNQ_MOM_SUM * C + c] = s;
+        mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = ss;
+        mom[(size_t)CNNQ_MOM_COUNT * C + c] = cnt;
+        mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = rs;
+        mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = rss;
+    }
+    if (stats) {
+        const double mean = s / cnt;
+        double var = (ss - s * mean) / (cnt - 1.);
+        if (var < 0.) var = 0.;
+        stats[(size_t)CNNQ_STAT_MIN * C + c] = (float)mn;
+        stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)mx;
+        stats[(size_t)CNNQ_STAT_MEAN * C + c] = (float)mean;
+        stats[(size_t)CNNQ_STAT_STD * C + c] = (float)sqrt(var);
+        if (has_relu) {
+            double rv = (rss - rs * (rs / cnt)) / (cnt - 1.);
+            if (rv < 0.) rv = 0.;
+            stats[(size_t)CNNQ_STAT_STD_POS * C + c] = (float)sqrt(rv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass B: sum |x - mean| and sum ((x - mean)/std)^4 per channel
+// ------------------------------------------------------------------------------------------
+template <int VEC, int A, int J, bool KURT>
+__global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, const Geo g,
+                                                const float* __restrict__ stats, double* __restrict__ part2) {
+    constexpr int NE = TPB * J * A;
+    __shared__ double l_a[NE];
+    __shared__ double l_k[KURT ? NE : 1];
+    __shared__ float sh_mean[MAXCH], sh_std[MAXCH];
+
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+        sh_mean[i] = stats[(size_t)CNNQ_STAT_MEAN * g.C + b.c0 + i];
+        sh_std[i] = stats[(size_t)CNNQ_STAT_STD * g.C + b.c0 + i];
+    }
+    __syncthreads();
+    int col[J];
+    bool ok[J];
+    float mean[J][A], sd[J][A];
+    double sa[J][A], sk[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+            mean[j][a] = sh_mean[ch];
+            sd[j][a] = sh_std[ch];
+            sa[j][a] = 0.;
+            sk[j][a] = 0.;
+        }
+    }
+    const float* row = x + (size_t)b.n0 * (size_t)g.P;
+#pragma unroll 2
+    for (int n = b.n0; n < b.n1; ++n, row += g.P) {
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                const float d = v[j][e] - mean[j][a];
+                sa[j][a] += (double)fabsf(d);
+                if constexpr (KURT) {
+                    const float z = d / sd[j][a];
+                    const float z2 = z * z;
+                    sk[j][a] += (double)(z2 * z2);
+                }
+            }
+    }
+    auto emit = [&](int ch, double ta, double tk) {
+        double* p = part2 + (size_t)b.grp * CNNQ_NDEV * g.C + ch;
+        p[(size_t)CNNQ_DEV_ABS * g.C] = ta;
+        p[(size_t)CNNQ_DEV_Z4 * g.C] = KURT ? tk : 0.;
+    };
+    const int wv = tid >> 6, lane = tid & 63;
+    if (g.mode == 1) {
+        double ta = 0., tk = 0.;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (ok[j]) { ta += sa[j][0]; tk += sk[j][0]; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { ta += shfl_xor_d(ta, m); tk += shfl_xor_d(tk, m); }
+        if (lane == 0) { l_a[wv] = ta; if constexpr (KURT) l_k[wv] = tk; }
+        __syncthreads();
+        if (tid == 0) {
+            double ra = 0., rk = 0.;
+            for (int i = 0; i < TPB / 64; ++i) { ra += l_a[i]; if constexpr (KURT) rk += l_k[i]; }
+            emit(b.c0, ra, rk);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int e = (j * TPB + tid) * A + a;
+                l_a[e] = sa[j][a];
+                if constexpr (KURT) l_k[e] = sk[j][a];
+            }
+        }
+    __syncthreads();
+    const int epc = g.HW * A / VEC;
+    if (epc <= 16) {
+        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
+            const int lo = (ch - b.c0) * epc;
+            double ra = 0., rk = 0.;
+            for (int e = lo; e < lo + epc; ++e) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
+            emit(ch, ra, rk);
+        }
+        return;
+    }
+    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
+        const int lo = (ch - b.c0) * epc;
+        double ra = 0., rk = 0.;
+        for (int e = lo + lane; e < lo + epc; e += 64) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { ra += shfl_xor_d(ra, m); rk += shfl_xor_d(rk, m); }
+        if (lane == 0) emit(ch, ra, rk);
+    }
+}
+
+__global__ void __launch_bounds__(TPB) k_combine_dev(const double* __restrict__ part2, int G, int C,
+                                                     const double* __restrict__ mom, int want_kurt,
+                                                     double* __restrict__ dev_out, float* __restrict__ stats) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + wv;
+    if (c >= C) return;
+    double sa = 0., sk = 0.;
+    for (int gi = lane; gi < G; gi += 64) {
+        const double* p = part2 + (size_t)gi * CNNQ_NDEV * C + c;
+        sa += p[(size_t)CNNQ_DEV_ABS * C];
+        sk += p[(size_t)CNNQ_DEV_Z4 * C];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { sa += shfl_xor_d(sa, m); sk += shfl_xor_d(sk, m); }
+    if (lane != 0) return;
+    if (dev_out) {
+        dev_out[(size_t)CNNQ_DEV_ABS * C + c] = sa;
+        dev_out[(size_t)CNNQ_DEV_Z4 * C + c] = sk;
+    }
+    if (stats) {
+        const double cnt = mom[(size_t)CNNQ_MOM_COUNT * C + c];
+        stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sa / cnt);
+        if (want_kurt) stats[(size_t)CNNQ_STAT_KURT * C + c] = (float)(sk / cnt - 3.);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// statistics -> scale / zero point / qmax (one workgroup, no host round trips)
+// ------------------------------------------------------------------------------------------
+constexpr int PTPB = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = 0.;
+    for (int i = 0; i < PTPB / 64; ++i) r += sh[i];
+    return r;
+}
+
+__constant__ float c_laplace[9] = {1.05f, 1.86f, 2.83f, 3.89f, 5.03f, 6.2f, 7.41f, 8.64f, 9.89f};
+__constant__ float c_laplace_pos[9] = {1.86f, 2.83f, 3.89f, 5.02f, 6.2f, 7.41f, 8.64f, 9.89f, 11.16f};
+__constant__ float c_gaus[9] = {0.f, 1.24f, 1.71f, 2.15f, 2.55f, 2.93f, 3.28f, 3.61f, 3.92f};
+__constant__ float c_gaus_pos[9] = {0.f, 1.71f, 2.15f, 2.55f, 2.93f, 3.28f, 3.61f, 3.92f, 4.2f};
+
+__global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats, int C, const cnnq_params_cfg cfg,
+                                                 float* __restrict__ qp, float* __restrict__ diag,
+                                                 float* __restrict__ bits_ws) {
+    __shared__ double sh[PTPB / 64];
+    const int tid = threadIdx.x;
+    const float* vmin = stats + (size_t)CNNQ_STAT_MIN * C;
+    const float* vmax = stats + (size_t)CNNQ_STAT_MAX * C;
+    const float* vmean = stats + (size_t)CNNQ_STAT_MEAN * C;
+    const float* vstd = stats + (size_t)CNNQ_STAT_STD * C;
+    const float* vb = stats + (size_t)CNNQ_STAT_B * C;
+    const bool ba = cfg.bit_alloc && cfg.num_bits <= 4;
+
+    if (ba) {
+        // fixed-target bit allocation, iq.py:381-407 (fp32 tensor math, double target)
+        const float* prior = cfg.prior_is_b ? vb : vstd;
+        const float goal = (float)cfg.target;
+        double target = cfg.target;
+        double delta = 1.;
+        // p = prior^(2/3) and its sum do not change between iterations
+        double psum_d = 0.;
+        for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(prior[c], (float)(2. / 3));
+        const float psum = (float)block_sum(psum_d, sh);
+        for (int it = 0; it < 10 && fabs(2. * delta) > 0.01; ++it) {
+            const float B = (float)((double)C * pow(2., target));
+            double bsum = 0.;
+            for (int c = tid; c < C; c += PTPB) {
+                const float p = powf(prior[c], (float)(2. / 3));
+                const float bins = (B * p) / psum;
+                float bits = cfg.round_mode ? rintf(log2f(bins)) : ceilf(log2f(bins));
+                if (bits < 0.f) bits = 0.f;
+                if (bits > 8.f) bits = 8.f;
+                bits_ws[c] = bits;
+                bsum += (double)bits;
+            }
+            const float mean_bits = (float)block_sum(bsum, sh) / (float)C;
+            delta = (double)((goal - mean_bits) / 2.f);
+            target += delta;
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < C; c += PTPB) {
+        const float bits = ba ? bits_ws[c] : (float)cfg.num_bits;
+        float alpha = 0.f, delta, offset;
+        if (cfg.clip == 0) {
+            offset = cfg.positive ? 0.f : vmin[c];
+            delta = vmax[c] - offset;
+        } else {
+            if (cfg.clip == 1) {
+                const int ib = (int)bits;  // NaN bits cannot occur: clamped comparisons leave 0..8
+                alpha = vb[c] * (cfg.positive ? c_laplace_pos[ib] : c_laplace[ib]);
+            } else if (cfg.clip == 2) {
+                alpha = vstd[c] * (cfg.positive ? c_gaus_pos[cfg.num_bits] : c_gaus[cfg.num_bits]);
+            } else {
+                alpha = cfg.pstd * vstd[c];
+            }
+            float range;
+            if (cfg.positive) {
+                range = fmaxf(vmean[c], 0.f) + alpha;
+                offset = 0.f;
+            } else {
+                range = 2.f * alpha;
+                offset = fmaxf(vmin[c], vmean[c] - alpha);
+            }
+            const float mx = offset + range;                   // iq.py:351
+            delta = cfg.direct_range ? range : mx - offset;    // iq.py:443 (per channel) / :357 (per tensor)
+        }
+        float qmax, scale;
+        if (ba) {
+            qmax = exp2f(bits) - 1.f;
+            scale = (qmax > 0.f) ? delta / qmax : 0.f;
+        } else {
+            qmax = (float)((1u << cfg.num_bits) - 1u);
+            scale = delta / qmax;
+        }
+        scale = (scale < 1e-8f) ? 1e-8f : scale;  // NaN stays NaN, as torch.max does
+        const float zp = rintf(0.f - offset / scale);
+        qp[(size_t)CNNQ_QP_SCALE * C + c] = scale;
+        qp[(size_t)CNNQ_QP_ZP * C + c] = zp;
+        qp[(size_t)CNNQ_QP_QMAX * C + c] = qmax;
+        if (diag) {
+            diag[(size_t)CNNQ_DIAG_BITS * C + c] = bits;
+            diag[(size_t)CNNQ_DIAG_ALPHA * C + c] = alpha;
+            diag[(size_t)CNNQ_DIAG_DELTA * C + c] = delta;
+            diag[(size_t)CNNQ_DIAG_OFFSET * C + c] = offset;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the core: fused per-channel quantize -> clamp -> round -> dequantize on native NCHW
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax, float& code) {
+    float q = x / scale;         // IEEE divide (v_div_scale / v_rcp / v_fma.. / v_div_fixup)
+    q = q + zp;                  // separately rounded (-ffp-contract=off)
+    q = (q > qmax) ? qmax : q;   // compare+select keeps NaN like torch.clamp / torch.where
+    q = (q < 0.f) ? 0.f : q;
+    q = rintf(q);                // v_rndne_f32: half to even, as torch.round
+    code = q;
+    return (q - zp) * scale;
+}
+
+// Code histogram (for the Shannon entropy of utils/entropy.py:6-17): 256 bins x 32 replicas in
+// LDS, replica = lane & 31 so the 32 lanes of a service group hit 32 different banks (no
+// conflicts however skewed the codes are); replicas are summed and flushed once per workgroup.
+constexpr int HREP = 32;
+
+template <int VEC, int A, int J, bool CODES, bool HIST>
+__global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
+                                             const float* __restrict__ qp, uint8_t* __restrict__ codes,
+                                             unsigned long long* __restrict__ hist) {
+    __shared__ float sh_sc[MAXCH], sh_zp[MAXCH], sh_qm[MAXCH];
+    __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    if constexpr (HIST) {
+        for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
+    }
+    // stage this workgroup's channels once: coalesced reads of the three parameter rows
+    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+        sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+        sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+        sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+    }
+    __syncthreads();
+    int col[J];
+    bool ok[J];
+    float sc[J][A], zp[J][A], qm[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+            sc[j][a] = sh_sc[ch];
+            zp[j][a] = sh_zp[ch];
+            qm[j][a] = sh_qm[ch];
+        }
+    }
+    size_t off = (size_t)b.n0 * (size_t)g.P;
+#pragma unroll 2
+    for (int n = b.n0; n < b.n1; ++n, off += g.P) {
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float o[VEC], cd[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                o[e] = qdq1(v[j][e], sc[j][a], zp[j][a], qm[j][a], cd[e]);
+            }
+            if (ok[j]) {
+                stv<VEC>(y + off + (size_t)col[j] * VEC, o);
+                if constexpr (HIST) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        atomicAdd(&sh_hist[((unsigned)(int)cd[e] & 255u) * HREP + (tid & (HREP - 1))], 1u);
+                }
+                if constexpr (CODES) {
+                    uint8_t* cp = codes + off + (size_t)col[j] * VEC;
+                    if constexpr (VEC == 4) {
+                        const uint32_t pk = (uint32_t)cd[0] | ((uint32_t)cd[1] << 8) | ((uint32_t)cd[2] << 16) |
+                                            ((uint32_t)cd[3] << 24);
+                        *reinterpret_cast<uint32_t*>(cp) = pk;
+                    } else {
+                        *cp = (uint8_t)cd[0];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        unsigned tot = 0;
+#pragma unroll 8
+        for (int r = 0; r < HREP; ++r) tot += sh_hist[tid * HREP + ((r + tid) & (HREP - 1))];
+        if (tot) atomicAdd(&hist[tid], (unsigned long long)tot);
+    }
+}
+
+// Shannon entropy (bits) of a histogram: -sum p log2 p over the non-empty bins
+__global__ void __launch_bounds__(TPB) k_entropy(const unsigned long long* __restrict__ hist, int nbins,
+                                                 float* __restrict__ out) {
+    __shared__ double sh[TPB / 64];
+    __shared__ double sh_total;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    double t = 0.;
+    for (int i = tid; i < nbins; i += TPB) t += (double)hist[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += shfl_xor_d(t, m);
+    if (lane == 0) sh[wv] = t;
+    __syncthreads();
+    if (tid == 0) sh_total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    const float total = (float)sh_total;
+    double e = 0.;
+    for (int i = tid; i < nbins; i += TPB) {
+        const unsigned long long c = hist[i];
+        if (c) {
+            const float pr = (float)c / total;
+            e += (double)(-pr * log2f(pr));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) e += shfl_xor_d(e, m);
+    __syncthreads();
+    if (lane == 0) sh[wv] = e;
+    __syncthreads();
+    if (tid == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-tensor GEMMLOWP path (replaces kernels/gemmlowp.cu)
+// ------------------------------------------------------------------------------------------
+// ptp: [0] scale [1] shift [2] qmax [3] true-zero flag [4] passthrough flag [5] range [6] offset
+__global__ void __launch_bounds__(64) k_pt_setup(int have_host, float h_range, float h_offset,
+                                                 const float* __restrict__ stats, int64_t stride, int rows,
+                                                 int rows_mode, int zero_min, int num_bits, int int_exp, int etz,
+                                                 float* __restrict__ ptp) {
+    const int lane = threadIdx.x;
+    float range, offset;
+    bool ptz;
+    if (have_host) {
+        range = h_range;
+        offset = h_offset;
+        ptz = etz != 0;
+    } else {
+        const float* vmin = stats + (size_t)CNNQ_STAT_MIN * stride;
+        const float* vmax = stats + (size_t)CNNQ_STAT_MAX * stride;
+        float mn, mx;
+        if (rows_mode == 0) {  // per-sample then mean over the batch (iq.py:515-526)
+            double smn = 0., smx = 0.;
+            for (int r = lane; r < rows; r += 64) { smn += (double)vmin[r]; smx += (double)vmax[r]; }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { smn += shfl_xor_d(smn, m); smx += shfl_xor_d(smx, m); }
+            mn = (float)(smn / (double)rows);
+            mx = (float)(smx / (double)rows);
+        } else {  // whole tensor
+            mn = INFINITY; mx = -INFINITY;
+            for (int r = lane; r < rows; r += 64) { mn = fminf(mn, vmin[r]); mx = fmaxf(mx, vmax[r]); }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, shfl_xor_f(mn, m)); mx = fmaxf(mx, shfl_xor_f(mx, m)); }
+        }
+        if (zero_min) mn = 0.f;
+        range = mx - mn;   // iq.py:379
+        offset = mn;
+        ptz = etz && ((offset + range) > 0.f) && (offset < 0.f);  // iq.py:613
+    }
+    if (lane != 0) return;
+    const float qmax = (float)((1ll << num_bits) - 1);
+    float scale = range / qmax;
+    if (int_exp) scale = powf(2.f, (float)(int)ceilf(log2f(scale)));
+    const float zero_point = roundf(-offset / scale);
+    ptp[0] = scale;
+    ptp[1] = ptz ? zero_point : -offset;
+    ptp[2] = qmax;
+    ptp[3] = ptz ? 1.f : 0.f;
+    ptp[4] = (range <= 0.f) ? 1.f : 0.f;
+    ptp[5] = range;
+    ptp[6] = offset;
+    ptp[7] = 0.f;
+}
+
+__device__ __forceinline__ float ptq1(float v, float scale, float shift, float qmax, bool etz, float nz) {
+    float t = etz ? (v / scale) + shift : (v + shift) / scale;
+    t = t + nz;  // the reference always adds the noise tensor (zeros when not stochastic)
+    t = fminf(t, qmax);
+    t = fmaxf(t, 0.f);
+    t = roundf(t);
+    return etz ? (t - shift) * scale : t * scale - shift;
+}
+
+template <int VEC, bool NOISE>
+__global__ void __launch_bounds__(TPB) k_pt_qdq(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                const float* __restrict__ ptp, const float* __restrict__ noise) {
+    const float scale = ptp[0], shift = ptp[1], qmax = ptp[2];
+    const bool etz = ptp[3] != 0.f, pass = ptp[4] != 0.f;
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += stride) {
+        float v[VEC], z[VEC], o[VEC];
+        ldv<VEC>(x + i * VEC, v);
+        if constexpr (NOISE) ldv<VEC>(noise + i * VEC, z);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = pass ? v[e] : ptq1(v[e], scale, shift, qmax, etz, NOISE ? z[e] : 0.f);
+        stv<VEC>(y + i * VEC, o);
+    }
+    if constexpr (VEC > 1) {  // tail
+        const int64_t i = nv * VEC + (int64_t)blockIdx.x * TPB + threadIdx.x;
+        if (i < n) y[i] = pass ? x[i] : ptq1(x[i], scale, shift, qmax, etz, NOISE ? noise[i] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: geometry and launches
+// ------------------------------------------------------------------------------------------
+int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+int choose_variant(int64_t C, int64_t HW, bool aligned16, Variant* v) {
+    if (aligned16 && HW % 4 == 0) { *v = {4, 1, 4}; return 0; }
+    if (aligned16 && (C * HW) % 4 == 0) {
+        const int m = 4 / gcd_i((int)(HW % 4), 4);
+        if ((int64_t)m * HW <= TPB * 4) { *v = {4, 4, 1}; return 0; }
+    }
+    *v = {1, 1, 4};
+    return 0;
+}
+
+int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, Geo* g) {
+    if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
+    if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    g->N = (int)N; g->C = (int)C; g->HW = (int)HW; g->P = (int)(C * HW);
+    g->nb = 1; g->w = 0; g->k = 1;
+    const int cap = TPB * v.J;  // loads per block per sample
+    if (v.A == 4) {             // straddle: k whole channels with k*HW % 4 == 0
+        const int m = 4 / gcd_i((int)(HW % 4), 4);
+        int k = (int)((cap * 4) / HW);
+        k -= k % m;
+        g->mode = 2;
+        g->k = k;
+        g->ncb = (int)((C + k - 1) / k);
+    } else {
+        const int64_t cpc = HW / v.vec;
+        if (cpc > cap) {
+            g->mode = 1;
+            int64_t nb = (cpc + cap - 1) / cap;
+            const int64_t w = (cpc + nb - 1) / nb;
+            nb = (cpc + w - 1) / w;
+            if (C * nb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+            g->nb = (int)nb;
+            g->w = (int)w;
+            g->ncb = (int)(C * nb);
+        } else {
+            g->mode = 2;
+            g->k = (int)(cap / cpc);
+            g->ncb = (int)((C + g->k - 1) / g->k);
+        }
+    }
+    // enough workgroups to fill 256 CUs several times over, but few enough partial groups
+    const int64_t target = 4096;
+    int64_t S = (target + g->ncb - 1) / g->ncb;
+    if (S > N) S = N;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    g->S = (int)S;
+    if ((int64_t)g->S * g->ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    return 0;
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+const char* cnnq_version(void) { return "cnnq-hip 0.1 gfx950"; }
+
+int cnnq_pc_groups(int64_t N, int64_t C, int64_t HW, int aligned16) {
+    Variant v;
+    Geo g;
+    choose_variant(C, HW, aligned16 != 0, &v);
+    const int rc = make_geo(N, C, HW, v, &g);
+    if (rc) return rc;
+    return g.S * g.nb;
+}
+
+int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_relu, double* part, void* stream) {
+    if (!x || !part) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    choose_variant(C, HW, al16(x), &v);
+    const int rc = make_geo(N, C, HW, v, &g);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_MOM(VEC, A, J)                                                                          \
+    do {                                                                                               \
+        if (want_relu) hipLaunchKernelGGL((k_moments<VEC, A, J, true>), grid, block, 0, st, x, g, part); \
+        else hipLaunchKernelGGL((k_moments<VEC, A, J, false>), grid, block, 0, st, x, g, part);          \
+    } while (0)
+    if (v.vec == 4 && v.A == 1) LAUNCH_MOM(4, 1, 4);
+    else if (v.vec == 4) LAUNCH_MOM(4, 4, 1);
+    else LAUNCH_MOM(1, 1, 4);
+#undef LAUNCH_MOM
+    return launch_status();
+}
+
+int cnnq_pc_combine(const double* part, int G, int64_t C, int has_relu, double* mom, float* stats, void* stream) {
+    if (!part || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!mom && !stats)) return CNNQ_EINVAL;
+    const dim3 grid((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), block(TPB);
+    hipLaunchKernelGGL(k_combine, grid, block, 0, (hipStream_t)stream, part, G, (int)C, has_relu, mom, stats);
+    return launch_status();
+}
+
+int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float* stats, int want_kurt,
+                   double* part2, void* stream) {
+    if (!x || !stats || !part2) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    choose_variant(C, HW, al16(x), &v);
+    const int rc = make_geo(N, C, HW, v, &g);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_DEV(VEC, A, J)                                                                                  \
+    do {                                                                                                       \
+        if (want_kurt) hipLaunchKernelGGL((k_absdev<VEC, A, J, true>), grid, block, 0, st, x, g, stats, part2);  \
+        else hipLaunchKernelGGL((k_absdev<VEC, A, J, false>), grid, block, 0, st, x, g, stats, part2);           \
+    } while (0)
+    if (v.vec == 4 && v.A == 1) LAUNCH_DEV(4, 1, 4);
+    else if (v.vec == 4) LAUNCH_DEV(4, 4, 1);
+    else LAUNCH_DEV(1, 1, 4);
+#undef LAUNCH_DEV
+    return launch_status();
+}
+
+int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom, int want_kurt, double* dev_out,
+                        float* stats, void* stream) {
+    if (!part2 || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!dev_out && !stats) || (stats && !mom))
+        return CNNQ_EINVAL;
+    const dim3 grid((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), block(TPB);
+    hipLaunchKernelGGL(k_combine_dev, grid, block, 0, (hipStream_t)stream, part2, G, (int)C, mom, want_kurt, dev_out,
+                       stats);
+    return launch_status();
+}
+
+int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg, float* qp, float* diag,
+                   void* stream) {
+    if (!stats || !cfg || !qp || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
+    if (cfg->num_bits < 1 || cfg->num_bits > 8 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
+    if (cfg->bit_alloc && cfg->num_bits <= 4 && !diag) return CNNQ_EINVAL;  // bit table lives in diag
+    float* bits_ws = diag ? diag + (size_t)CNNQ_DIAG_BITS * C : nullptr;
+    hipLaunchKernelGGL(k_params, dim3(1), dim3(PTPB), 0, (hipStream_t)stream, stats, (int)C, *cfg, qp, diag,
+                       bits_ws);
+    return launch_status();
+}
+
+int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, uint8_t* codes,
+                uint64_t* hist, void* stream) {
+    if (!x || !y || !qp) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    choose_variant(C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), &v);
+    const int rc = make_geo(N, C, HW, v, &g);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* h = reinterpret_cast<unsigned long long*>(hist);
+#define LAUNCH_QDQ(VEC, A, J)                                                                                       \
+    do {                                                                                                            \
+        if (codes && h) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, true>), grid, block, 0, st, x, y, g, qp, codes, h); \
+        else if (codes) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, false>), grid, block, 0, st, x, y, g, qp, codes, h); \
+        else if (h) hipLaunchKernelGGL((k_qdq<VEC, A, J, false, true>), grid, block, 0, st, x, y, g, qp, codes, h);  \
+        else hipLaunchKernelGGL((k_qdq<VEC, A, J, false, false>), grid, block, 0, st, x, y, g, qp, codes, h);        \
+    } while (0)
+    if (v.vec == 4 && v.A == 1) LAUNCH_QDQ(4, 1, 4);
+    else if (v.vec == 4) LAUNCH_QDQ(4, 4, 1);
+    else LAUNCH_QDQ(1, 1, 4);
+#undef LAUNCH_QDQ
+    return launch_status();
+}
+
+int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream) {
+    if (!hist || !out || nbins <= 0) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_entropy, dim3(1), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(hist), nbins, out);
+    return launch_status();
+}
+
+int cnnq_pt_setup(const float* range_offset_host, const float* stats, int64_t stats_stride, int rows, int rows_mode,
+                  int zero_min, int num_bits, int int_exp, int enforce_true_zero, float* ptp, void* stream) {
+    if (!ptp || num_bits < 1 || num_bits > 31) return CNNQ_EINVAL;
+    if (!range_offset_host && (!stats || rows <= 0 || stats_stride < rows)) return CNNQ_EINVAL;
+    const float hr = range_offset_host ? range_offset_host[0] : 0.f;
+    const float ho = range_offset_host ? range_offset_host[1] : 0.f;
+    hipLaunchKernelGGL(k_pt_setup, dim3(1), dim3(64), 0, (hipStream_t)stream, range_offset_host ? 1 : 0, hr, ho,
+                       stats, stats_stride, rows, rows_mode, zero_min, num_bits, int_exp, enforce_true_zero, ptp);
+    return launch_status();
+}
+
+int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const float* noise, void* stream) {
+    if (!x || !y || !ptp || n <= 0) return CNNQ_EINVAL;
+    const bool vec = al16(x) && al16(y) && (!noise || al16(noise));
+    const int64_t work = vec ? (n + 3) / 4 : n;
+    int64_t blocks = (work + TPB - 1) / TPB;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const dim3 grid((unsigned)blocks), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) {
+        if (noise) hipLaunchKernelGGL((k_pt_qdq<4, true>), grid, block, 0, st, x, y, n, ptp, noise);
+        else hipLaunchKernelGGL((k_pt_qdq<4, false>), grid, block, 0, st, x, y, n, ptp, noise);
+    } else {
+        if (noise) hipLaunchKernelGGL((k_pt_qdq<1, true>), grid, block, 0, st, x, y, n, ptp, noise);
+        else hipLaunchKernelGGL((k_pt_qdq<1, false>), grid, block, 0, st, x, y, n, ptp, noise);
+    }
+    return launch_status();
+}
+
+}  // extern "C"

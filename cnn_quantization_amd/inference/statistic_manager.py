@@ -1,0 +1,99 @@
+"""Per-tensor calibration statistics (CSV), mirror of
+pytorch_quantizer/quantization/inference/statistic_manager.py: same API and file layout
+(`~/mxt-sim/statistics/<name>/<name>_summary.csv`, columns {min,mean,max}_<stat> indexed by layer
+id).  Serves the per-tensor quantizers (pooling, classifier, linear) in `-sm use` mode.
+
+The scalar statistics of a batch are one pass of the device kernels over the tensor viewed as a
+single channel; the error/KLD columns of the reference (mse_*, cos_*, kld_th) are calibration
+diagnostics outside the hot path and are not produced."""
+import os
+import shutil
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+from .. import _lib as L
+from .. import ops
+from ..utils.misc import Singleton, sorted_nicely
+
+
+def base_dir():
+    return os.path.join(str(Path.home()), 'mxt-sim')
+
+
+class StatisticManager(metaclass=Singleton):
+    def __init__(self, folder, load_stats, stats=('max', 'min', 'std', 'mean', 'kurtosis', 'mean_abs', 'b', 'dim'),
+                 batch_avg=False, kld_threshold=False, collect_err=False):
+        self.name = folder
+        self.folder = os.path.join(base_dir(), 'statistics', folder)
+        self.stats_names = list(stats)
+        if kld_threshold or collect_err:
+            raise NotImplementedError('KLD thresholds / error columns are outside the hot path')
+        self.batch_avg = batch_avg
+        self.stats = {}
+        self.metadata = {}
+        self.save_stats = not load_stats
+        if load_stats:
+            stats_file = os.path.join(self.folder, '%s_summary.csv' % self.name)
+            assert os.path.exists(stats_file), stats_file
+            self.stats_df = pd.read_csv(stats_file, index_col=0)
+        else:
+            self.stats_df = None
+
+    def save_tensor_stats(self, tensor, tag, id, tensors_q={}, force_global_min_max=False):
+        x = tensor.detach().contiguous()
+        n = x.numel()
+        table, mom = ops.pc_stats(x, 1, 1, n, need_b=True, need_kurt=True, need_relu=True)
+        host = table.cpu().numpy()[:, 0]
+        m = mom.cpu().numpy()[:, 0]
+        vals = {'max': host[L.STAT_MAX], 'min': host[L.STAT_MIN], 'std': host[L.STAT_STD],
+                'mean': host[L.STAT_MEAN], 'kurtosis': host[L.STAT_KURT], 'b': host[L.STAT_B],
+                'mean_abs': np.float32((2. * m[L.MOM_SUM_RELU] - m[L.MOM_SUM]) / n), 'dim': n}
+        if self.batch_avg and not force_global_min_max and x.dim() > 1:
+            rows, _ = ops.pc_stats(x, 1, x.shape[0], n // x.shape[0], local_only=True)
+            r = rows.cpu().numpy()
+            vals['max'] = r[L.STAT_MAX].mean(dtype=np.float32)
+            vals['min'] = r[L.STAT_MIN].mean(dtype=np.float32)
+        row = np.array([[vals[s] for s in self.stats_names]], dtype=np.float64)
+        if id in self.stats:
+            self.stats[id] = np.concatenate([self.stats[id], row])
+        else:
+            self.stats[id] = row
+            self.metadata[id] = tag
+
+    def get_tensor_stat(self, id, stat, kind='mean'):
+        if self.stats_df is not None:
+            return self.stats_df.loc[id, '%s_%s' % (kind, stat)]
+        return None
+
+    def get_tensor_stats(self, id, kind=None):
+        kind = kind or {}
+        if self.stats_df is None:
+            return (None,) * 6
+        return tuple(self.stats_df.loc[id, '%s_%s' % (kind.get(s, 'mean'), s)]
+                     for s in ('min', 'max', 'mean', 'std', 'mean_abs', 'b'))
+
+    def __exit__(self, *args):
+        if not self.save_stats:
+            return
+        if os.path.exists(self.folder):
+            shutil.rmtree(self.folder)
+        os.makedirs(self.folder)
+        frames = {}
+        for s_id in self.stats:
+            df = pd.DataFrame(columns=self.stats_names, data=self.stats[s_id])
+            df.to_csv(os.path.join(self.folder, '%s.csv' % s_id), index=False)
+            frames[s_id] = df
+        columns = []
+        for c in self.stats_names:
+            columns += ['min_%s' % c, 'mean_%s' % c, 'max_%s' % c]
+        summary = pd.DataFrame(columns=['internal_name'] + columns)
+        for s_id in sorted_nicely(frames.keys()):
+            summary.loc[s_id, 'internal_name'] = self.metadata[s_id]
+            for c in self.stats_names:
+                summary.loc[s_id, 'min_%s' % c] = frames[s_id][c].min()
+                summary.loc[s_id, 'mean_%s' % c] = frames[s_id][c].mean()
+                summary.loc[s_id, 'max_%s' % c] = frames[s_id][c].max()
+            summary.loc[s_id, 'dim'] = frames[s_id]['dim'][0]
+        summary.to_csv(os.path.join(self.folder, '%s_summary.csv' % self.name), index=True)

@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the C ABI (include/cnnq_hip.h): device pointers, sizes and the
+current HIP stream go straight to libcnnq_hip.so.  torch supplies memory and streams only.
+
+No function here synchronises with the host; none has a CPU path - CPU tensors are rejected
+and a missing library raises (cnn_quantization_amd._lib.load)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import distributed as D
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev_f32(x, what='tensor'):
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise L.CnnqError('%s must be a CUDA/HIP tensor (there is no CPU path)' % what)
+    if x.dtype != torch.float32:
+        raise L.CnnqError('%s must be float32, got %s' % (what, x.dtype))
+    return x.detach().contiguous()
+
+
+def geometry(x, per_channel_dim=1):
+    """(N, C, HW) of a tensor addressed as x[N][C][HW].  4-D activations: channel dim 1.
+    per_channel_dim=0 (weights [OFM, ...], iq.py:455): N = 1, C = OFM."""
+    if per_channel_dim == 0:
+        return 1, x.shape[0], x.numel() // x.shape[0]
+    n, c = x.shape[0], x.shape[1]
+    return n, c, x.numel() // (n * c)
+
+
+# ------------------------------------------------------------------------------------- statistics
+def pc_moments(x, N, C, HW, want_relu=False):
+    """Pass A partial records [G, NMOM, C] (float64)."""
+    lib = L.load()
+    G = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+    if G <= 0:
+        L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    part = torch.empty((G, L.NMOM, C), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_pc_moments(_ptr(x), N, C, HW, int(want_relu), _ptr(part), _stream(x)), 'cnnq_pc_moments')
+    return part
+
+
+def pc_combine(part, has_relu=False, stats=None, want_mom=True):
+    """Merge [G, NMOM, C] records -> (mom [NMOM, C] f64, stats [NSTAT, C] f32)."""
+    lib = L.load()
+    G, _, C = part.shape
+    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=part.device) if want_mom else None
+    if stats is None:
+        stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=part.device)
+    L.check(lib.cnnq_pc_combine(_ptr(part), G, C, int(has_relu), _ptr(mom), _ptr(stats), _stream(part)),
+            'cnnq_pc_combine')
+    return mom, stats
+
+
+def pc_absdev(x, N, C, HW, stats, want_kurt=False):
+    lib = L.load()
+    G = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+    part2 = torch.empty((G, L.NDEV, C), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_pc_absdev(_ptr(x), N, C, HW, _ptr(stats), int(want_kurt), _ptr(part2), _stream(x)),
+            'cnnq_pc_absdev')
+    return part2
+
+
+def pc_combine_dev(part2, mom, stats=None, want_kurt=False, want_sums=False):
+    lib = L.load()
+    G, _, C = part2.shape
+    dev = torch.empty((L.NDEV, C), dtype=torch.float64, device=part2.device) if want_sums else None
+    L.check(lib.cnnq_pc_combine_dev(_ptr(part2), G, C, _ptr(mom), int(want_kurt), _ptr(dev), _ptr(stats),
+                                    _stream(part2)), 'cnnq_pc_combine_dev')
+    return dev
+
+
+def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=None, local_only=False):
+    """Per-channel statistics table [NSTAT, C] of x[N][C][HW] (rows MIN, MAX, MEAN, STD always;
+    B / KURT / STD_POS on request) plus the merged moment record [NMOM, C].
+
+    With a process group of world size > 1 the tensor is this rank's batch shard: the fp64
+    moment records are all-gathered (<= 7*C*8 bytes per rank, latency-bound on xGMI) and merged
+    in rank order on every rank, so all ranks hold the statistics of the GLOBAL batch."""
+    x = _dev_f32(x, 'x')
+    part = pc_moments(x, N, C, HW, need_relu)
+    world = 1 if local_only else D.world_size(group)
+    if world > 1:
+        mom_local, _ = pc_combine(part, need_relu)
+        part = D.all_gather_records(mom_local, group)
+    mom, stats = pc_combine(part, need_relu)
+    if need_b or need_kurt:
+        part2 = pc_absdev(x, N, C, HW, stats, need_kurt)
+        if world > 1:
+            dev_local = pc_combine_dev(part2, mom, None, need_kurt, want_sums=True)
+            part2 = D.all_gather_records(dev_local, group)
+        pc_combine_dev(part2, mom, stats, need_kurt)
+    return stats, mom
+
+
+# ------------------------------------------------------------------------------------- parameters
+CLIP_CODES = {'no': 0, 'laplace': 1, 'gaus': 2}
+
+
+def pc_params(stats, num_bits, positive=False, clip='no', bit_alloc=False, prior_is_b=False, target=None,
+              round_mode=True, direct_range=False):
+    """stats [NSTAT, C] -> (qp [NQP, C], diag [NDIAG, C]); see cnnq_pc_params."""
+    lib = L.load()
+    C = stats.shape[1]
+    cfg = L.ParamsCfg()
+    cfg.num_bits = int(num_bits)
+    cfg.positive = int(bool(positive))
+    if clip in CLIP_CODES:
+        cfg.clip, cfg.pstd = CLIP_CODES[clip], 0.
+    elif 'std' in clip:
+        cfg.clip, cfg.pstd = 3, float(clip.replace('std', ''))
+    else:
+        raise L.CnnqError('unsupported clipping %r' % (clip,))
+    cfg.bit_alloc = int(bool(bit_alloc))
+    cfg.prior_is_b = int(bool(prior_is_b))
+    cfg.target = float(num_bits if target is None else target)
+    cfg.round_mode = int(bool(round_mode))
+    cfg.direct_range = int(bool(direct_range))
+    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=stats.device)
+    diag = torch.empty((L.NDIAG, C), dtype=torch.float32, device=stats.device)
+    L.check(lib.cnnq_pc_params(_ptr(stats), C, ctypes.byref(cfg), _ptr(qp), _ptr(diag), _stream(stats)),
+            'cnnq_pc_params')
+    return qp, diag
+
+
+# ------------------------------------------------------------------------------------- Q/DQ
+def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None):
+    """y = dequant(quant(x)) with per-channel parameters; optionally the uint8 codes; `hist`
+    (optional zeroed int64[256] tensor) receives the code histogram."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    y = torch.empty_like(x) if out is None else out
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+    L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)),
+            'cnnq_pc_qdq')
+    return (y, codes) if want_codes else y
+
+
+def entropy_from_hist(hist):
+    """Shannon entropy (bits) of an int64 histogram tensor -> 0-dim float32 tensor on the device."""
+    lib = L.load()
+    out = torch.empty(1, dtype=torch.float32, device=hist.device)
+    L.check(lib.cnnq_entropy(_ptr(hist), hist.numel(), _ptr(out), _stream(hist)), 'cnnq_entropy')
+    return out[0]
+
+
+def pt_setup(device, num_bits, range_offset=None, stats=None, rows=0, rows_mode=0, zero_min=False,
+             int_exp=False, enforce_true_zero=True):
+    """Per-tensor parameters ptp[8] on the device from host scalars or from per-row stats."""
+    lib = L.load()
+    ptp = torch.empty(8, dtype=torch.float32, device=device)
+    ro = None
+    if range_offset is not None:
+        ro = (ctypes.c_float * 2)(float(range_offset[0]), float(range_offset[1]))
+    stride = stats.shape[1] if stats is not None else 0
+    L.check(lib.cnnq_pt_setup(ro, _ptr(stats), stride, int(rows), int(rows_mode), int(bool(zero_min)),
+                              int(num_bits), int(bool(int_exp)), int(bool(enforce_true_zero)), _ptr(ptp),
+                              _stream(ptp)), 'cnnq_pt_setup')
+    return ptp
+
+
+def pt_qdq(x, ptp, noise=None, out=None):
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    y = torch.empty_like(x) if out is None else out
+    if noise is not None:
+        noise = _dev_f32(noise, 'noise')
+    if x.numel() == 0:
+        return y
+    L.check(lib.cnnq_pt_qdq(_ptr(x), _ptr(y), x.numel(), _ptr(ptp), _ptr(noise), _stream(x)), 'cnnq_pt_qdq')
+    return y
+
+
+# ------------------------------------------------------------------------------------- pipelines
+def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False, prior_is_b=False, target=None,
+                        round_mode=True, per_channel_dim=1, group=None, want_codes=False, want_parts=False,
+                        stats=None, want_entropy=False, whole_tensor=False):
+    """The dynamic per-channel hot path end to end: statistics (one or two coalesced reads of
+    x) -> parameters (one workgroup) -> fused Q/DQ (one read, one write).  Covers iq.py:409-451
+    (clip='no'), iq.py:327-352 (ACIQ) and, with per_channel_dim=0, the weights of iq.py:453-476;
+    whole_tensor=True treats the tensor as ONE channel (per-tensor clipping, iq.py:353-357).
+    `stats` (optional [NSTAT, C] table, e.g. from a calibration file) replaces the dynamic
+    statistics.  group=False: never exchange (replicated data such as weights).
+    Returns y [, codes] [, entropy (0-dim device tensor)] [, parts].  No host synchronisation."""
+    x = _dev_f32(x, 'x')
+    N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x, per_channel_dim)
+    use_ba = bool(bit_alloc) and num_bits <= 4 and not whole_tensor
+    if stats is None:
+        need_b = (clip == 'laplace') or (use_ba and prior_is_b)
+        stats, _ = pc_stats(x, N, C, HW, need_b=need_b, group=None if group is False else group,
+                            local_only=group is False)
+    qp, diag = pc_params(stats, num_bits, positive, clip, use_ba, prior_is_b, target, round_mode,
+                         direct_range=whole_tensor)
+    hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
+    res = pc_qdq(x, N, C, HW, qp, want_codes, hist=hist)
+    out = list(res) if want_codes else [res]
+    if want_entropy:
+        if D.world_size(None if group is False else group) > 1 and group is not False:
+            D.all_reduce_sum_(hist, group)
+        out.append(entropy_from_hist(hist))
+    if want_parts:
+        out.append(dict(stats=stats, qp=qp, diag=diag))
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, group=None, want_entropy=False):
+    raise NotImplementedError('mid-tread quantization (iq.py:185-225) is not built yet')
+
+
+def tensor_row_stats(x, rows):
+    """Per-row MIN/MAX (and friends) of x viewed as [rows, numel/rows]: the per-sample statistics
+    of iq.py:510-517 (rows = batch) - the per-channel kernels with N = 1, C = rows."""
+    x = _dev_f32(x, 'x')
+    stats, _ = pc_stats(x, 1, rows, x.numel() // rows)
+    return stats
+
+
+def minmax_qdq_per_tensor(x, num_bits, avg_over_batch, zero_min=False, int_exp=False, enforce_true_zero=True,
+                          group=None):
+    """iq.py:361-379 + 605-614 with dynamic statistics: per-sample min/max, their batch mean
+    (or the whole-tensor min/max), then the GEMMLOWP kernel - all on the device."""
+    x = _dev_f32(x, 'x')
+    rows = x.shape[0] if x.dim() > 1 else 1
+    stats = tensor_row_stats(x, rows)
+    if D.world_size(group) > 1:
+        stats = D.merge_row_minmax(stats, rows, avg_over_batch, group)
+        rows = stats.shape[1]
+    ptp = pt_setup(x.device, num_bits, stats=stats, rows=rows, rows_mode=0 if avg_over_batch else 1,
+                   zero_min=zero_min, int_exp=int_exp, enforce_true_zero=enforce_true_zero)
+    return pt_qdq(x, ptp)

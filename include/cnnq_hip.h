@@ -1,0 +1,169 @@
+/*
+ * cnnq_hip.h - C ABI of libcnnq_hip.so: MI355X (gfx950) kernels for the GEMMLOWP-style
+ * per-channel quantize / clip / dequantize hot path of submission2019/cnn-quantization.
+ *
+ * This is the drop-in boundary.  The reference's only native module is
+ *     kernels/int_quantization.cpp:10-12  ->  float2gemmlowp(in, range, offset, num_bits,
+ *                                             int_exp, enforce_true_zero, noise)
+ *     kernels/gemmlowp.cu:8-45            (kernel + host wrapper)
+ * which cnnq_pt_qdq replaces one for one.  Everything else the reference does on this path
+ * is a chain of aten ops inside pytorch_quantizer/quantization/qtypes/int_quantizer.py
+ * (abbreviated iq.py) and pytorch_quantizer/quantization/inference/
+ * statistic_manager_perchannel.py (smpc.py); each entry point below names the lines it fuses.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - activations are fp32 NCHW, addressed as x[N][C][HW] (HW = H*W contiguous floats);
+ *     weights [OFM][IFM*K*K] are the same layout with N = 1, C = OFM;
+ *     per-sample statistics of any tensor are the same layout with N = 1, C = samples;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *     enqueued, never synchronised; nothing is allocated, no global state is kept, every
+ *     function is re-entrant;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     CNNQ_E* for rejected arguments (nothing is enqueued then).
+ */
+#ifndef CNNQ_HIP_H
+#define CNNQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNNQ_EINVAL (-1) /* null pointer, non-positive size, unsupported option */
+#define CNNQ_ERANGE (-2) /* C*HW does not fit the 31-bit plane index */
+
+/* Rows of the per-channel fp32 statistics table `stats[CNNQ_NSTAT][C]`
+ * (iq.py:530-555 and smpc.py:54-79 name the same quantities). */
+enum {
+    CNNQ_STAT_MIN = 0,
+    CNNQ_STAT_MAX = 1,
+    CNNQ_STAT_MEAN = 2,
+    CNNQ_STAT_STD = 3,     /* unbiased (n-1) */
+    CNNQ_STAT_B = 4,       /* mean |x - mean| */
+    CNNQ_STAT_KURT = 5,    /* mean(((x-mean)/std)^4) - 3 */
+    CNNQ_STAT_STD_POS = 6, /* unbiased std of relu(x) */
+    CNNQ_NSTAT = 7
+};
+
+/* Rows of the fp64 moment records `mom[CNNQ_NMOM][C]` that ranks exchange (all_gather) and
+ * cnnq_pc_combine merges: partial results are mergeable, statistics are not. */
+enum {
+    CNNQ_MOM_MIN = 0,
+    CNNQ_MOM_MAX = 1,
+    CNNQ_MOM_SUM = 2,
+    CNNQ_MOM_SUMSQ = 3,
+    CNNQ_MOM_COUNT = 4,
+    CNNQ_MOM_SUM_RELU = 5,
+    CNNQ_MOM_SUMSQ_RELU = 6,
+    CNNQ_NMOM = 7
+};
+/* Rows of the second-pass records `dev[CNNQ_NDEV][C]` (need the global mean / std). */
+enum { CNNQ_DEV_ABS = 0, CNNQ_DEV_Z4 = 1, CNNQ_NDEV = 2 };
+
+/* Rows of the quantisation parameter table `qp[CNNQ_NQP][C]` (iq.py:559-572). */
+enum { CNNQ_QP_SCALE = 0, CNNQ_QP_ZP = 1, CNNQ_QP_QMAX = 2, CNNQ_NQP = 3 };
+/* Rows of the diagnostic table `diag[CNNQ_NDIAG][C]` written by cnnq_pc_params. */
+enum { CNNQ_DIAG_BITS = 0, CNNQ_DIAG_ALPHA = 1, CNNQ_DIAG_DELTA = 2, CNNQ_DIAG_OFFSET = 3, CNNQ_NDIAG = 4 };
+
+/* library / build identification ("cnnq-hip <version> gfx950") */
+const char* cnnq_version(void);
+
+/* Number of partial groups G that the streaming statistics kernels emit per channel for a
+ * tensor of this geometry; the caller sizes `part` as [G][CNNQ_NMOM][C] doubles (and
+ * [G][CNNQ_NDEV][C] for the second pass).  `aligned16` = (x % 16 == 0).  Returns G > 0 or
+ * a negative CNNQ_E*. */
+int cnnq_pc_groups(int64_t N, int64_t C, int64_t HW, int aligned16);
+
+/* Pass A over x[N][C][HW]: per channel min, max, sum, sum of squares, count (and, when
+ * want_relu, sum and sum of squares of relu(x)) -> part[G][CNNQ_NMOM][C].  One coalesced
+ * read of x, no transposed copy.  Fuses the reductions of iq.py:534-550 (max/min/mean/std),
+ * smpc.py:54-55,64-66 (mean, std, std_pos) that the reference runs as one full pass each
+ * after a transpose+copy. */
+int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_relu, double* part,
+                    void* stream);
+
+/* Merge G moment records per channel (G = groups of one tensor, or G = world size after an
+ * all_gather of per-rank records) into mom[CNNQ_NMOM][C] and, when `stats` is not NULL, write
+ * rows MIN, MAX, MEAN, STD (and STD_POS when the records carry relu sums) of stats[CNNQ_NSTAT][C].
+ * Fixed merge order -> deterministic.  `mom` may be NULL. */
+int cnnq_pc_combine(const double* part, int G, int64_t C, int has_relu, double* mom, float* stats,
+                    void* stream);
+
+/* Pass B: per channel sum |x - mean[c]| and (want_kurt) sum ((x-mean[c])/std[c])^4, reading
+ * mean/std from stats rows MEAN/STD -> part2[G][CNNQ_NDEV][C].  iq.py:548 ('b'),
+ * smpc.py:58-61 (kurtosis, b). */
+int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float* stats, int want_kurt,
+                   double* part2, void* stream);
+
+/* Merge pass-B records; divides by the COUNT row of `mom` and writes stats rows B (and KURT).
+ * `dev_out` (merged [CNNQ_NDEV][C] sums, for the cross-rank exchange) may be NULL, and
+ * `stats` may be NULL when only the merged sums are wanted. */
+int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom, int want_kurt,
+                        double* dev_out, float* stats, void* stream);
+
+/* Per-channel statistics -> quantisation parameters, entirely on the device (the reference
+ * takes >= 6 host round trips here: iq.py:248,285-288,355,405).  One workgroup.
+ *   clip: 0 = min/max range (iq.py:409-424), 1 = ACIQ laplace (iq.py:227-253),
+ *         2 = ACIQ gaus (iq.py:255-264), 3 = p*std (iq.py:266-275, p = pstd);
+ *   positive = force_positive || half_range (iq.py:289,411);
+ *   bit_alloc != 0 (and num_bits <= 4): per-channel bit allocation from the prior statistic
+ *         (prior_is_b ? B : STD) by the fixed-target iteration of iq.py:381-407 with
+ *         `target` bits and round (1) or ceil (0);
+ *   alpha2DeltaOffset (iq.py:284-300), delta = (offset + range) - offset (iq.py:351,443),
+ *   scale / zero-point (iq.py:559-572).
+ * Reads stats[CNNQ_NSTAT][C] rows as needed, writes qp[CNNQ_NQP][C] and (if not NULL)
+ * diag[CNNQ_NDIAG][C]. */
+typedef struct cnnq_params_cfg {
+    int32_t num_bits;
+    int32_t positive;
+    int32_t clip;
+    float pstd;
+    int32_t bit_alloc;
+    int32_t prior_is_b;
+    double target;
+    int32_t round_mode;
+    int32_t direct_range; /* per-tensor clipping branch (iq.py:353-357): delta = range itself */
+} cnnq_params_cfg;
+int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg /* host */, float* qp,
+                   float* diag, void* stream);
+
+/* Weights (iq.py:453-476): identical parameter derivation with the range always min/max and
+ * the bit allocation prior always STD; provided as cnnq_pc_params with clip = 0. */
+
+/* The core: y = dequant(quant(x)) on native NCHW with per-channel scale / zero point / qmax
+ * (iq.py:573-592 - div, add, clamp, round, sub, mul as ONE pass; the four transpose copies of
+ * iq.py:427,450,534 disappear).  IEEE division, separate roundings (no FMA), clamp before
+ * round, round half to even: integer codes are bit-exact with the reference's.
+ * `codes` (optional, may be NULL): the integer codes as one byte per element.
+ * `hist` (optional, may be NULL): 256 uint64 bins, ZEROED BY THE CALLER, to which the code
+ * histogram of the whole tensor is added (integer atomics -> deterministic); with cnnq_entropy
+ * this replaces the full sort of torch.unique in utils/entropy.py:6-17 (iq.py:586-587). */
+int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                uint8_t* codes, uint64_t* hist, void* stream);
+
+/* Shannon entropy in bits, -sum p*log2(p) over the non-empty bins -> out[0] (utils/entropy.py:12-15). */
+int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream);
+
+/* Per-tensor path, replaces kernels/gemmlowp.cu:8-45 (`float2gemmlowp`).
+ * cnnq_pt_setup derives {scale, shift, qmax, ...} on the device into ptp[8]:
+ *   - from host scalars (range_offset_host != NULL: {range, offset}), or
+ *   - from per-row statistics (rows MIN/MAX of a stats table with row stride `stats_stride`,
+ *     `rows` entries each): rows_mode 0 = their mean over rows, the per-sample-then-batch-mean
+ *     of iq.py:372,515-526; rows_mode 1 = min of mins / max of maxes, the whole-tensor
+ *     min/max of iq.py:515-517; zero_min (iq.py:376-377) is applied afterwards;
+ *   preserve_zero follows iq.py:613 when enforce_true_zero != 0.
+ * cnnq_pt_qdq then streams x -> y with roundf / fminf / fmaxf semantics (gemmlowp.cu:11-24);
+ * range <= 0 copies x to y (the reference returns its input there, gemmlowp.cu:31-32).
+ * `noise` may be NULL (stochastic rounding is hard-wired off, iq.py:60). */
+int cnnq_pt_setup(const float* range_offset_host, const float* stats, int64_t stats_stride, int rows,
+                  int rows_mode, int zero_min, int num_bits, int int_exp, int enforce_true_zero, float* ptp,
+                  void* stream);
+int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const float* noise, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNNQ_HIP_H */
