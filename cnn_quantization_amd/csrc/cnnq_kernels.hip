@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cnnq_hip.h"
 
@@ -36,8 +37,12 @@ struct Geo {
     int mode;   // 1: block = slice of one channel, 2: block = k whole channels
     int nb, w;  // mode 1: blocks per channel, columns (loads) per block
     int k;      // mode 2: channels per block
-    int ncb;    // column blocks per plane
+    int ncb;    // column blocks per plane (of the channel range)
     int S;      // batch splits
+    int cbeg;   // first channel of the range this launch covers
+    int Cn;     // channels in the range
+    int rev;    // 1: walk blocks and samples in descending address order (re-read what the
+                //    previous pass touched LAST first: Infinity-Cache friendly)
 };
 
 struct Variant {
@@ -54,22 +59,24 @@ struct Blk {
 template <int VEC>
 __device__ __forceinline__ Blk blk_of(const Geo& g) {
     Blk b;
-    const int cb = blockIdx.x % g.ncb;
-    const int s = blockIdx.x / g.ncb;
+    const int bid = g.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int cb = bid % g.ncb;
+    const int s = bid / g.ncb;
     b.n0 = (int)(((int64_t)s * g.N) / g.S);
     b.n1 = (int)(((int64_t)(s + 1) * g.N) / g.S);
     if (g.mode == 1) {
         const int cpc = g.HW / VEC;
-        const int c = cb / g.nb;
-        const int bb = cb - c * g.nb;
+        const int cr = cb / g.nb;
+        const int bb = cb - cr * g.nb;
+        const int c = g.cbeg + cr;
         b.c0 = c;
         b.c1 = c + 1;
         b.col0 = c * cpc + bb * g.w;
         b.col1 = min(b.col0 + g.w, (c + 1) * cpc);
         b.grp = s * g.nb + bb;
     } else {
-        b.c0 = cb * g.k;
-        b.c1 = min(g.C, b.c0 + g.k);
+        b.c0 = g.cbeg + cb * g.k;
+        b.c1 = min(g.cbeg + g.Cn, b.c0 + g.k);
         b.col0 = (int)(((int64_t)b.c0 * g.HW) / VEC);
         b.col1 = (int)(((int64_t)b.c1 * g.HW) / VEC);
         b.grp = s;
@@ -582,15 +589,161 @@ __device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax
     return (q - zp) * scale;
 }
 
+// Exact per-channel min / max for config 2.  Each workgroup writes ONE {min, max} pair per
+// channel it owns into pmm[G][2][C] (plain stores, every (group, channel) entry written exactly
+// once: no atomics, no initialisation, deterministic).  The fused Q/DQ kernel reduces the G
+// pairs of its channels in its prologue.  (Device-scope atomics into a shared table were tried
+// first: ~160 K contended atomics per small layer cost ~50 us - see DESIGN.md.)
+// Floats are compared through order-preserving unsigned keys so that LDS integer atomics can do
+// the prologue reduction.
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <int VEC, int A, int J>
+__global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, const Geo g,
+                                                float* __restrict__ pmm) {
+    constexpr int NE = TPB * J * A;
+    __shared__ float l_mn[NE], l_mx[NE];
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    int col[J];
+    bool ok[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+    }
+    float mn[J][A], mx[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int a = 0; a < A; ++a) { mn[j][a] = INFINITY; mx[j][a] = -INFINITY; }
+    const float* row = x + (size_t)b.n0 * (size_t)g.P;
+    constexpr int NU = (J == 1) ? 4 : 2;  // samples in flight per lane
+#pragma unroll NU
+    for (int n = b.n0; n < b.n1; ++n, row += g.P) {
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if constexpr (A == 1 && VEC == 4) {
+                mn[j][0] = fminf(fminf(mn[j][0], fminf(v[j][0], v[j][1])), fminf(v[j][2], v[j][3]));
+                mx[j][0] = fmaxf(fmaxf(mx[j][0], fmaxf(v[j][0], v[j][1])), fmaxf(v[j][2], v[j][3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    mn[j][A == 1 ? 0 : e] = fminf(mn[j][A == 1 ? 0 : e], v[j][e]);
+                    mx[j][A == 1 ? 0 : e] = fmaxf(mx[j][A == 1 ? 0 : e], v[j][e]);
+                }
+            }
+        }
+    }
+    float* pn = pmm + (size_t)(2 * b.grp) * g.C;
+    float* px = pn + g.C;
+    const int wv = tid >> 6, lane = tid & 63;
+    if (g.mode == 1) {
+        float tn = INFINITY, tx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (ok[j]) { tn = fminf(tn, mn[j][0]); tx = fmaxf(tx, mx[j][0]); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { tn = fminf(tn, shfl_xor_f(tn, m)); tx = fmaxf(tx, shfl_xor_f(tx, m)); }
+        if (lane == 0) { l_mn[wv] = tn; l_mx[wv] = tx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < TPB / 64; ++i) { tn = fminf(tn, l_mn[i]); tx = fmaxf(tx, l_mx[i]); }
+            pn[b.c0] = tn;
+            px[b.c0] = tx;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int e = (j * TPB + tid) * A + a;
+                l_mn[e] = mn[j][a];
+                l_mx[e] = mx[j][a];
+            }
+        }
+    __syncthreads();
+    const int epc = g.HW * A / VEC;
+    if (epc <= 16) {
+        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
+            const int lo = (ch - b.c0) * epc;
+            float tn = INFINITY, tx = -INFINITY;
+            for (int e = lo; e < lo + epc; ++e) { tn = fminf(tn, l_mn[e]); tx = fmaxf(tx, l_mx[e]); }
+            pn[ch] = tn;
+            px[ch] = tx;
+        }
+        return;
+    }
+    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
+        const int lo = (ch - b.c0) * epc;
+        float tn = INFINITY, tx = -INFINITY;
+        for (int e = lo + lane; e < lo + epc; e += 64) { tn = fminf(tn, l_mn[e]); tx = fmaxf(tx, l_mx[e]); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { tn = fminf(tn, shfl_xor_f(tn, m)); tx = fmaxf(tx, shfl_xor_f(tx, m)); }
+        if (lane == 0) { pn[ch] = tn; px[ch] = tx; }
+    }
+}
+
 // Code histogram (for the Shannon entropy of utils/entropy.py:6-17): 256 bins x 32 replicas in
 // LDS, replica = lane & 31 so the 32 lanes of a service group hit 32 different banks (no
 // conflicts however skewed the codes are); replicas are summed and flushed once per workgroup.
 constexpr int HREP = 32;
+#ifndef QDQ_NT
+#define QDQ_NT 3  // bit 0: non-temporal loads of x, bit 1: non-temporal stores of y
+#endif
 
-template <int VEC, int A, int J, bool CODES, bool HIST>
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// streaming (non-temporal) forms for the Q/DQ pass: x is read for the last time and y is never
+// re-read by this path, so neither should displace the lines the NEXT kernel wants in the
+// 256 MB Infinity Cache (measured: +15 % on stats->Q/DQ sequences, tools/useq.py)
+template <int VEC>
+__device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = __builtin_nontemporal_load(p);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        f4_t t;
+        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<f4_t*>(p));
+    } else {
+        __builtin_nontemporal_store(v[0], p);
+    }
+}
+
+// FUSED: the per-channel parameters are derived in the prologue from the exact min/max keys
+// (config 2: delta = max - min, or max with a zero minimum; iq.py:409-424,559-572) instead of
+// being read from a table - no parameter kernel between the statistics and the Q/DQ pass.
+struct FusedCfg {
+    int num_bits;
+    int positive;
+    int G;  // min/max pairs per channel in pmm[G][2][C]
+};
+
+template <int VEC, int A, int J, bool CODES, bool HIST, bool FUSED>
 __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
                                              const float* __restrict__ qp, uint8_t* __restrict__ codes,
-                                             unsigned long long* __restrict__ hist) {
+                                             unsigned long long* __restrict__ hist,
+                                             const float* __restrict__ pmm, const FusedCfg fc,
+                                             float* __restrict__ qp_out) {
     __shared__ float sh_sc[MAXCH], sh_zp[MAXCH], sh_qm[MAXCH];
     __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
     const Blk b = blk_of<VEC>(g);
@@ -598,11 +751,51 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
     if constexpr (HIST) {
         for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
     }
-    // stage this workgroup's channels once: coalesced reads of the three parameter rows
-    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
-        sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
-        sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
-        sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+    const int nch = b.c1 - b.c0;
+    if constexpr (FUSED) {
+        // reduce the G {min, max} pairs of this workgroup's channels: all lanes load (coalesced
+        // along channels), LDS integer atomics on order-preserving keys do the reduction
+        unsigned* kmin = reinterpret_cast<unsigned*>(sh_zp);
+        unsigned* kmax = reinterpret_cast<unsigned*>(sh_qm);
+        for (int i = tid; i < nch; i += TPB) { kmin[i] = 0xffffffffu; kmax[i] = 0u; }
+        __syncthreads();
+        const int total = nch * fc.G;
+        for (int t = tid; t < total; t += TPB) {
+            const int gi = t / nch, i = t - gi * nch;
+            const float* pp = pmm + (size_t)(2 * gi) * g.C + b.c0 + i;
+            atomicMin(&kmin[i], f2key(pp[0]));
+            atomicMax(&kmax[i], f2key(pp[g.C]));
+        }
+        __syncthreads();
+    }
+    // stage this workgroup's channels once (coalesced), then every lane keeps its own in registers
+    for (int i = tid; i < nch; i += TPB) {
+        const int c = b.c0 + i;
+        float sc, zp, qm;
+        if constexpr (FUSED) {
+            const float mn = key2f(reinterpret_cast<unsigned*>(sh_zp)[i]);
+            const float mx = key2f(reinterpret_cast<unsigned*>(sh_qm)[i]);
+            const float offset = fc.positive ? 0.f : mn;
+            const float delta = mx - offset;
+            qm = (float)((1u << fc.num_bits) - 1u);
+            sc = delta / qm;
+            sc = (sc < 1e-8f) ? 1e-8f : sc;
+            zp = rintf(0.f - offset / sc);
+            // one workgroup per channel publishes the table (diagnostics / codes consumers)
+            const bool first = (b.n0 == 0) && (g.mode == 2 || b.col0 == c * (g.HW / VEC));
+            if (qp_out && first) {
+                qp_out[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
+                qp_out[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
+                qp_out[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
+            }
+        } else {
+            sc = qp[(size_t)CNNQ_QP_SCALE * g.C + c];
+            zp = qp[(size_t)CNNQ_QP_ZP * g.C + c];
+            qm = qp[(size_t)CNNQ_QP_QMAX * g.C + c];
+        }
+        sh_sc[i] = sc;
+        sh_zp[i] = zp;
+        sh_qm[i] = qm;
     }
     __syncthreads();
     int col[J];
@@ -622,12 +815,18 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
             qm[j][a] = sh_qm[ch];
         }
     }
-    size_t off = (size_t)b.n0 * (size_t)g.P;
-#pragma unroll 2
-    for (int n = b.n0; n < b.n1; ++n, off += g.P) {
+    const int nrows = b.n1 - b.n0;
+    constexpr int NU = (J == 1) ? 4 : 2;  // samples in flight per lane
+#pragma unroll NU
+    for (int r = 0; r < nrows; ++r) {
+        const int n = g.rev ? (b.n1 - 1 - r) : (b.n0 + r);
+        const size_t off = (size_t)n * (size_t)g.P;
         float v[J][VEC];
 #pragma unroll
-        for (int j = 0; j < J; ++j) ldv<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+        for (int j = 0; j < J; ++j) {
+            if constexpr ((QDQ_NT & 1) != 0) ldv_nt<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+            else ldv<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+        }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             float o[VEC], cd[VEC];
@@ -637,7 +836,8 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
                 o[e] = qdq1(v[j][e], sc[j][a], zp[j][a], qm[j][a], cd[e]);
             }
             if (ok[j]) {
-                stv<VEC>(y + off + (size_t)col[j] * VEC, o);
+                if constexpr ((QDQ_NT & 2) != 0) stv_nt<VEC>(y + off + (size_t)col[j] * VEC, o);
+                else stv<VEC>(y + off + (size_t)col[j] * VEC, o);
                 if constexpr (HIST) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
@@ -783,8 +983,27 @@ __global__ void __launch_bounds__(TPB) k_pt_qdq(const float* __restrict__ x, flo
 // ------------------------------------------------------------------------------------------
 int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
-int choose_variant(int64_t C, int64_t HW, bool aligned16, Variant* v) {
-    if (aligned16 && HW % 4 == 0) { *v = {4, 1, 4}; return 0; }
+constexpr int MAXG = 64;   // upper bound on batch splits S (partial groups per channel = S * nb)
+
+// Load shape for a tensor.  For the aligned float4 shape the loads per lane per sample (J) adapt
+// to the geometry: 4 when one channel row is long (H*W/4 > 1024 -> a workgroup owns a slice of a
+// channel), otherwise the largest of {4, 2, 1} that still yields >= 2048 workgroups, so that
+// small-H*W layers (14x14, 28x28 with few channels) fill the 256 CUs.
+int choose_variant(int64_t N, int64_t C, int64_t HW, bool aligned16, Variant* v) {
+    if (aligned16 && HW % 4 == 0) {
+        const int64_t cpc = HW / 4;
+        int J = 4;
+        if (cpc <= TPB * 4) {
+            const int64_t smax = N < MAXG ? N : MAXG;
+            for (J = 4; J > 1; J >>= 1) {
+                const int64_t cap = TPB * J;
+                const int64_t ncb = (cpc > cap) ? C * ((cpc + cap - 1) / cap) : (C + cap / cpc - 1) / (cap / cpc);
+                if (ncb * smax >= 2048) break;
+            }
+        }
+        *v = {4, 1, J};
+        return 0;
+    }
     if (aligned16 && (C * HW) % 4 == 0) {
         const int m = 4 / gcd_i((int)(HW % 4), 4);
         if ((int64_t)m * HW <= TPB * 4) { *v = {4, 4, 1}; return 0; }
@@ -793,19 +1012,25 @@ int choose_variant(int64_t C, int64_t HW, bool aligned16, Variant* v) {
     return 0;
 }
 
-int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, Geo* g) {
-    if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
+// Geometry of one launch over channels [cbeg, cbeg + Cn) of x[N][C][HW].
+// max_groups > 0 bounds the batch splits S (every kernel uses MAXG so that all passes over one
+// tensor share one geometry and one group count G = S * nb).
+int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, int64_t Cn, int max_groups, int rev,
+             Geo* g) {
+    if (N <= 0 || C <= 0 || HW <= 0 || cbeg < 0 || Cn <= 0 || cbeg + Cn > C) return CNNQ_EINVAL;
     if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31) return CNNQ_ERANGE;
     g->N = (int)N; g->C = (int)C; g->HW = (int)HW; g->P = (int)(C * HW);
+    g->cbeg = (int)cbeg; g->Cn = (int)Cn; g->rev = rev;
     g->nb = 1; g->w = 0; g->k = 1;
     const int cap = TPB * v.J;  // loads per block per sample
     if (v.A == 4) {             // straddle: k whole channels with k*HW % 4 == 0
         const int m = 4 / gcd_i((int)(HW % 4), 4);
+        if (cbeg % m != 0) return CNNQ_EINVAL;  // the range must start on a 16-byte boundary
         int k = (int)((cap * 4) / HW);
         k -= k % m;
         g->mode = 2;
         g->k = k;
-        g->ncb = (int)((C + k - 1) / k);
+        g->ncb = (int)((Cn + k - 1) / k);
     } else {
         const int64_t cpc = HW / v.vec;
         if (cpc > cap) {
@@ -813,21 +1038,21 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, Geo* g) {
             int64_t nb = (cpc + cap - 1) / cap;
             const int64_t w = (cpc + nb - 1) / nb;
             nb = (cpc + w - 1) / w;
-            if (C * nb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+            if (Cn * nb >= (int64_t)1 << 31) return CNNQ_ERANGE;
             g->nb = (int)nb;
             g->w = (int)w;
-            g->ncb = (int)(C * nb);
+            g->ncb = (int)(Cn * nb);
         } else {
             g->mode = 2;
             g->k = (int)(cap / cpc);
-            g->ncb = (int)((C + g->k - 1) / g->k);
+            g->ncb = (int)((Cn + g->k - 1) / g->k);
         }
     }
-    // enough workgroups to fill 256 CUs several times over, but few enough partial groups
+    // enough workgroups to fill 256 CUs (x 6-8 resident each) a few times over
     const int64_t target = 4096;
     int64_t S = (target + g->ncb - 1) / g->ncb;
     if (S > N) S = N;
-    if (S > 64) S = 64;
+    if (max_groups > 0 && S > max_groups) S = max_groups;
     if (S < 1) S = 1;
     g->S = (int)S;
     if ((int64_t)g->S * g->ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
@@ -837,17 +1062,53 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, Geo* g) {
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline int launch_status() { return (int)hipGetLastError(); }
 
+// one plan (load shape + geometry) per tensor, shared by every pass over it
+int plan(int64_t N, int64_t C, int64_t HW, bool aligned16, int rev, Variant* v, Geo* g) {
+    choose_variant(N, C, HW, aligned16, v);
+    return make_geo(N, C, HW, *v, 0, C, MAXG, rev, g);
+}
+
+// dispatch on the runtime load shape: invokes F<VEC, A, J>()
+#define CNNQ_DISPATCH(v, F)                                          \
+    do {                                                             \
+        if ((v).vec == 4 && (v).A == 1) {                            \
+            if ((v).J == 4) { F(4, 1, 4); }                          \
+            else if ((v).J == 2) { F(4, 1, 2); }                     \
+            else { F(4, 1, 1); }                                     \
+        } else if ((v).vec == 4) { F(4, 4, 1); }                     \
+        else { F(1, 1, 4); }                                         \
+    } while (0)
+
+template <bool FUSED>
+int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const float* qp, uint8_t* codes,
+               unsigned long long* h, const float* pmm, FusedCfg fc, float* qp_out, hipStream_t st) {
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+#define LAUNCH_QDQ(VEC, A, J)                                                                                  \
+    do {                                                                                                       \
+        if (codes && h) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, true, FUSED>), grid, block, 0, st, x, y, g, qp, \
+                                           codes, h, pmm, fc, qp_out);                                         \
+        else if (codes) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, false, FUSED>), grid, block, 0, st, x, y, g, qp, \
+                                           codes, h, pmm, fc, qp_out);                                         \
+        else if (h) hipLaunchKernelGGL((k_qdq<VEC, A, J, false, true, FUSED>), grid, block, 0, st, x, y, g, qp,  \
+                                       codes, h, pmm, fc, qp_out);                                             \
+        else hipLaunchKernelGGL((k_qdq<VEC, A, J, false, false, FUSED>), grid, block, 0, st, x, y, g, qp, codes, \
+                                h, pmm, fc, qp_out);                                                           \
+    } while (0)
+    CNNQ_DISPATCH(v, LAUNCH_QDQ);
+#undef LAUNCH_QDQ
+    return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
 
-const char* cnnq_version(void) { return "cnnq-hip 0.1 gfx950"; }
+const char* cnnq_version(void) { return "cnnq-hip 0.2 gfx950"; }
 
 int cnnq_pc_groups(int64_t N, int64_t C, int64_t HW, int aligned16) {
     Variant v;
     Geo g;
-    choose_variant(C, HW, aligned16 != 0, &v);
-    const int rc = make_geo(N, C, HW, v, &g);
+    const int rc = plan(N, C, HW, aligned16 != 0, 0, &v, &g);
     if (rc) return rc;
     return g.S * g.nb;
 }
@@ -856,8 +1117,7 @@ int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_r
     if (!x || !part) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    choose_variant(C, HW, al16(x), &v);
-    const int rc = make_geo(N, C, HW, v, &g);
+    const int rc = plan(N, C, HW, al16(x), 0, &v, &g);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
@@ -866,9 +1126,7 @@ int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_r
         if (want_relu) hipLaunchKernelGGL((k_moments<VEC, A, J, true>), grid, block, 0, st, x, g, part); \
         else hipLaunchKernelGGL((k_moments<VEC, A, J, false>), grid, block, 0, st, x, g, part);          \
     } while (0)
-    if (v.vec == 4 && v.A == 1) LAUNCH_MOM(4, 1, 4);
-    else if (v.vec == 4) LAUNCH_MOM(4, 4, 1);
-    else LAUNCH_MOM(1, 1, 4);
+    CNNQ_DISPATCH(v, LAUNCH_MOM);
 #undef LAUNCH_MOM
     return launch_status();
 }
@@ -885,8 +1143,7 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
     if (!x || !stats || !part2) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    choose_variant(C, HW, al16(x), &v);
-    const int rc = make_geo(N, C, HW, v, &g);
+    const int rc = plan(N, C, HW, al16(x), 0, &v, &g);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
@@ -895,9 +1152,7 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
         if (want_kurt) hipLaunchKernelGGL((k_absdev<VEC, A, J, true>), grid, block, 0, st, x, g, stats, part2);  \
         else hipLaunchKernelGGL((k_absdev<VEC, A, J, false>), grid, block, 0, st, x, g, stats, part2);           \
     } while (0)
-    if (v.vec == 4 && v.A == 1) LAUNCH_DEV(4, 1, 4);
-    else if (v.vec == 4) LAUNCH_DEV(4, 4, 1);
-    else LAUNCH_DEV(1, 1, 4);
+    CNNQ_DISPATCH(v, LAUNCH_DEV);
 #undef LAUNCH_DEV
     return launch_status();
 }
@@ -928,24 +1183,59 @@ int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, cons
     if (!x || !y || !qp) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    choose_variant(C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), &v);
-    const int rc = make_geo(N, C, HW, v, &g);
+    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), 0, &v, &g);
+    if (rc) return rc;
+    return launch_qdq<false>(x, y, g, v, qp, codes, reinterpret_cast<unsigned long long*>(hist), nullptr,
+                             FusedCfg{0, 0, 0}, nullptr, (hipStream_t)stream);
+}
+
+int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream) {
+    if (!x || !pmm) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, al16(x), 0, &v, &g);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long* h = reinterpret_cast<unsigned long long*>(hist);
-#define LAUNCH_QDQ(VEC, A, J)                                                                                       \
-    do {                                                                                                            \
-        if (codes && h) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, true>), grid, block, 0, st, x, y, g, qp, codes, h); \
-        else if (codes) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, false>), grid, block, 0, st, x, y, g, qp, codes, h); \
-        else if (h) hipLaunchKernelGGL((k_qdq<VEC, A, J, false, true>), grid, block, 0, st, x, y, g, qp, codes, h);  \
-        else hipLaunchKernelGGL((k_qdq<VEC, A, J, false, false>), grid, block, 0, st, x, y, g, qp, codes, h);        \
-    } while (0)
-    if (v.vec == 4 && v.A == 1) LAUNCH_QDQ(4, 1, 4);
-    else if (v.vec == 4) LAUNCH_QDQ(4, 4, 1);
-    else LAUNCH_QDQ(1, 1, 4);
-#undef LAUNCH_QDQ
+#define LAUNCH_MM(VEC, A, J) hipLaunchKernelGGL((k_minmax<VEC, A, J>), grid, block, 0, st, x, g, pmm)
+    CNNQ_DISPATCH(v, LAUNCH_MM);
+#undef LAUNCH_MM
     return launch_status();
+}
+
+int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                       const float* pmm, int G, float* qp_out, uint8_t* codes, uint64_t* hist, int reverse,
+                       void* stream) {
+    if (!x || !y || !pmm || G <= 0 || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), reverse ? 1 : 0,
+                        &v, &g);
+    if (rc) return rc;
+    return launch_qdq<true>(x, y, g, v, nullptr, codes, reinterpret_cast<unsigned long long*>(hist), pmm,
+                            FusedCfg{num_bits, positive ? 1 : 0, G}, qp_out, (hipStream_t)stream);
+}
+
+int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                       float* pmm, float* qp_out, uint8_t* codes, uint64_t* hist, void* stream) {
+    if (!x || !y || !pmm || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
+    // both passes must see the same load shape: decide it once from all pointers involved
+    const bool al = al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0);
+    Variant v;
+    Geo g;
+    int rc = plan(N, C, HW, al, 0, &v, &g);
+    if (rc) return rc;
+    const int G = g.S * g.nb;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_MM(VEC, A, J) hipLaunchKernelGGL((k_minmax<VEC, A, J>), grid, block, 0, st, x, g, pmm)
+    CNNQ_DISPATCH(v, LAUNCH_MM);
+#undef LAUNCH_MM
+    rc = launch_status();
+    if (rc) return rc;
+    g.rev = 1;  // re-read what the statistics pass touched last first
+    return launch_qdq<true>(x, y, g, v, nullptr, codes, reinterpret_cast<unsigned long long*>(hist), pmm,
+                            FusedCfg{num_bits, positive ? 1 : 0, G}, qp_out, st);
 }
 
 int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream) {

@@ -4,6 +4,7 @@ current HIP stream go straight to libcnnq_hip.so.  torch supplies memory and str
 No function here synchronises with the host; none has a CPU path - CPU tensors are rejected
 and a missing library raises (cnn_quantization_amd._lib.load)."""
 import ctypes
+import os
 
 import torch
 
@@ -144,6 +145,37 @@ def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None):
     return (y, codes) if want_codes else y
 
 
+def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
+                     want_parts=False):
+    """Config 2 in one library call (cnnq_pc_minmax_qdq): exact per-channel min/max partials, then
+    the fused Q/DQ whose prologue reduces them and derives scale / zero point - two launches."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    y = torch.empty_like(x) if out is None else out
+    G = max(lib.cnnq_pc_groups(N, C, HW, 1), lib.cnnq_pc_groups(N, C, HW, 0))
+    if G <= 0:
+        L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
+    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device) if want_parts else None
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+    hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
+    L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
+                                   _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
+    res = [y]
+    if want_codes:
+        res.append(codes)
+    if want_entropy:
+        res.append(entropy_from_hist(hist))
+    if want_parts:
+        al = x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and (codes is None or codes.data_ptr() % 4 == 0)
+        g_used = lib.cnnq_pc_groups(N, C, HW, int(al))
+        stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
+        stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
+        stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]
+        res.append(dict(stats=stats, qp=qp, diag=None))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
 def entropy_from_hist(hist):
     """Shannon entropy (bits) of an int64 histogram tensor -> 0-dim float32 tensor on the device."""
     lib = L.load()
@@ -182,7 +214,7 @@ def pt_qdq(x, ptp, noise=None, out=None):
 # ------------------------------------------------------------------------------------- pipelines
 def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False, prior_is_b=False, target=None,
                         round_mode=True, per_channel_dim=1, group=None, want_codes=False, want_parts=False,
-                        stats=None, want_entropy=False, whole_tensor=False):
+                        stats=None, want_entropy=False, whole_tensor=False, out=None):
     """The dynamic per-channel hot path end to end: statistics (one or two coalesced reads of
     x) -> parameters (one workgroup) -> fused Q/DQ (one read, one write).  Covers iq.py:409-451
     (clip='no'), iq.py:327-352 (ACIQ) and, with per_channel_dim=0, the weights of iq.py:453-476;
@@ -193,6 +225,10 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
     x = _dev_f32(x, 'x')
     N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x, per_channel_dim)
     use_ba = bool(bit_alloc) and num_bits <= 4 and not whole_tensor
+    world = 1 if group is False else D.world_size(group)
+    if stats is None and clip == 'no' and not use_ba and world == 1 and not whole_tensor:
+        return minmax_qdq_fused(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out,
+                                want_parts=want_parts)
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)
         stats, _ = pc_stats(x, N, C, HW, need_b=need_b, group=None if group is False else group,
@@ -200,7 +236,7 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
     qp, diag = pc_params(stats, num_bits, positive, clip, use_ba, prior_is_b, target, round_mode,
                          direct_range=whole_tensor)
     hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
-    res = pc_qdq(x, N, C, HW, qp, want_codes, hist=hist)
+    res = pc_qdq(x, N, C, HW, qp, want_codes, out=out, hist=hist)
     out = list(res) if want_codes else [res]
     if want_entropy:
         if D.world_size(None if group is False else group) > 1 and group is not False:

@@ -144,6 +144,26 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg /* 
 int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
                 uint8_t* codes, uint64_t* hist, void* stream);
 
+/* Config 2 (dynamic per-channel min/max, no clipping, uniform bit width: iq.py:409-451 with
+ * bit allocation off) as TWO launches with no parameter kernel in between:
+ *   cnnq_pc_minmax      exact per-channel {min, max} partials pmm[G][2][C] (G = cnnq_pc_groups;
+ *                       every entry written exactly once: no atomics, no initialisation);
+ *   cnnq_pc_qdq_minmax  the fused Q/DQ; its prologue reduces the G pairs of the workgroup's
+ *                       channels (LDS integer atomics on order-preserving keys) and derives scale /
+ *                       zero point (iq.py:559-572).  Non-temporal loads and stores (x is read for
+ *                       the last time, y is never re-read: neither should displace useful lines of
+ *                       the 256 MB Infinity Cache); reverse != 0 walks the tensor in descending
+ *                       address order, so what the statistics pass read last is re-read first.
+ *                       qp_out (optional [CNNQ_NQP][C]) receives the parameters used.
+ *   cnnq_pc_minmax_qdq  both, in one call (reverse order for the second pass).
+ * codes / hist as in cnnq_pc_qdq. */
+int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream);
+int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                       const float* pmm, int G, float* qp_out, uint8_t* codes, uint64_t* hist, int reverse,
+                       void* stream);
+int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                       float* pmm, float* qp_out, uint8_t* codes, uint64_t* hist, void* stream);
+
 /* Shannon entropy in bits, -sum p*log2(p) over the non-empty bins -> out[0] (utils/entropy.py:12-15). */
 int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream);
 
