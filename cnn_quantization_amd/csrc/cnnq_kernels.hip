@@ -696,6 +696,21 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
     }
 }
 
+// pmm[G][2][C] -> out[2][C]: the rank-local extrema that ranks exchange (all_gather) before the
+// fused Q/DQ reduces the W gathered pairs in its prologue
+__global__ void __launch_bounds__(TPB) k_minmax_reduce(const float* __restrict__ pmm, int G, int C,
+                                                       float* __restrict__ out) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int gi = 0; gi < G; ++gi) {
+        mn = fminf(mn, pmm[(size_t)(2 * gi) * C + c]);
+        mx = fmaxf(mx, pmm[(size_t)(2 * gi + 1) * C + c]);
+    }
+    out[c] = mn;
+    out[C + c] = mx;
+}
+
 // Code histogram (for the Shannon entropy of utils/entropy.py:6-17): 256 bins x 32 replicas in
 // LDS, replica = lane & 31 so the 32 lanes of a service group hit 32 different banks (no
 // conflicts however skewed the codes are); replicas are summed and flushed once per workgroup.
@@ -1200,6 +1215,13 @@ int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm,
 #define LAUNCH_MM(VEC, A, J) hipLaunchKernelGGL((k_minmax<VEC, A, J>), grid, block, 0, st, x, g, pmm)
     CNNQ_DISPATCH(v, LAUNCH_MM);
 #undef LAUNCH_MM
+    return launch_status();
+}
+
+int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* stream) {
+    if (!pmm || !out || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_minmax_reduce, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, pmm,
+                       G, (int)C, out);
     return launch_status();
 }
 

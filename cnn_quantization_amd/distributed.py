@@ -42,7 +42,11 @@ def all_gather_records(rec, group=None):
     if w == 1:
         out[0].copy_(rec)
         return out
-    dist.all_gather_into_tensor(out.view(-1), rec.view(-1), group=group)   # flat: same on RCCL and gloo
+    try:
+        dist.all_gather_into_tensor(out.view(-1), rec.view(-1), group=group)   # flat: same on RCCL and gloo
+    except RuntimeError:
+        # gloo with device tensors (single-GPU test rigs): list form
+        dist.all_gather([out[i] for i in range(w)], rec, group=group)
     return out
 
 

@@ -146,9 +146,13 @@ def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None):
 
 
 def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
-                     want_parts=False):
-    """Config 2 in one library call (cnnq_pc_minmax_qdq): exact per-channel min/max partials, then
-    the fused Q/DQ whose prologue reduces them and derives scale / zero point - two launches."""
+                     want_parts=False, group=None):
+    """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials, then the fused Q/DQ whose
+    prologue reduces them and derives scale / zero point - two launches, no host sync.
+
+    World size > 1 (x is this rank's batch shard): the local extrema [2, C] are all-gathered and the
+    Q/DQ prologue reduces the W gathered pairs instead - exact, so the result is bit-identical to a
+    single GPU holding the whole batch."""
     lib = L.load()
     x = _dev_f32(x, 'x')
     y = torch.empty_like(x) if out is None else out
@@ -159,8 +163,21 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device) if want_parts else None
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
     hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
-    L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
-                                   _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
+    world = D.world_size(group)
+    if world == 1:
+        L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
+                                       _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
+    else:
+        g_used = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+        L.check(lib.cnnq_pc_minmax(_ptr(x), N, C, HW, _ptr(pmm), _stream(x)), 'cnnq_pc_minmax')
+        local = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), g_used, C, _ptr(local), _stream(x)), 'cnnq_pc_minmax_reduce')
+        pmm = D.all_gather_records(local, group)                     # [W, 2, C]
+        L.check(lib.cnnq_pc_qdq_minmax(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
+                                       world, _ptr(qp), _ptr(codes), _ptr(hist), 1, _stream(x)),
+                'cnnq_pc_qdq_minmax')
+        if want_entropy:
+            D.all_reduce_sum_(hist, group)
     res = [y]
     if want_codes:
         res.append(codes)
@@ -168,7 +185,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         res.append(entropy_from_hist(hist))
     if want_parts:
         al = x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and (codes is None or codes.data_ptr() % 4 == 0)
-        g_used = lib.cnnq_pc_groups(N, C, HW, int(al))
+        g_used = world if world > 1 else lib.cnnq_pc_groups(N, C, HW, int(al))
         stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
         stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
         stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]
@@ -226,9 +243,9 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
     N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x, per_channel_dim)
     use_ba = bool(bit_alloc) and num_bits <= 4 and not whole_tensor
     world = 1 if group is False else D.world_size(group)
-    if stats is None and clip == 'no' and not use_ba and world == 1 and not whole_tensor:
+    if stats is None and clip == 'no' and not use_ba and not whole_tensor:
         return minmax_qdq_fused(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out,
-                                want_parts=want_parts)
+                                want_parts=want_parts, group=None if world == 1 else group)
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)
         stats, _ = pc_stats(x, N, C, HW, need_b=need_b, group=None if group is False else group,

@@ -156,8 +156,13 @@ int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, cons
  *                       address order, so what the statistics pass read last is re-read first.
  *                       qp_out (optional [CNNQ_NQP][C]) receives the parameters used.
  *   cnnq_pc_minmax_qdq  both, in one call (reverse order for the second pass).
+ *   cnnq_pc_minmax_reduce  pmm[G][2][C] -> out[2][C]: a rank's local extrema.  Multi-GPU config 2:
+ *                       minmax -> reduce -> all_gather of out over the ranks -> qdq_minmax with the
+ *                       gathered [W][2][C] as pmm and G = W (exact, so any world size gives the
+ *                       bit-identical result of one GPU holding the whole batch).
  * codes / hist as in cnnq_pc_qdq. */
 int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream);
+int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* stream);
 int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                        const float* pmm, int G, float* qp_out, uint8_t* codes, uint64_t* hist, int reverse,
                        void* stream);
