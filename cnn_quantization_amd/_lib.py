@@ -15,6 +15,8 @@ STAT_MIN, STAT_MAX, STAT_MEAN, STAT_STD, STAT_B, STAT_KURT, STAT_STD_POS, NSTAT 
 MOM_MIN, MOM_MAX, MOM_SUM, MOM_SUMSQ, MOM_COUNT, MOM_SUM_RELU, MOM_SUMSQ_RELU, NMOM = 0, 1, 2, 3, 4, 5, 6, 7
 DEV_ABS, DEV_Z4, NDEV = 0, 1, 2
 QP_SCALE, QP_ZP, QP_QMAX, NQP = 0, 1, 2, 3
+MT_DELTA, MT_CMIN, MT_CMAX, MT_OMEGA, MT_ALPHA, NMT = 0, 1, 2, 3, 4, 5
+MT_HIST_BINS = 131072
 DIAG_BITS, DIAG_ALPHA, DIAG_DELTA, DIAG_OFFSET, NDIAG = 0, 1, 2, 3, 4
 
 
@@ -38,6 +40,9 @@ SIGNATURES = {
     'cnnq_pc_minmax_reduce': (_I, [_P, _I, _L, _P, _P]),
     'cnnq_pc_qdq_minmax': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     'cnnq_pc_minmax_qdq': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
+    'cnnq_pc_midtread_params': (_I, [_P, _L, ctypes.c_double, _I, _I, _P, _I, _P, _P]),
+    'cnnq_pc_midtread_qdq': (_I, [_P, _P, _L, _L, _L, _P, _I, _P, _P, _P]),
+    'cnnq_midtread_entropy': (_I, [_P, _P, _L, _L, _P, _P]),
     'cnnq_entropy': (_I, [_P, _I, _P, _P]),
     'cnnq_pt_setup': (_I, [ctypes.POINTER(_F), _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'cnnq_pt_qdq': (_I, [_P, _P, _L, _P, _P, _P]),

@@ -912,6 +912,203 @@ __global__ void __launch_bounds__(TPB) k_entropy(const unsigned long long* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// mid-tread quantization with per-channel bin allocation (config 5, iq.py:128-225)
+// ------------------------------------------------------------------------------------------
+struct MtCfg {
+    double target;  // bits; bins per channel on average = 2^target
+    int clip;       // 1: laplace-prior clipping around the mean (activations), 0: min/max range (weights)
+    int sym;        // 0: non-negative range (force_positive / half_range)
+};
+
+constexpr int MT_NB = CNNQ_MT_HIST_BINS;  // integer-code bins, codes -MT_NB/2 .. MT_NB/2-1
+
+__global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ stats, int C, const MtCfg cfg,
+                                                    const double* __restrict__ tabs, int ntab,
+                                                    float* __restrict__ mt) {
+    __shared__ double sh[PTPB / 64];
+    const int tid = threadIdx.x;
+    const float* vmin = stats + (size_t)CNNQ_STAT_MIN * C;
+    const float* vmax = stats + (size_t)CNNQ_STAT_MAX * C;
+    const float* vmean = stats + (size_t)CNNQ_STAT_MEAN * C;
+    const float* vstd = stats + (size_t)CNNQ_STAT_STD * C;
+    const float* vb = stats + (size_t)CNNQ_STAT_B * C;
+    const double* otab = tabs;
+    const double* atab = tabs + ntab;
+    // eq. 10 (iq.py:128-135): omega = round(C * 2^target * sigma^(2/3) / sum sigma^(2/3))
+    double psum_d = 0.;
+    for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(vstd[c], (float)(2. / 3));
+    const float psum = (float)block_sum(psum_d, sh);
+    const float B = (float)((double)C * pow(2., cfg.target));
+    for (int c = tid; c < C; c += PTPB) {
+        const float p = powf(vstd[c], (float)(2. / 3));
+        const float omega = rintf((B * p) / psum);
+        float rng, am = 0.f;
+        const float mu = vmean[c];
+        const float mu0 = fmaxf(mu, 0.f);
+        if (cfg.clip) {
+            // linear interpolation in the (omega, alpha) table, fp64 like numpy (iq.py:137-145)
+            const double om = (double)(cfg.sym ? omega : omega * 2.f);
+            int lo = 0, hi = ntab;  // searchsorted, side='left'
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (otab[mid] < om) lo = mid + 1; else hi = mid;
+            }
+            const int i = lo < ntab ? lo : ntab - 1;     // (the reference raises beyond the table)
+            const int im = i == 0 ? ntab - 1 : i - 1;    // numpy's index -1 wraps
+            const double inc = (atab[i] - atab[im]) / (otab[i] - otab[im]);
+            am = (float)(atab[i] - inc * (otab[i] - om));
+            rng = cfg.sym ? (2.f * am) * vb[c] : mu0 + am * vb[c];
+        } else {
+            rng = cfg.sym ? vmax[c] - vmin[c] : vmax[c];
+        }
+        const float delta = (omega > 0.f) ? rng / omega : 3.402823466e+38f;
+        float cmin = -INFINITY, cmax = INFINITY;
+        if (cfg.clip) {
+            const float muq = (cfg.sym ? mu : mu0) / delta;
+            cmax = muq + (cfg.sym ? omega / 2.f : omega);
+            cmin = cfg.sym ? muq - omega / 2.f : 0.f;
+        }
+        mt[(size_t)CNNQ_MT_DELTA * C + c] = delta;
+        mt[(size_t)CNNQ_MT_CMIN * C + c] = cmin;
+        mt[(size_t)CNNQ_MT_CMAX * C + c] = cmax;
+        mt[(size_t)CNNQ_MT_OMEGA * C + c] = omega;
+        mt[(size_t)CNNQ_MT_ALPHA * C + c] = am;
+    }
+}
+
+// hist layout (uint64): [0, MT_NB) integer codes -MT_NB/2.., [MT_NB] below range, [MT_NB+1] above
+// range, then C counts of "clamped to a non-integer c_min[c]" and C of "... c_max[c]".
+template <int VEC, int A, int J, bool CLIP, bool HIST, bool CODES>
+__global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
+                                                const float* __restrict__ mt, float* __restrict__ codes,
+                                                unsigned long long* __restrict__ hist) {
+    __shared__ float sh_d[MAXCH], sh_lo[MAXCH], sh_hi[MAXCH];
+    __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
+    __shared__ unsigned sh_clo[HIST ? MAXCH : 1], sh_chi[HIST ? MAXCH : 1];
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    const int nch = b.c1 - b.c0;
+    if constexpr (HIST) {
+        for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
+        for (int i = tid; i < nch; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
+    }
+    for (int i = tid; i < nch; i += TPB) {
+        sh_d[i] = mt[(size_t)CNNQ_MT_DELTA * g.C + b.c0 + i];
+        sh_lo[i] = mt[(size_t)CNNQ_MT_CMIN * g.C + b.c0 + i];
+        sh_hi[i] = mt[(size_t)CNNQ_MT_CMAX * g.C + b.c0 + i];
+    }
+    __syncthreads();
+    int col[J], chl[J][A];
+    bool ok[J];
+    float d[J][A], lo[J][A], hi[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+            chl[j][a] = ch;
+            d[j][a] = sh_d[ch];
+            lo[j][a] = sh_lo[ch];
+            hi[j][a] = sh_hi[ch];
+        }
+    }
+    const int nrows = b.n1 - b.n0;
+    constexpr int NU = (J == 1) ? 4 : 2;
+#pragma unroll NU
+    for (int r = 0; r < nrows; ++r) {
+        const size_t off = (size_t)(b.n0 + r) * (size_t)g.P;
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv_nt<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float o[VEC], q[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                float t = rintf(v[j][e] / d[j][a]);          // iq.py:202-203
+                if constexpr (CLIP) {
+                    // torch.min(t, hi) = t < hi ? t : hi and torch.max(t, lo) = t > lo ? t : lo, NaN kept
+                    // (the bound wins ties: max(-0, +0) is +0, iq.py:213-214)
+                    t = (t < hi[j][a] || t != t) ? t : hi[j][a];
+                    t = (t > lo[j][a] || t != t) ? t : lo[j][a];
+                }
+                q[e] = t;
+                o[e] = t * d[j][a];                          // iq.py:224
+            }
+            if (ok[j]) {
+                stv_nt<VEC>(y + off + (size_t)col[j] * VEC, o);
+                if constexpr (CODES) stv<VEC>(codes + off + (size_t)col[j] * VEC, q);
+                if constexpr (HIST) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int a = (A == 1 ? 0 : e);
+                        const float t = q[e];
+                        if (t == rintf(t)) {
+                            const int k = (int)fminf(fmaxf(t, -1e9f), 1e9f);
+                            if (k >= -128 && k < 128) atomicAdd(&sh_hist[(unsigned)(k + 128) * HREP + (tid & (HREP - 1))], 1u);
+                            else if (k >= -MT_NB / 2 && k < MT_NB / 2) atomicAdd(&hist[k + MT_NB / 2], 1ull);
+                            else atomicAdd(&hist[k < 0 ? MT_NB : MT_NB + 1], 1ull);
+                        } else if (CLIP && t == hi[j][a]) {
+                            atomicAdd(&sh_chi[chl[j][a]], 1u);
+                        } else {
+                            atomicAdd(&sh_clo[chl[j][a]], 1u);   // non-integer clamp value c_min (or NaN)
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        unsigned tot = 0;
+#pragma unroll 8
+        for (int r = 0; r < HREP; ++r) tot += sh_hist[tid * HREP + ((r + tid) & (HREP - 1))];
+        if (tot) atomicAdd(&hist[tid - 128 + MT_NB / 2], (unsigned long long)tot);
+        for (int i = tid; i < nch; i += TPB) {
+            if (sh_clo[i]) atomicAdd(&hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]);
+            if (sh_chi[i]) atomicAdd(&hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]);
+        }
+    }
+}
+
+// entropy over integer bins + the per-channel non-integer clamp values (equal values merged,
+// as torch.unique would, utils/entropy.py:10)
+__global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* __restrict__ hist,
+                                                     const float* __restrict__ mt, int C, double total,
+                                                     float* __restrict__ out) {
+    __shared__ double sh[PTPB / 64];
+    const int tid = threadIdx.x;
+    const float ftotal = (float)total;
+    double e = 0.;
+    for (int i = tid; i < MT_NB + 2; i += PTPB) {
+        const unsigned long long c = hist[i];
+        if (c) { const float pr = (float)c / ftotal; e += (double)(-pr * log2f(pr)); }
+    }
+    const unsigned long long* cl = hist + MT_NB + 2;
+    for (int i = tid; i < 2 * C; i += PTPB) {
+        if (!cl[i]) continue;
+        const float vi = mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
+        bool dup = false;
+        unsigned long long cnt = cl[i];
+        for (int j = 0; j < 2 * C; ++j) {
+            if (j == i || !cl[j]) continue;
+            const float vj = mt[(size_t)(j < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (j < C ? j : j - C)];
+            if (vj == vi) { if (j < i) { dup = true; break; } cnt += cl[j]; }
+        }
+        if (dup) continue;
+        const float pr = (float)cnt / ftotal;
+        e += (double)(-pr * log2f(pr));
+    }
+    const double r = block_sum(e, sh);
+    if (tid == 0) out[0] = (float)r;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-tensor GEMMLOWP path (replaces kernels/gemmlowp.cu)
 // ------------------------------------------------------------------------------------------
 // ptp: [0] scale [1] shift [2] qmax [3] true-zero flag [4] passthrough flag [5] range [6] offset
@@ -1258,6 +1455,49 @@ int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t H
     g.rev = 1;  // re-read what the statistics pass touched last first
     return launch_qdq<true>(x, y, g, v, nullptr, codes, reinterpret_cast<unsigned long long*>(hist), pmm,
                             FusedCfg{num_bits, positive ? 1 : 0, G}, qp_out, st);
+}
+
+int cnnq_pc_midtread_params(const float* stats, int64_t C, double target, int clip, int sym, const double* tables,
+                            int ntab, float* mt, void* stream) {
+    if (!stats || !mt || !tables || ntab < 2 || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
+    const MtCfg cfg{target, clip ? 1 : 0, sym ? 1 : 0};
+    hipLaunchKernelGGL(k_mt_params, dim3(1), dim3(PTPB), 0, (hipStream_t)stream, stats, (int)C, cfg, tables, ntab, mt);
+    return launch_status();
+}
+
+int cnnq_pc_midtread_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* mt, int clip,
+                         float* codes, uint64_t* hist, void* stream) {
+    if (!x || !y || !mt) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || al16(codes)), 0, &v, &g);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* h = reinterpret_cast<unsigned long long*>(hist);
+#define LAUNCH_MT3(VEC, A, J, CL, HI)                                                                            \
+    do {                                                                                                        \
+        if (codes) hipLaunchKernelGGL((k_mt_qdq<VEC, A, J, CL, HI, true>), grid, block, 0, st, x, y, g, mt, codes, h); \
+        else hipLaunchKernelGGL((k_mt_qdq<VEC, A, J, CL, HI, false>), grid, block, 0, st, x, y, g, mt, codes, h);      \
+    } while (0)
+#define LAUNCH_MT(VEC, A, J)                                      \
+    do {                                                          \
+        if (clip && h) LAUNCH_MT3(VEC, A, J, true, true);         \
+        else if (clip) LAUNCH_MT3(VEC, A, J, true, false);        \
+        else if (h) LAUNCH_MT3(VEC, A, J, false, true);           \
+        else LAUNCH_MT3(VEC, A, J, false, false);                 \
+    } while (0)
+    CNNQ_DISPATCH(v, LAUNCH_MT);
+#undef LAUNCH_MT
+#undef LAUNCH_MT3
+    return launch_status();
+}
+
+int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int64_t total, float* out, void* stream) {
+    if (!hist || !mt || !out || C <= 0 || total <= 0) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_mt_entropy, dim3(1), dim3(PTPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(hist), mt, (int)C, (double)total, out);
+    return launch_status();
 }
 
 int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream) {

@@ -264,8 +264,53 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
     return out[0] if len(out) == 1 else tuple(out)
 
 
-def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, group=None, want_entropy=False):
-    raise NotImplementedError('mid-tread quantization (iq.py:185-225) is not built yet')
+_MT_TABLES = {}
+
+
+def _midtread_tables(device):
+    """The (omega, alpha) interpolation tables of iq.py:41-51 as a device fp64 [2, 101] tensor."""
+    key = str(device)
+    if key not in _MT_TABLES:
+        from .qtypes._midtread_tables import ALPHA_TABLE, OMEGA_TABLE
+        _MT_TABLES[key] = torch.tensor([OMEGA_TABLE, ALPHA_TABLE], dtype=torch.float64, device=device)
+    return _MT_TABLES[key]
+
+
+def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, group=None, want_entropy=False,
+                  want_codes=False, want_parts=False):
+    """Mid-tread quantization with per-channel bin allocation (iq.py:147-225): statistics ->
+    cnnq_pc_midtread_params -> cnnq_pc_midtread_qdq (+ histogram -> entropy).  Returns
+    (y, entropy or None [, codes] [, parts])."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x, per_channel_dim)
+    local = group is False
+    grp = None if local else group
+    stats, _ = pc_stats(x, N, C, HW, need_b=bool(clip), group=grp, local_only=local)
+    tabs = _midtread_tables(x.device)
+    mt = torch.empty((L.NMT, C), dtype=torch.float32, device=x.device)
+    L.check(lib.cnnq_pc_midtread_params(_ptr(stats), C, float(target), int(bool(clip)), int(bool(sym)), _ptr(tabs),
+                                        tabs.shape[1], _ptr(mt), _stream(x)), 'cnnq_pc_midtread_params')
+    y = torch.empty_like(x)
+    codes = torch.empty_like(x) if want_codes else None
+    hist = torch.zeros(L.MT_HIST_BINS + 2 + 2 * C, dtype=torch.int64, device=x.device) if want_entropy else None
+    L.check(lib.cnnq_pc_midtread_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(mt), int(bool(clip)), _ptr(codes), _ptr(hist),
+                                     _stream(x)), 'cnnq_pc_midtread_qdq')
+    entropy = None
+    if want_entropy:
+        world = 1 if local else D.world_size(grp)
+        if world > 1:
+            D.all_reduce_sum_(hist, grp)
+        ent = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_midtread_entropy(_ptr(hist), _ptr(mt), C, x.numel() * world, _ptr(ent), _stream(x)),
+                'cnnq_midtread_entropy')
+        entropy = ent[0]
+    res = [y, entropy]
+    if want_codes:
+        res.append(codes)
+    if want_parts:
+        res.append(dict(stats=stats, mt=mt, hist=hist))
+    return tuple(res)
 
 
 def tensor_row_stats(x, rows):

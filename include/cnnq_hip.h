@@ -68,6 +68,12 @@ enum { CNNQ_QP_SCALE = 0, CNNQ_QP_ZP = 1, CNNQ_QP_QMAX = 2, CNNQ_NQP = 3 };
 /* Rows of the diagnostic table `diag[CNNQ_NDIAG][C]` written by cnnq_pc_params. */
 enum { CNNQ_DIAG_BITS = 0, CNNQ_DIAG_ALPHA = 1, CNNQ_DIAG_DELTA = 2, CNNQ_DIAG_OFFSET = 3, CNNQ_NDIAG = 4 };
 
+/* Rows of the mid-tread parameter table `mt[CNNQ_NMT][C]` and the size of its code histogram
+ * (uint64 words: CNNQ_MT_HIST_BINS integer-code bins centred on 0, 2 out-of-range bins, then
+ * 2*C counters for codes clamped to a non-integer c_min[c] / c_max[c]). */
+enum { CNNQ_MT_DELTA = 0, CNNQ_MT_CMIN = 1, CNNQ_MT_CMAX = 2, CNNQ_MT_OMEGA = 3, CNNQ_MT_ALPHA = 4, CNNQ_NMT = 5 };
+#define CNNQ_MT_HIST_BINS 131072
+
 /* library / build identification ("cnnq-hip <version> gfx950") */
 const char* cnnq_version(void);
 
@@ -168,6 +174,22 @@ int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t H
                        void* stream);
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                        float* pmm, float* qp_out, uint8_t* codes, uint64_t* hist, void* stream);
+
+/* Mid-tread quantization with per-channel BIN allocation (config 5, -mtq; iq.py:128-225):
+ *   cnnq_pc_midtread_params  stats -> mt[CNNQ_NMT][C]: omega = round(C*2^target*std^(2/3)/sum) (eq. 10),
+ *       clip != 0: alpha multiplier by linear interpolation in the 101-entry (omega, alpha) tables
+ *       (`tables` = device fp64 [2][ntab], omega row then alpha row; iq.py:41-51,137-145),
+ *       range = 2*alpha*b (sym) or max(mean,0)+alpha*b, Delta = range/omega, clamp bounds around the
+ *       quantized mean; clip == 0 (weights): range = max-min (sym) or max.  One workgroup.
+ *   cnnq_pc_midtread_qdq     y = clamp(round(x/Delta[c]), c_min[c], c_max[c]) * Delta[c] in one pass;
+ *       `codes` (optional) fp32 codes; `hist` (optional, zeroed by the caller,
+ *       CNNQ_MT_HIST_BINS + 2 + 2*C uint64 words) the code histogram.
+ *   cnnq_midtread_entropy    Shannon entropy of that histogram (equal clamp values merged). */
+int cnnq_pc_midtread_params(const float* stats, int64_t C, double target, int clip, int sym, const double* tables,
+                            int ntab, float* mt, void* stream);
+int cnnq_pc_midtread_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* mt, int clip,
+                         float* codes, uint64_t* hist, void* stream);
+int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int64_t total, float* out, void* stream);
 
 /* Shannon entropy in bits, -sum p*log2(p) over the non-empty bins -> out[0] (utils/entropy.py:12-15). */
 int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream);

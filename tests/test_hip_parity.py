@@ -310,3 +310,72 @@ def test_full_size_properties(ops):
     # error bound: |x - y| <= scale/2 inside the range
     err = (x - y).abs() - 0.5001 * qp[0].view(1, -1, 1, 1)
     assert float(err.max()) <= 0.
+
+
+# --------------------------------------------------------------------------- a14 / a15: mid-tread + entropy
+def test_midtread_golden(ops, golden):
+    """Config 5 (-mtq -me): bin allocation, table interpolation, clamp around the quantized mean and
+    the entropy of the codes.  omega (rounded bin counts) must match exactly; Delta / clamp bounds
+    derive from mean, b, std (fp64-sum tier), so codes may differ on elements at a rounding boundary."""
+    from cnn_quantization_amd import _lib as L
+    g = golden('midtread')
+    total = diff = 0
+    for key in g.np('names'):
+        key = str(key)
+        name, si = key.rsplit('_s', 1)
+        x = g.t('x' + si)
+        target = float(g.np(key + '_target'))
+        half = bool(g.np(key + '_half'))
+        y, ent, codes, parts = ops.mid_tread_qdq(dev(x), target, clip=True, sym=not half, want_entropy=True,
+                                                 want_codes=True, want_parts=True)
+        mt = parts['mt'].cpu()
+        assert np.array_equal(mt[L.MT_OMEGA].numpy(), g.np(key + '_omega')), key
+        np.testing.assert_allclose(mt[L.MT_ALPHA].numpy(), g.np(key + '_alpha_mult').astype(np.float32), rtol=1e-6,
+                                   err_msg=key)
+        ref_codes = g.np(key + '_codes')
+        c = codes.cpu().numpy()
+        d = np.abs(c - ref_codes)
+        assert d.max() <= 1.0001, key
+        total += d.size
+        diff += int((d > 1e-4).sum())
+        step = float(mt[L.MT_DELTA][mt[L.MT_OMEGA] > 0].max())
+        np.testing.assert_allclose(y.cpu().numpy(), g.np(key + '_y'), rtol=1e-5, atol=step * 1.001, err_msg=key)
+        assert abs(float(ent) - float(g.np(key + '_entropy'))) < 2e-3, (key, float(ent), float(g.np(key + '_entropy')))
+    assert diff <= 5e-4 * total, (diff, total)
+    for wi in range(2):                      # weights: no clipping, symmetric, range = max - min (exact statistics)
+        w = g.t('w%d' % wi)
+        y, ent, codes = ops.mid_tread_qdq(dev(w), 4, clip=False, sym=True, per_channel_dim=0, group=False,
+                                          want_entropy=True, want_codes=True)
+        ref = g.np('w%d_codes' % wi)
+        assert (np.abs(codes.cpu().numpy() - ref) > 0).mean() < 2e-3
+        assert abs(float(ent) - float(g.np('w%d_entropy' % wi))) < 5e-3
+
+
+def test_midtread_bit_exact_given_oracle_stats(ops, golden):
+    """With the oracle's statistics injected the mid-tread parameters, codes and floats are bit-exact."""
+    from cnn_quantization_amd import _lib as L
+    g, tab = golden('midtread'), golden('tables')
+    lib = L.load()
+    for key in g.np('names'):
+        key = str(key)
+        name, si = key.rsplit('_s', 1)
+        x = g.t('x' + si)
+        N, C = x.shape[:2]
+        HW = x.shape[2] * x.shape[3]
+        target, half = float(g.np(key + '_target')), bool(g.np(key + '_half'))
+        st = O.act_stats_perchannel(x, ['min', 'max', 'mean', 'b', 'std'])
+        table = torch.zeros(L.NSTAT, C)
+        for row, nm in ((L.STAT_MIN, 'min'), (L.STAT_MAX, 'max'), (L.STAT_MEAN, 'mean'), (L.STAT_B, 'b'),
+                        (L.STAT_STD, 'std')):
+            table[row] = st[nm]
+        table = dev(table)
+        tabs = ops._midtread_tables(table.device)
+        mt = torch.empty((L.NMT, C), dtype=torch.float32, device='cuda')
+        L.check(lib.cnnq_pc_midtread_params(ops._ptr(table), C, target, 1, int(not half), ops._ptr(tabs), 101,
+                                            ops._ptr(mt), ops._stream(table)), 'params')
+        xd = dev(x)
+        y, codes = torch.empty_like(xd), torch.empty_like(xd)
+        L.check(lib.cnnq_pc_midtread_qdq(ops._ptr(xd), ops._ptr(y), N, C, HW, ops._ptr(mt), 1, ops._ptr(codes), None,
+                                         ops._stream(xd)), 'qdq')
+        assert bits_equal(codes.cpu(), g.np(key + '_codes')), key
+        assert bits_equal(y.cpu(), g.np(key + '_y')), key
