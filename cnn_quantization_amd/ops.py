@@ -264,6 +264,45 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
     return out[0] if len(out) == 1 else tuple(out)
 
 
+def weight_correction(w, w_q, vcorr=False, bcorr=False):
+    """Per-output-channel variance / mean correction of quantized weights (iqm.py:374-391).
+    Returns a new tensor; weights are replicated across ranks, so no exchange."""
+    if not (vcorr or bcorr):
+        return w_q
+    lib = L.load()
+    w = _dev_f32(w, 'w')
+    out = _dev_f32(w_q, 'w_q').clone()
+    C, HW = w.shape[0], w.numel() // w.shape[0]
+    st_w, _ = pc_stats(w, 1, C, HW, local_only=True)
+    st_q, _ = pc_stats(out, 1, C, HW, local_only=True)
+    L.check(lib.cnnq_pc_weight_correct(_ptr(out), C, HW, _ptr(st_w), _ptr(st_q), int(bool(vcorr)), int(bool(bcorr)),
+                                       _stream(out)), 'cnnq_pc_weight_correct')
+    return out.view(w_q.shape)
+
+
+def act_bias_correction_(out, out_q, relu_first, group=None):
+    """Activation bias correction (iqm.py:180-196), IN PLACE on out_q; `out` is the unquantized
+    activation.  With world size > 1 the per-channel sums are exchanged so the bias is global."""
+    lib = L.load()
+    x = _dev_f32(out, 'out')
+    if not (isinstance(out_q, torch.Tensor) and out_q.is_cuda and out_q.is_contiguous() and out_q.dtype == torch.float32):
+        raise L.CnnqError('out_q must be a contiguous float32 device tensor')
+    N, C, HW = geometry(x)
+    G = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0 and out_q.data_ptr() % 16 == 0))
+    part3 = torch.empty((G, 3, C), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_pc_bcorr_sums(_ptr(x), _ptr(out_q), N, C, HW, int(bool(relu_first)), _ptr(part3), _stream(x)),
+            'cnnq_pc_bcorr_sums')
+    bias = torch.empty(C, dtype=torch.float32, device=x.device)
+    if D.world_size(group) > 1:
+        sums = torch.empty((3, C), dtype=torch.float64, device=x.device)
+        L.check(lib.cnnq_pc_bcorr_bias(_ptr(part3), G, C, _ptr(sums), None, _stream(x)), 'cnnq_pc_bcorr_bias')
+        part3 = D.all_gather_records(sums, group)
+        G = part3.shape[0]
+    L.check(lib.cnnq_pc_bcorr_bias(_ptr(part3), G, C, None, _ptr(bias), _stream(x)), 'cnnq_pc_bcorr_bias')
+    L.check(lib.cnnq_pc_bcorr_apply(_ptr(out_q), N, C, HW, _ptr(bias), _stream(x)), 'cnnq_pc_bcorr_apply')
+    return out_q
+
+
 _MT_TABLES = {}
 
 

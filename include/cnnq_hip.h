@@ -175,6 +175,24 @@ int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t H
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                        float* pmm, float* qp_out, uint8_t* codes, uint64_t* hist, void* stream);
 
+/* Weight bias / variance correction after quantization (iqm.py:374-391), in place on
+ * wq[C][HW]: vcorr: wq = (wq - mean_q) * std_w/(std_q + 1e-8) + mean_q; bcorr: wq = wq - mean_q + mean_w
+ * (mean_q is the pre-correction mean in both), with the reference's operation order.  stats_w /
+ * stats_q are the stats tables (rows MEAN, STD) of the original and the quantized weights. */
+int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_w, const float* stats_q, int vcorr,
+                           int bcorr, void* stream);
+
+/* Activation bias correction (iqm.py:180-196; -sm use with -bca):
+ *   cnnq_pc_bcorr_sums   per channel sum(x'), sum(y), count(x' > 0), x' = relu(x) when relu_first,
+ *                        -> part3[G][3][C] fp64 (G = cnnq_pc_groups);
+ *   cnnq_pc_bcorr_bias   merges G records (or W ranks' sums) -> sums[3][C] (optional, for the
+ *                        cross-rank exchange) and bias[c] = (sum x' - sum y)/(count + 1e-8);
+ *   cnnq_pc_bcorr_apply  y += (y > 0) * bias[c], in place. */
+int cnnq_pc_bcorr_sums(const float* x, const float* y, int64_t N, int64_t C, int64_t HW, int relu_first,
+                       double* part3, void* stream);
+int cnnq_pc_bcorr_bias(const double* part3, int G, int64_t C, double* sums, float* bias, void* stream);
+int cnnq_pc_bcorr_apply(float* y, int64_t N, int64_t C, int64_t HW, const float* bias, void* stream);
+
 /* Mid-tread quantization with per-channel BIN allocation (config 5, -mtq; iq.py:128-225):
  *   cnnq_pc_midtread_params  stats -> mt[CNNQ_NMT][C]: omega = round(C*2^target*std^(2/3)/sum) (eq. 10),
  *       clip != 0: alpha multiplier by linear interpolation in the 101-entry (omega, alpha) tables

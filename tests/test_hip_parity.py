@@ -379,3 +379,34 @@ def test_midtread_bit_exact_given_oracle_stats(ops, golden):
                                          ops._stream(xd)), 'qdq')
         assert bits_equal(codes.cpu(), g.np(key + '_codes')), key
         assert bits_equal(y.cpu(), g.np(key + '_y')), key
+
+
+# --------------------------------------------------------------------------- a11 / a12: corrections
+@pytest.mark.parametrize('wshape', [(16, 8, 3, 3), (10, 64), (24, 3, 7, 7), (300, 5, 1, 1)])
+@pytest.mark.parametrize('vc,bc', [(False, True), (True, False), (True, True)])
+def test_weight_correction_vs_oracle(ops, wshape, vc, bc):
+    """iqm.py:374-391.  Per-channel means / stds are fp64-sum tier, so agreement is ~1e-6 relative."""
+    gen = torch.Generator().manual_seed(21)
+    w = torch.randn(wshape, generator=gen) * 0.05 + 0.01
+    wq = O.weights_per_channel_qdq(w, 4)
+    ref = O.weight_correction(w, wq, vcorr=vc, bcorr=bc)
+    out = ops.weight_correction(dev(w), dev(wq), vcorr=vc, bcorr=bc).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-5, atol=2e-7)
+    # the corrected weights have the original per-channel mean (bcorr) / std (vcorr)
+    if bc:
+        np.testing.assert_allclose(out.view(wshape[0], -1).mean(-1), w.view(wshape[0], -1).mean(-1), atol=2e-6)
+    if vc and not bc:
+        np.testing.assert_allclose(out.view(wshape[0], -1).std(-1), w.view(wshape[0], -1).std(-1), rtol=1e-4)
+
+
+@pytest.mark.parametrize('shape', [(4, 8, 7, 7), (3, 20, 14, 14), (2, 5, 33, 31)])
+@pytest.mark.parametrize('relu_first', [False, True])
+def test_act_bias_correction_vs_oracle(ops, shape, relu_first):
+    """iqm.py:188-196."""
+    gen = torch.Generator().manual_seed(22)
+    x = torch.randn(shape, generator=gen) * 2 + 0.4
+    xq = O.act_per_channel_qdq(x, 4, half_range=relu_first)
+    ref = O.act_bias_correction(x, xq.clone(), relu_first)
+    out = ops.act_bias_correction_(dev(x), dev(xq).clone(), relu_first).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(out == 0, ref == 0)
