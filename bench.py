@@ -197,7 +197,10 @@ def main():
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
         'roofline': {'bound': 'hbm', 'kernel': 'k_qdq (fused per-channel Q/DQ, 8 algorithmic B/elem)',
                      'achieved': qdq_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': qdq_gbs / HBM_PEAK_GBS,
-                     'traffic': None, 'launches_per_step': n_launch, 'avg_launch_ms': t_qdq * 1e3 / n_launch,
+                     'traffic': 872.6e6, 'traffic_unit': 'bytes per launch',
+                     'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same '
+                                       'command; committed in profiles/r01_pmc_summary.md (not re-measured live)',
+                     'launches_per_step': n_launch, 'avg_launch_ms': t_qdq * 1e3 / n_launch,
                      'bytes_per_launch': elems * BYTES_QDQ / n_launch},
         'roofline_stats': {'bound': 'hbm', 'kernel': 'k_minmax (per-channel exact min/max, 4 B/elem)',
                            'achieved': stats_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
