@@ -55,7 +55,8 @@ def laplace_activation(shape, gen_seed, device):
     x = torch.empty(shape, device=device, dtype=torch.float32)
     chunk = max(1, (1 << 26) // (C * H * W))       # bound the temporaries
     for n0 in range(0, N, chunk):
-        u = torch.rand((min(chunk, N - n0), C, H, W), generator=g, device=device) - 0.5
+        # |u| < 0.5 strictly: rand() == 0 would give log1p(-1) = -inf (about 6 samples per 100 M)
+        u = (torch.rand((min(chunk, N - n0), C, H, W), generator=g, device=device) - 0.5) * (1 - 2 ** -20)
         x[n0:n0 + chunk] = mu.view(1, C, 1, 1) - b.view(1, C, 1, 1) * torch.sign(u) * torch.log1p(-2 * u.abs())
     return x
 

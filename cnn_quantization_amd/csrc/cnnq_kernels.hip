@@ -29,7 +29,7 @@
 namespace {
 
 constexpr int TPB = 256;       // 4 wave64 per workgroup
-constexpr int MAXCH = 1024;    // max channels a workgroup can own (mode 2, H*W/VEC == 1)
+constexpr int MAXCH = 256;     // max channels a workgroup owns (keeps the per-channel LDS tables at 1 KB each)
 
 struct Geo {
     int N, C, HW;
@@ -712,8 +712,9 @@ __global__ void __launch_bounds__(TPB) k_minmax_reduce(const float* __restrict__
 }
 
 // Code histogram (for the Shannon entropy of utils/entropy.py:6-17): 256 bins x 32 replicas in
-// LDS, replica = lane & 31 so the 32 lanes of a service group hit 32 different banks (no
-// conflicts however skewed the codes are); replicas are summed and flushed once per workgroup.
+// LDS (32 KB), replica = lane & 31: address % 32 == lane % 32, so the 32 lanes of an LDS service
+// group always hit 32 different banks however skewed the codes are (measured with 8 replicas: 90 %
+// of the LDS cycles were bank conflicts, ~18 cycles per atomic); flushed once per workgroup.
 constexpr int HREP = 32;
 #ifndef QDQ_NT
 #define QDQ_NT 3  // bit 0: non-temporal loads of x, bit 1: non-temporal stores of y
@@ -816,6 +817,10 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
     int col[J];
     bool ok[J];
     float sc[J][A], zp[J][A], qm[J][A];
+    // histogram: the code of x == 0 (the zero point) is by far the most frequent one (about half
+    // of a half-range layer); counting it in a register per lane instead of an LDS atomic removes
+    // the same-address serialisation that otherwise doubles the kernel time
+    unsigned nzp[HIST ? J : 1][HIST ? A : 1];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int c = b.col0 + j * TPB + tid;
@@ -828,6 +833,7 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
             sc[j][a] = sh_sc[ch];
             zp[j][a] = sh_zp[ch];
             qm[j][a] = sh_qm[ch];
+            if constexpr (HIST) nzp[j][a] = 0u;
         }
     }
     const int nrows = b.n1 - b.n0;
@@ -855,8 +861,11 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
                 else stv<VEC>(y + off + (size_t)col[j] * VEC, o);
                 if constexpr (HIST) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        atomicAdd(&sh_hist[((unsigned)(int)cd[e] & 255u) * HREP + (tid & (HREP - 1))], 1u);
+                    for (int e = 0; e < VEC; ++e) {
+                        const int a = (A == 1 ? 0 : e);
+                        if (cd[e] == zp[j][a]) ++nzp[j][a];
+                        else atomicAdd(&sh_hist[((unsigned)(int)cd[e] & 255u) * HREP + (tid & (HREP - 1))], 1u);
+                    }
                 }
                 if constexpr (CODES) {
                     uint8_t* cp = codes + off + (size_t)col[j] * VEC;
@@ -872,6 +881,11 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
         }
     }
     if constexpr (HIST) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+                if (nzp[j][a]) atomicAdd(&sh_hist[((unsigned)(int)zp[j][a] & 255u) * HREP + (tid & (HREP - 1))], nzp[j][a]);
         __syncthreads();
         unsigned tot = 0;
 #pragma unroll 8
@@ -982,25 +996,43 @@ template <int VEC, int A, int J, bool CLIP, bool HIST, bool CODES>
 __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
                                                 const float* __restrict__ mt, float* __restrict__ codes,
                                                 unsigned long long* __restrict__ hist) {
+    // LDS histogram window: MT_W integer codes starting at the smallest clamp bound of this
+    // workgroup's channels (codes are >= c_min), MT_REP replicas by lane to spread equal codes;
+    // codes beyond the window (a channel with > MT_W bins) go to the global bins directly.
+    // The first MT_HOT codes of the window (where the mass is) get 32 lane-replicas = conflict-free,
+    // the tail 8.
+    constexpr int MT_W = 512, MT_HOT = 64, MT_REP = 8;
+    constexpr int MT_WORDS = MT_HOT * 32 + (MT_W - MT_HOT) * MT_REP;
+    auto hidx = [](unsigned kk, int tid) -> unsigned {
+        return kk < (unsigned)MT_HOT ? kk * 32u + (unsigned)(tid & 31)
+                                     : (unsigned)(MT_HOT * 32) + (kk - MT_HOT) * MT_REP + (unsigned)(tid & (MT_REP - 1));
+    };
     __shared__ float sh_d[MAXCH], sh_lo[MAXCH], sh_hi[MAXCH];
-    __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
+    __shared__ unsigned sh_hist[HIST ? MT_WORDS : 1];
     __shared__ unsigned sh_clo[HIST ? MAXCH : 1], sh_chi[HIST ? MAXCH : 1];
+    __shared__ int sh_wstart;
     const Blk b = blk_of<VEC>(g);
     const int tid = threadIdx.x;
     const int nch = b.c1 - b.c0;
     if constexpr (HIST) {
-        for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
+        for (int i = tid; i < MT_WORDS; i += TPB) sh_hist[i] = 0u;
         for (int i = tid; i < nch; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
-    }
-    for (int i = tid; i < nch; i += TPB) {
-        sh_d[i] = mt[(size_t)CNNQ_MT_DELTA * g.C + b.c0 + i];
-        sh_lo[i] = mt[(size_t)CNNQ_MT_CMIN * g.C + b.c0 + i];
-        sh_hi[i] = mt[(size_t)CNNQ_MT_CMAX * g.C + b.c0 + i];
+        if (tid == 0) sh_wstart = CLIP ? 0x7fffffff : -MT_W / 2;
     }
     __syncthreads();
+    for (int i = tid; i < nch; i += TPB) {
+        sh_d[i] = mt[(size_t)CNNQ_MT_DELTA * g.C + b.c0 + i];
+        const float lo_i = mt[(size_t)CNNQ_MT_CMIN * g.C + b.c0 + i];
+        sh_lo[i] = lo_i;
+        sh_hi[i] = mt[(size_t)CNNQ_MT_CMAX * g.C + b.c0 + i];
+        if constexpr (HIST && CLIP) atomicMin(&sh_wstart, (int)floorf(fminf(fmaxf(lo_i, -1e9f), 1e9f)));
+    }
+    __syncthreads();
+    const int wstart = HIST ? max(sh_wstart, -MT_NB / 2) : 0;
     int col[J], chl[J][A];
     bool ok[J];
     float d[J][A], lo[J][A], hi[J][A];
+    unsigned nzero = 0;  // code 0 (the mode of the distribution) is counted in a register, see k_qdq
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int c = b.col0 + j * TPB + tid;
@@ -1048,15 +1080,21 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
                     for (int e = 0; e < VEC; ++e) {
                         const int a = (A == 1 ? 0 : e);
                         const float t = q[e];
-                        if (t == rintf(t)) {
-                            const int k = (int)fminf(fmaxf(t, -1e9f), 1e9f);
-                            if (k >= -128 && k < 128) atomicAdd(&sh_hist[(unsigned)(k + 128) * HREP + (tid & (HREP - 1))], 1u);
-                            else if (k >= -MT_NB / 2 && k < MT_NB / 2) atomicAdd(&hist[k + MT_NB / 2], 1ull);
-                            else atomicAdd(&hist[k < 0 ? MT_NB : MT_NB + 1], 1ull);
-                        } else if (CLIP && t == hi[j][a]) {
+                        // fast path (branch-light): integer code inside the LDS window
+                        const int k = (int)t;                       // saturating; NaN -> 0
+                        const bool isint = ((float)k == t);
+                        const unsigned kk = (unsigned)(k - wstart);
+                        if (t == 0.f) {
+                            ++nzero;
+                        } else if (isint && kk < (unsigned)MT_W) {
+                            atomicAdd(&sh_hist[hidx(kk, tid)], 1u);
+                        } else if (t == rintf(t)) {                 // rare: integer code outside the window
+                            if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
+                            else atomicAdd(&hist[t < 0.f ? MT_NB : MT_NB + 1], 1ull);
+                        } else if (CLIP && t == hi[j][a]) {         // rare: clamped to a non-integer bound
                             atomicAdd(&sh_chi[chl[j][a]], 1u);
                         } else {
-                            atomicAdd(&sh_clo[chl[j][a]], 1u);   // non-integer clamp value c_min (or NaN)
+                            atomicAdd(&sh_clo[chl[j][a]], 1u);      // non-integer c_min (or NaN)
                         }
                     }
                 }
@@ -1064,11 +1102,19 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
         }
     }
     if constexpr (HIST) {
+        if (nzero) {
+            const int kk = -wstart;
+            if (kk >= 0 && kk < MT_W) atomicAdd(&sh_hist[hidx((unsigned)kk, tid)], nzero);
+            else atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
+        }
         __syncthreads();
-        unsigned tot = 0;
-#pragma unroll 8
-        for (int r = 0; r < HREP; ++r) tot += sh_hist[tid * HREP + ((r + tid) & (HREP - 1))];
-        if (tot) atomicAdd(&hist[tid - 128 + MT_NB / 2], (unsigned long long)tot);
+        for (int i = tid; i < MT_W; i += TPB) {
+            unsigned tot = 0;
+            const int nrep = i < MT_HOT ? 32 : MT_REP;
+            for (int r = 0; r < nrep; ++r) tot += sh_hist[hidx((unsigned)i, r + tid)];
+            const int k = wstart + i;
+            if (tot && k < MT_NB / 2) atomicAdd(&hist[k + MT_NB / 2], (unsigned long long)tot);
+        }
         for (int i = tid; i < nch; i += TPB) {
             if (sh_clo[i]) atomicAdd(&hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]);
             if (sh_chi[i]) atomicAdd(&hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]);
@@ -1089,16 +1135,32 @@ __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* _
         const unsigned long long c = hist[i];
         if (c) { const float pr = (float)c / ftotal; e += (double)(-pr * log2f(pr)); }
     }
+    // non-integer clamp values: one histogram entry per (channel, bound); equal values are merged.
+    // The pairwise scan runs out of LDS (2*C <= MT_ENT entries), from global memory beyond that.
     const unsigned long long* cl = hist + MT_NB + 2;
-    for (int i = tid; i < 2 * C; i += PTPB) {
-        if (!cl[i]) continue;
-        const float vi = mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
+    constexpr int MT_ENT = 4096;
+    __shared__ float sv[MT_ENT];
+    __shared__ unsigned sc[MT_ENT];
+    const int n2 = 2 * C;
+    const bool in_lds = n2 <= MT_ENT;
+    if (in_lds) {
+        for (int i = tid; i < n2; i += PTPB) {
+            sv[i] = mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
+            sc[i] = (unsigned)cl[i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n2; i += PTPB) {
+        const unsigned long long ci = in_lds ? sc[i] : cl[i];
+        if (!ci) continue;
+        const float vi = in_lds ? sv[i] : mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
         bool dup = false;
-        unsigned long long cnt = cl[i];
-        for (int j = 0; j < 2 * C; ++j) {
-            if (j == i || !cl[j]) continue;
-            const float vj = mt[(size_t)(j < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (j < C ? j : j - C)];
-            if (vj == vi) { if (j < i) { dup = true; break; } cnt += cl[j]; }
+        unsigned long long cnt = ci;
+        for (int j = 0; j < n2; ++j) {
+            const unsigned long long cj = in_lds ? sc[j] : cl[j];
+            if (j == i || !cj) continue;
+            const float vj = in_lds ? sv[j] : mt[(size_t)(j < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (j < C ? j : j - C)];
+            if (vj == vi) { if (j < i) { dup = true; break; } cnt += cj; }
         }
         if (dup) continue;
         const float pr = (float)cnt / ftotal;
@@ -1402,6 +1464,7 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, i
         const int m = 4 / gcd_i((int)(HW % 4), 4);
         if (cbeg % m != 0) return CNNQ_EINVAL;  // the range must start on a 16-byte boundary
         int k = (int)((cap * 4) / HW);
+        if (k > MAXCH) k = MAXCH;
         k -= k % m;
         g->mode = 2;
         g->k = k;
@@ -1420,6 +1483,7 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, i
         } else {
             g->mode = 2;
             g->k = (int)(cap / cpc);
+            if (g->k > MAXCH) g->k = MAXCH;
             g->ncb = (int)((Cn + g->k - 1) / g->k);
         }
     }
