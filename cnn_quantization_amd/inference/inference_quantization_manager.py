@@ -164,6 +164,13 @@ class LinearWithId(nn.Linear):
         return out
 
 
+def reset_layer_counters():
+    """Restart the per-class id counters (a new experiment in the same process; the reference runs
+    one model per process and never needs this)."""
+    for cls in (ReLUWithId, MaxPool2dWithId, AvgPool2dWithId, BatchNorm2dWithId, Conv2dWithId, LinearWithId):
+        cls._id = count(0)
+
+
 _PATCHED = {'Linear': LinearWithId, 'Conv2d': Conv2dWithId, 'BatchNorm2d': BatchNorm2dWithId,
             'MaxPool2d': MaxPool2dWithId, 'AvgPool2d': AvgPool2dWithId, 'ReLU': ReLUWithId}
 
