@@ -128,6 +128,21 @@ struct Mom {
             rss = fma(r, r, rss);
         }
     }
+    // four values of ONE channel (a float4 that does not straddle): the 4-sums are formed in fp32
+    // (each rounding is unbiased and relative to a 4-term sum, far below the fp32 result precision
+    // once thousands of them are accumulated in fp64) - 4 instead of 12 fp64-rate ops per float4
+    template <bool RELU>
+    __device__ __forceinline__ void add4(const float (&v)[4]) {
+        mn = fminf(fminf(mn, fminf(v[0], v[1])), fminf(v[2], v[3]));
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        s += (double)((v[0] + v[1]) + (v[2] + v[3]));
+        ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+        if constexpr (RELU) {
+            const float r0 = fmaxf(v[0], 0.f), r1 = fmaxf(v[1], 0.f), r2 = fmaxf(v[2], 0.f), r3 = fmaxf(v[3], 0.f);
+            rs += (double)((r0 + r1) + (r2 + r3));
+            rss += (double)((r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3));
+        }
+    }
     template <bool RELU>
     __device__ __forceinline__ void merge(const Mom& o) {
         mn = fminf(mn, o.mn);
@@ -195,9 +210,14 @@ __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, co
 #pragma unroll
         for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
 #pragma unroll
-        for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j) {
+            if constexpr (VEC == 4 && A == 1) {
+                acc[j][0].template add4<RELU>(v[j]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[j][A == 1 ? 0 : e].template add<RELU>(v[j][e]);
+                for (int e = 0; e < VEC; ++e) acc[j][A == 1 ? 0 : e].template add<RELU>(v[j][e]);
+            }
+        }
     }
 
     const double rows = (double)(b.n1 - b.n0);
@@ -367,9 +387,12 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
             sk[j][a] = 0.;
         }
     }
-    const float* row = x + (size_t)b.n0 * (size_t)g.P;
+    const int nrows = b.n1 - b.n0;
 #pragma unroll 2
-    for (int n = b.n0; n < b.n1; ++n, row += g.P) {
+    for (int r = 0; r < nrows; ++r) {
+        // pass B follows pass A over the same tensor: walking it backwards (g.rev) re-reads what
+        // pass A touched last from the Infinity Cache
+        const float* row = x + (size_t)(g.rev ? b.n1 - 1 - r : b.n0 + r) * (size_t)g.P;
         float v[J][VEC];
 #pragma unroll
         for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
@@ -1582,7 +1605,7 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
     if (!x || !stats || !part2) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    const int rc = plan(N, C, HW, al16(x), 0, &v, &g);
+    const int rc = plan(N, C, HW, al16(x), /*rev=*/1, &v, &g);   // descending: follows the ascending pass A
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
