@@ -82,7 +82,8 @@ def run_step(ops, layers, group):
 def time_kernel_classes(layers):
     """Device time per kernel class, measured live with HIP events recorded on the launch stream
     between the launches of ONE pass that issues exactly the sequence cnnq_pc_minmax_qdq issues
-    (so cache state is the real one).  Returns {class: (seconds, launches)}."""
+    (so cache state is the real one; the ~3 us parameter kernel is charged to k_qdq).  Returns
+    {class: (seconds, launches)}."""
     import ctypes
     from cnn_quantization_amd import _lib
     lib = _lib.load()
@@ -92,12 +93,13 @@ def time_kernel_classes(layers):
         x, y, N, C, HW = L['x'], L['y'], L['N'], L['C'], L['HW']
         G = lib.cnnq_pc_groups(N, C, HW, 1)
         pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
+        qp = torch.empty((3, C), dtype=torch.float32, device=x.device)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
         _lib.check(lib.cnnq_pc_minmax(x.data_ptr(), N, C, HW, pmm.data_ptr(), st), 'minmax')
         e[1].record()
-        _lib.check(lib.cnnq_pc_qdq_minmax(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']), pmm.data_ptr(),
-                                          G, None, None, None, 1, st), 'qdq')
+        _lib.check(lib.cnnq_pc_minmax_params(pmm.data_ptr(), G, C, 4, int(L['half']), qp.data_ptr(), st), 'params')
+        _lib.check(lib.cnnq_pc_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, qp.data_ptr(), None, None, 1, st), 'qdq')
         e[2].record()
         recs.append(e)
     torch.cuda.synchronize()

@@ -719,19 +719,29 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
     }
 }
 
-// pmm[G][2][C] -> out[2][C]: the rank-local extrema that ranks exchange (all_gather) before the
-// fused Q/DQ reduces the W gathered pairs in its prologue
-__global__ void __launch_bounds__(TPB) k_minmax_reduce(const float* __restrict__ pmm, int G, int C,
-                                                       float* __restrict__ out) {
-    const int c = blockIdx.x * TPB + threadIdx.x;
-    if (c >= C) return;
-    float mn = INFINITY, mx = -INFINITY;
-    for (int gi = 0; gi < G; ++gi) {
+// one wave64 per channel reduces the G {min, max} pairs of that channel: lanes stride over the
+// groups (independent loads in flight), then a shuffle reduction - a serial loop over G in one
+// thread cost 10-26 us per call (measured), this form ~3 us
+__device__ __forceinline__ void reduce_pairs(const float* __restrict__ pmm, int G, int C, int c, float& mn, float& mx) {
+    const int lane = threadIdx.x & 63;
+    mn = INFINITY;
+    mx = -INFINITY;
+    for (int gi = lane; gi < G; gi += 64) {
         mn = fminf(mn, pmm[(size_t)(2 * gi) * C + c]);
         mx = fmaxf(mx, pmm[(size_t)(2 * gi + 1) * C + c]);
     }
-    out[c] = mn;
-    out[C + c] = mx;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, shfl_xor_f(mn, m)); mx = fmaxf(mx, shfl_xor_f(mx, m)); }
+}
+
+// pmm[G][2][C] -> out[2][C]: the rank-local extrema that ranks exchange (all_gather)
+__global__ void __launch_bounds__(TPB) k_minmax_reduce(const float* __restrict__ pmm, int G, int C,
+                                                       float* __restrict__ out) {
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float mn, mx;
+    reduce_pairs(pmm, G, C, c, mn, mx);
+    if ((threadIdx.x & 63) == 0) { out[c] = mn; out[C + c] = mx; }
 }
 
 // Code histogram (for the Shannon entropy of utils/entropy.py:6-17): 256 bins x 32 replicas in
@@ -768,21 +778,33 @@ __device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[V
     }
 }
 
-// FUSED: the per-channel parameters are derived in the prologue from the exact min/max keys
-// (config 2: delta = max - min, or max with a zero minimum; iq.py:409-424,559-572) instead of
-// being read from a table - no parameter kernel between the statistics and the Q/DQ pass.
-struct FusedCfg {
-    int num_bits;
-    int positive;
-    int G;  // min/max pairs per channel in pmm[G][2][C]
-};
+// pmm[G][2][C] -> qp[3][C] for config 2 (iq.py:409-424,559-572): delta = max - min (or max with a
+// zero minimum), scale = max(delta / qmax, 1e-8), zero_point = round(0 - offset/scale).  One
+// wave per channel; G is the groups of one tensor or the world size after the all_gather.
+__global__ void __launch_bounds__(TPB) k_minmax_params(const float* __restrict__ pmm, int G, int C, int num_bits,
+                                                       int positive, float* __restrict__ qp) {
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float mn, mx;
+    reduce_pairs(pmm, G, C, c, mn, mx);
+    if ((threadIdx.x & 63) != 0) return;
+    const float offset = positive ? 0.f : mn;
+    const float delta = mx - offset;
+    const float qm = (float)((1u << num_bits) - 1u);
+    float sc = delta / qm;
+    sc = (sc < 1e-8f) ? 1e-8f : sc;
+    qp[(size_t)CNNQ_QP_SCALE * C + c] = sc;
+    qp[(size_t)CNNQ_QP_ZP * C + c] = rintf(0.f - offset / sc);
+    qp[(size_t)CNNQ_QP_QMAX * C + c] = qm;
+}
 
-template <int VEC, int A, int J, bool CODES, bool HIST, bool FUSED>
+// The fused Q/DQ.  Launched with MANY short workgroups in address order (about 14 KB of x each,
+// see make_geo `fine`): measured on MI355X, read+write streaming runs at 6.1-6.7 TB/s this way
+// against 5.4 TB/s when a workgroup walks 30+ samples (tools/ubench_copy.py, tools/split_probe.py).
+template <int VEC, int A, int J, bool CODES, bool HIST>
 __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
                                              const float* __restrict__ qp, uint8_t* __restrict__ codes,
-                                             unsigned long long* __restrict__ hist,
-                                             const float* __restrict__ pmm, const FusedCfg fc,
-                                             float* __restrict__ qp_out) {
+                                             unsigned long long* __restrict__ hist) {
     __shared__ float sh_sc[MAXCH], sh_zp[MAXCH], sh_qm[MAXCH];
     __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
     const Blk b = blk_of<VEC>(g);
@@ -790,51 +812,11 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
     if constexpr (HIST) {
         for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
     }
-    const int nch = b.c1 - b.c0;
-    if constexpr (FUSED) {
-        // reduce the G {min, max} pairs of this workgroup's channels: all lanes load (coalesced
-        // along channels), LDS integer atomics on order-preserving keys do the reduction
-        unsigned* kmin = reinterpret_cast<unsigned*>(sh_zp);
-        unsigned* kmax = reinterpret_cast<unsigned*>(sh_qm);
-        for (int i = tid; i < nch; i += TPB) { kmin[i] = 0xffffffffu; kmax[i] = 0u; }
-        __syncthreads();
-        const int total = nch * fc.G;
-        for (int t = tid; t < total; t += TPB) {
-            const int gi = t / nch, i = t - gi * nch;
-            const float* pp = pmm + (size_t)(2 * gi) * g.C + b.c0 + i;
-            atomicMin(&kmin[i], f2key(pp[0]));
-            atomicMax(&kmax[i], f2key(pp[g.C]));
-        }
-        __syncthreads();
-    }
     // stage this workgroup's channels once (coalesced), then every lane keeps its own in registers
-    for (int i = tid; i < nch; i += TPB) {
-        const int c = b.c0 + i;
-        float sc, zp, qm;
-        if constexpr (FUSED) {
-            const float mn = key2f(reinterpret_cast<unsigned*>(sh_zp)[i]);
-            const float mx = key2f(reinterpret_cast<unsigned*>(sh_qm)[i]);
-            const float offset = fc.positive ? 0.f : mn;
-            const float delta = mx - offset;
-            qm = (float)((1u << fc.num_bits) - 1u);
-            sc = delta / qm;
-            sc = (sc < 1e-8f) ? 1e-8f : sc;
-            zp = rintf(0.f - offset / sc);
-            // one workgroup per channel publishes the table (diagnostics / codes consumers)
-            const bool first = (b.n0 == 0) && (g.mode == 2 || b.col0 == c * (g.HW / VEC));
-            if (qp_out && first) {
-                qp_out[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
-                qp_out[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
-                qp_out[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
-            }
-        } else {
-            sc = qp[(size_t)CNNQ_QP_SCALE * g.C + c];
-            zp = qp[(size_t)CNNQ_QP_ZP * g.C + c];
-            qm = qp[(size_t)CNNQ_QP_QMAX * g.C + c];
-        }
-        sh_sc[i] = sc;
-        sh_zp[i] = zp;
-        sh_qm[i] = qm;
+    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+        sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+        sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+        sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
     }
     __syncthreads();
     int col[J];
@@ -1473,10 +1455,11 @@ int choose_variant(int64_t N, int64_t C, int64_t HW, bool aligned16, Variant* v)
 }
 
 // Geometry of one launch over channels [cbeg, cbeg + Cn) of x[N][C][HW].
-// max_groups > 0 bounds the batch splits S (every kernel uses MAXG so that all passes over one
-// tensor share one geometry and one group count G = S * nb).
+// max_groups > 0 bounds the batch splits S of the passes that emit one partial record per group
+// and channel (they all use MAXG, so they share one group count G = S * nb); `fine` requests the
+// short-workgroup geometry of the table-driven elementwise passes instead.
 int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, int64_t Cn, int max_groups, int rev,
-             Geo* g) {
+             int fine, Geo* g) {
     if (N <= 0 || C <= 0 || HW <= 0 || cbeg < 0 || Cn <= 0 || cbeg + Cn > C) return CNNQ_EINVAL;
     if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31) return CNNQ_ERANGE;
     g->N = (int)N; g->C = (int)C; g->HW = (int)HW; g->P = (int)(C * HW);
@@ -1515,6 +1498,16 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, i
     int64_t S = (target + g->ncb - 1) / g->ncb;
     if (S > N) S = N;
     if (max_groups > 0 && S > max_groups) S = max_groups;
+    if (fine) {
+        // table-driven elementwise passes (no per-workgroup reduction or partial record): many short
+        // workgroups dispatched in address order - about 14 KB of x per workgroup - stream read+write
+        // markedly faster than long-lived ones (6.1-6.7 vs 5.4 TB/s measured)
+        const int64_t cols = (g->mode == 1) ? g->w : (int64_t)g->k * HW * v.A / v.vec / v.A;
+        const int64_t row_bytes = cols * v.vec * 4;
+        int64_t rows = (14336 + row_bytes / 2) / (row_bytes > 0 ? row_bytes : 1);
+        if (rows < 1) rows = 1;
+        S = (N + rows - 1) / rows;
+    }
     if (S < 1) S = 1;
     g->S = (int)S;
     if ((int64_t)g->S * g->ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
@@ -1525,9 +1518,9 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline int launch_status() { return (int)hipGetLastError(); }
 
 // one plan (load shape + geometry) per tensor, shared by every pass over it
-int plan(int64_t N, int64_t C, int64_t HW, bool aligned16, int rev, Variant* v, Geo* g) {
+int plan(int64_t N, int64_t C, int64_t HW, bool aligned16, int rev, Variant* v, Geo* g, int fine = 0) {
     choose_variant(N, C, HW, aligned16, v);
-    return make_geo(N, C, HW, *v, 0, C, MAXG, rev, g);
+    return make_geo(N, C, HW, *v, 0, C, MAXG, rev, fine, g);
 }
 
 // dispatch on the runtime load shape: invokes F<VEC, A, J>()
@@ -1541,20 +1534,15 @@ int plan(int64_t N, int64_t C, int64_t HW, bool aligned16, int rev, Variant* v, 
         else { F(1, 1, 4); }                                         \
     } while (0)
 
-template <bool FUSED>
 int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const float* qp, uint8_t* codes,
-               unsigned long long* h, const float* pmm, FusedCfg fc, float* qp_out, hipStream_t st) {
+               unsigned long long* h, hipStream_t st) {
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
-#define LAUNCH_QDQ(VEC, A, J)                                                                                  \
-    do {                                                                                                       \
-        if (codes && h) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, true, FUSED>), grid, block, 0, st, x, y, g, qp, \
-                                           codes, h, pmm, fc, qp_out);                                         \
-        else if (codes) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, false, FUSED>), grid, block, 0, st, x, y, g, qp, \
-                                           codes, h, pmm, fc, qp_out);                                         \
-        else if (h) hipLaunchKernelGGL((k_qdq<VEC, A, J, false, true, FUSED>), grid, block, 0, st, x, y, g, qp,  \
-                                       codes, h, pmm, fc, qp_out);                                             \
-        else hipLaunchKernelGGL((k_qdq<VEC, A, J, false, false, FUSED>), grid, block, 0, st, x, y, g, qp, codes, \
-                                h, pmm, fc, qp_out);                                                           \
+#define LAUNCH_QDQ(VEC, A, J)                                                                                       \
+    do {                                                                                                            \
+        if (codes && h) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, true>), grid, block, 0, st, x, y, g, qp, codes, h);   \
+        else if (codes) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, false>), grid, block, 0, st, x, y, g, qp, codes, h);  \
+        else if (h) hipLaunchKernelGGL((k_qdq<VEC, A, J, false, true>), grid, block, 0, st, x, y, g, qp, codes, h);      \
+        else hipLaunchKernelGGL((k_qdq<VEC, A, J, false, false>), grid, block, 0, st, x, y, g, qp, codes, h);            \
     } while (0)
     CNNQ_DISPATCH(v, LAUNCH_QDQ);
 #undef LAUNCH_QDQ
@@ -1641,14 +1629,15 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg, fl
 }
 
 int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, uint8_t* codes,
-                uint64_t* hist, void* stream) {
+                uint64_t* hist, int reverse, void* stream) {
     if (!x || !y || !qp) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), 0, &v, &g);
+    // the histogram variant zeroes and flushes an LDS table per workgroup: keep its workgroups long
+    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), reverse ? 1 : 0, &v,
+                        &g, /*fine=*/hist ? 0 : 1);
     if (rc) return rc;
-    return launch_qdq<false>(x, y, g, v, qp, codes, reinterpret_cast<unsigned long long*>(hist), nullptr,
-                             FusedCfg{0, 0, 0}, nullptr, (hipStream_t)stream);
+    return launch_qdq(x, y, g, v, qp, codes, reinterpret_cast<unsigned long long*>(hist), (hipStream_t)stream);
 }
 
 int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream) {
@@ -1667,44 +1656,30 @@ int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm,
 
 int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* stream) {
     if (!pmm || !out || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
-    hipLaunchKernelGGL(k_minmax_reduce, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, pmm,
-                       G, (int)C, out);
+    hipLaunchKernelGGL(k_minmax_reduce, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0,
+                       (hipStream_t)stream, pmm, G, (int)C, out);
     return launch_status();
 }
 
-int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                       const float* pmm, int G, float* qp_out, uint8_t* codes, uint64_t* hist, int reverse,
-                       void* stream) {
-    if (!x || !y || !pmm || G <= 0 || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
-    Variant v;
-    Geo g;
-    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), reverse ? 1 : 0,
-                        &v, &g);
-    if (rc) return rc;
-    return launch_qdq<true>(x, y, g, v, nullptr, codes, reinterpret_cast<unsigned long long*>(hist), pmm,
-                            FusedCfg{num_bits, positive ? 1 : 0, G}, qp_out, (hipStream_t)stream);
+int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int positive, float* qp, void* stream) {
+    if (!pmm || !qp || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || num_bits < 1 || num_bits > 8)
+        return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_minmax_params, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0,
+                       (hipStream_t)stream, pmm, G, (int)C, num_bits, positive ? 1 : 0, qp);
+    return launch_status();
 }
 
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                       float* pmm, float* qp_out, uint8_t* codes, uint64_t* hist, void* stream) {
-    if (!x || !y || !pmm || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
-    // both passes must see the same load shape: decide it once from all pointers involved
-    const bool al = al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0);
-    Variant v;
-    Geo g;
-    int rc = plan(N, C, HW, al, 0, &v, &g);
+                       float* pmm, float* qp, uint8_t* codes, uint64_t* hist, void* stream) {
+    if (!x || !y || !pmm || !qp || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    int rc = cnnq_pc_minmax(x, N, C, HW, pmm, stream);
     if (rc) return rc;
-    const int G = g.S * g.nb;
-    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
-    hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_MM(VEC, A, J) hipLaunchKernelGGL((k_minmax<VEC, A, J>), grid, block, 0, st, x, g, pmm)
-    CNNQ_DISPATCH(v, LAUNCH_MM);
-#undef LAUNCH_MM
-    rc = launch_status();
+    rc = cnnq_pc_minmax_params(pmm, G, C, num_bits, positive, qp, stream);
     if (rc) return rc;
-    g.rev = 1;  // re-read what the statistics pass touched last first
-    return launch_qdq<true>(x, y, g, v, nullptr, codes, reinterpret_cast<unsigned long long*>(hist), pmm,
-                            FusedCfg{num_bits, positive ? 1 : 0, G}, qp_out, st);
+    // descending address order: what the statistics pass read last is re-read first
+    return cnnq_pc_qdq(x, y, N, C, HW, qp, codes, hist, /*reverse=*/1, stream);
 }
 
 int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_w, const float* stats_q, int vcorr,
@@ -1745,7 +1720,7 @@ int cnnq_pc_bcorr_apply(float* y, int64_t N, int64_t C, int64_t HW, const float*
     if (!y || !bias) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    const int rc = plan(N, C, HW, al16(y), 0, &v, &g);
+    const int rc = plan(N, C, HW, al16(y), 0, &v, &g, /*fine=*/1);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
@@ -1768,7 +1743,7 @@ int cnnq_pc_midtread_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t
     if (!x || !y || !mt) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || al16(codes)), 0, &v, &g);
+    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || al16(codes)), 0, &v, &g, /*fine=*/hist ? 0 : 1);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;

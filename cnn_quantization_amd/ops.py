@@ -133,26 +133,26 @@ def pc_params(stats, num_bits, positive=False, clip='no', bit_alloc=False, prior
 
 
 # ------------------------------------------------------------------------------------- Q/DQ
-def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None):
+def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None, reverse=False):
     """y = dequant(quant(x)) with per-channel parameters; optionally the uint8 codes; `hist`
-    (optional zeroed int64[256] tensor) receives the code histogram."""
+    (optional zeroed int64[256] tensor) receives the code histogram; reverse: descending addresses."""
     lib = L.load()
     x = _dev_f32(x, 'x')
     y = torch.empty_like(x) if out is None else out
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
-    L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)),
-            'cnnq_pc_qdq')
+    L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), int(bool(reverse)),
+                            _stream(x)), 'cnnq_pc_qdq')
     return (y, codes) if want_codes else y
 
 
 def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
                      want_parts=False, group=None):
-    """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials, then the fused Q/DQ whose
-    prologue reduces them and derives scale / zero point - two launches, no host sync.
+    """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials -> parameter table (one tiny
+    launch) -> fused Q/DQ in descending address order; no host sync.
 
     World size > 1 (x is this rank's batch shard): the local extrema [2, C] are all-gathered and the
-    Q/DQ prologue reduces the W gathered pairs instead - exact, so the result is bit-identical to a
-    single GPU holding the whole batch."""
+    parameter kernel reduces the W gathered pairs instead - exact, so the result is bit-identical to
+    a single GPU holding the whole batch."""
     lib = L.load()
     x = _dev_f32(x, 'x')
     y = torch.empty_like(x) if out is None else out
@@ -160,7 +160,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     if G <= 0:
         L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
     pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
-    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device) if want_parts else None
+    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device)
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
     hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
     world = D.world_size(group)
@@ -173,9 +173,10 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         local = torch.empty((2, C), dtype=torch.float32, device=x.device)
         L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), g_used, C, _ptr(local), _stream(x)), 'cnnq_pc_minmax_reduce')
         pmm = D.all_gather_records(local, group)                     # [W, 2, C]
-        L.check(lib.cnnq_pc_qdq_minmax(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
-                                       world, _ptr(qp), _ptr(codes), _ptr(hist), 1, _stream(x)),
-                'cnnq_pc_qdq_minmax')
+        L.check(lib.cnnq_pc_minmax_params(_ptr(pmm), world, C, int(num_bits), int(bool(positive)), _ptr(qp),
+                                          _stream(x)), 'cnnq_pc_minmax_params')
+        L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), 1, _stream(x)),
+                'cnnq_pc_qdq')
         if want_entropy:
             D.all_reduce_sum_(hist, group)
     res = [y]
@@ -185,7 +186,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         res.append(entropy_from_hist(hist))
     if want_parts:
         al = x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and (codes is None or codes.data_ptr() % 4 == 0)
-        g_used = world if world > 1 else lib.cnnq_pc_groups(N, C, HW, int(al))
+        g_used = world if world > 1 else lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
         stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
         stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
         stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]

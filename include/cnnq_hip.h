@@ -143,37 +143,34 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg /* 
  * (iq.py:573-592 - div, add, clamp, round, sub, mul as ONE pass; the four transpose copies of
  * iq.py:427,450,534 disappear).  IEEE division, separate roundings (no FMA), clamp before
  * round, round half to even: integer codes are bit-exact with the reference's.
+ * Non-temporal loads and stores (x is read for the last time, y is never re-read by this path);
+ * launched as many short workgroups in address order, which is what read+write streaming on
+ * MI355X wants; reverse != 0 walks the tensor in descending address order (use it when the
+ * previous pass over x went ascending: its tail is still in the 256 MB Infinity Cache).
  * `codes` (optional, may be NULL): the integer codes as one byte per element.
  * `hist` (optional, may be NULL): 256 uint64 bins, ZEROED BY THE CALLER, to which the code
  * histogram of the whole tensor is added (integer atomics -> deterministic); with cnnq_entropy
  * this replaces the full sort of torch.unique in utils/entropy.py:6-17 (iq.py:586-587). */
 int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
-                uint8_t* codes, uint64_t* hist, void* stream);
+                uint8_t* codes, uint64_t* hist, int reverse, void* stream);
 
 /* Config 2 (dynamic per-channel min/max, no clipping, uniform bit width: iq.py:409-451 with
- * bit allocation off) as TWO launches with no parameter kernel in between:
- *   cnnq_pc_minmax      exact per-channel {min, max} partials pmm[G][2][C] (G = cnnq_pc_groups;
- *                       every entry written exactly once: no atomics, no initialisation);
- *   cnnq_pc_qdq_minmax  the fused Q/DQ; its prologue reduces the G pairs of the workgroup's
- *                       channels (LDS integer atomics on order-preserving keys) and derives scale /
- *                       zero point (iq.py:559-572).  Non-temporal loads and stores (x is read for
- *                       the last time, y is never re-read: neither should displace useful lines of
- *                       the 256 MB Infinity Cache); reverse != 0 walks the tensor in descending
- *                       address order, so what the statistics pass read last is re-read first.
- *                       qp_out (optional [CNNQ_NQP][C]) receives the parameters used.
- *   cnnq_pc_minmax_qdq  both, in one call (reverse order for the second pass).
+ * bit allocation off) as three launches, two of them streaming:
+ *   cnnq_pc_minmax         exact per-channel {min, max} partials pmm[G][2][C] (G = cnnq_pc_groups;
+ *                          every entry written exactly once: no atomics, no initialisation);
+ *   cnnq_pc_minmax_params  reduces the G pairs and derives qp[CNNQ_NQP][C] (iq.py:559-572);
+ *   cnnq_pc_qdq            the fused Q/DQ (reverse = 1: descending addresses).
+ *   cnnq_pc_minmax_qdq     all three in one call; pmm and qp are caller workspaces (qp is also the
+ *                          parameter table used, for inspection).
  *   cnnq_pc_minmax_reduce  pmm[G][2][C] -> out[2][C]: a rank's local extrema.  Multi-GPU config 2:
- *                       minmax -> reduce -> all_gather of out over the ranks -> qdq_minmax with the
- *                       gathered [W][2][C] as pmm and G = W (exact, so any world size gives the
- *                       bit-identical result of one GPU holding the whole batch).
- * codes / hist as in cnnq_pc_qdq. */
+ *                          minmax -> reduce -> all_gather of out over the ranks -> minmax_params with
+ *                          the gathered [W][2][C] as pmm and G = W -> qdq (exact, so any world size
+ *                          gives the bit-identical result of one GPU holding the whole batch). */
 int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream);
 int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* stream);
-int cnnq_pc_qdq_minmax(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                       const float* pmm, int G, float* qp_out, uint8_t* codes, uint64_t* hist, int reverse,
-                       void* stream);
+int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int positive, float* qp, void* stream);
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                       float* pmm, float* qp_out, uint8_t* codes, uint64_t* hist, void* stream);
+                       float* pmm, float* qp, uint8_t* codes, uint64_t* hist, void* stream);
 
 /* Weight bias / variance correction after quantization (iqm.py:374-391), in place on
  * wq[C][HW]: vcorr: wq = (wq - mean_q) * std_w/(std_q + 1e-8) + mean_q; bcorr: wq = wq - mean_q + mean_w

@@ -47,7 +47,7 @@ def test_argument_validation_needs_no_device():
     assert lib.cnnq_pc_groups(4, 1 << 20, 1 << 12, 1) == -2          # CNNQ_ERANGE: plane >= 2^31
     assert lib.cnnq_pc_groups(512, 64, 112 * 112, 1) > 0
     assert lib.cnnq_pc_moments(None, 1, 1, 1, 0, None, None) == -1
-    assert lib.cnnq_pc_qdq(None, None, 1, 1, 1, None, None, None, None) == -1
+    assert lib.cnnq_pc_qdq(None, None, 1, 1, 1, None, None, None, 0, None) == -1
     assert lib.cnnq_pt_qdq(None, None, 0, None, None, None) == -1
     with pytest.raises(L.CnnqError):
         L.check(-2, 'x')
