@@ -103,6 +103,39 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&v)[VEC]
     }
 }
 
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// streaming (non-temporal) forms.  Read-only streaming with `nt` loads runs at 7.1 TB/s on MI355X
+// against 6.3 TB/s with plain loads (tools/ubench_read.py); they do not allocate in the Infinity
+// Cache, so the statistics passes use them only for tensors too large for the next pass to find
+// anything still cached (NT_BYTES).  The Q/DQ pass always uses them: x is read for the last time and
+// y is never re-read by this path.
+constexpr int64_t NT_BYTES = (int64_t)384 << 20;   // swept 0..1000 MB on the ResNet-50 set: flat optimum 250-400
+
+template <int VEC>
+__device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = __builtin_nontemporal_load(p);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        f4_t t;
+        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<f4_t*>(p));
+    } else {
+        __builtin_nontemporal_store(v[0], p);
+    }
+}
+template <int VEC, bool NTL>
+__device__ __forceinline__ void ldv_sel(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (NTL) ldv_nt<VEC>(p, v); else ldv<VEC>(p, v);
+}
+
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
@@ -179,7 +212,7 @@ __device__ __forceinline__ void write_mom(double* __restrict__ part, int grp, in
     p[(size_t)CNNQ_MOM_SUMSQ_RELU * C] = RELU ? m.rss : 0.;
 }
 
-template <int VEC, int A, int J, bool RELU>
+template <int VEC, int A, int J, bool RELU, bool NTL>
 __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, const Geo g,
                                                  double* __restrict__ part) {
     constexpr int NE = TPB * J * A;  // LDS entries (one per column, or per element when straddling)
@@ -208,7 +241,7 @@ __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, co
     for (int n = b.n0; n < b.n1; ++n, row += g.P) {
         float v[J][VEC];
 #pragma unroll
-        for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
+        for (int j = 0; j < J; ++j) ldv_sel<VEC, NTL>(row + (size_t)col[j] * VEC, v[j]);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             if constexpr (VEC == 4 && A == 1) {
@@ -353,7 +386,7 @@ __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part
 // ------------------------------------------------------------------------------------------
 // Pass B: sum |x - mean| and sum ((x - mean)/std)^4 per channel
 // ------------------------------------------------------------------------------------------
-template <int VEC, int A, int J, bool KURT>
+template <int VEC, int A, int J, bool KURT, bool NTL>
 __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, const Geo g,
                                                 const float* __restrict__ stats, double* __restrict__ part2) {
     constexpr int NE = TPB * J * A;
@@ -395,7 +428,7 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
         const float* row = x + (size_t)(g.rev ? b.n1 - 1 - r : b.n0 + r) * (size_t)g.P;
         float v[J][VEC];
 #pragma unroll
-        for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
+        for (int j = 0; j < J; ++j) ldv_sel<VEC, NTL>(row + (size_t)col[j] * VEC, v[j]);
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -627,7 +660,7 @@ __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-template <int VEC, int A, int J>
+template <int VEC, int A, int J, bool NTL>
 __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, const Geo g,
                                                 float* __restrict__ pmm) {
     constexpr int NE = TPB * J * A;
@@ -653,7 +686,7 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
     for (int n = b.n0; n < b.n1; ++n, row += g.P) {
         float v[J][VEC];
 #pragma unroll
-        for (int j = 0; j < J; ++j) ldv<VEC>(row + (size_t)col[j] * VEC, v[j]);
+        for (int j = 0; j < J; ++j) ldv_sel<VEC, NTL>(row + (size_t)col[j] * VEC, v[j]);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             if constexpr (A == 1 && VEC == 4) {
@@ -752,31 +785,6 @@ constexpr int HREP = 32;
 #ifndef QDQ_NT
 #define QDQ_NT 3  // bit 0: non-temporal loads of x, bit 1: non-temporal stores of y
 #endif
-
-typedef float f4_t __attribute__((ext_vector_type(4)));
-
-// streaming (non-temporal) forms for the Q/DQ pass: x is read for the last time and y is never
-// re-read by this path, so neither should displace the lines the NEXT kernel wants in the
-// 256 MB Infinity Cache (measured: +15 % on stats->Q/DQ sequences, tools/useq.py)
-template <int VEC>
-__device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
-        const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-        v[0] = __builtin_nontemporal_load(p);
-    }
-}
-template <int VEC>
-__device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[VEC]) {
-    if constexpr (VEC == 4) {
-        f4_t t;
-        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-        __builtin_nontemporal_store(t, reinterpret_cast<f4_t*>(p));
-    } else {
-        __builtin_nontemporal_store(v[0], p);
-    }
-}
 
 // pmm[G][2][C] -> qp[3][C] for config 2 (iq.py:409-424,559-572): delta = max - min (or max with a
 // zero minimum), scale = max(delta / qmax, 1e-8), zero_point = round(0 - offset/scale).  One
@@ -1571,10 +1579,13 @@ int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_r
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_MOM(VEC, A, J)                                                                          \
-    do {                                                                                               \
-        if (want_relu) hipLaunchKernelGGL((k_moments<VEC, A, J, true>), grid, block, 0, st, x, g, part); \
-        else hipLaunchKernelGGL((k_moments<VEC, A, J, false>), grid, block, 0, st, x, g, part);          \
+    const bool ntl = N * C * HW * 4 > NT_BYTES;
+#define LAUNCH_MOM(VEC, A, J)                                                                                        \
+    do {                                                                                                             \
+        if (want_relu && ntl) hipLaunchKernelGGL((k_moments<VEC, A, J, true, true>), grid, block, 0, st, x, g, part);   \
+        else if (want_relu) hipLaunchKernelGGL((k_moments<VEC, A, J, true, false>), grid, block, 0, st, x, g, part);    \
+        else if (ntl) hipLaunchKernelGGL((k_moments<VEC, A, J, false, true>), grid, block, 0, st, x, g, part);          \
+        else hipLaunchKernelGGL((k_moments<VEC, A, J, false, false>), grid, block, 0, st, x, g, part);                  \
     } while (0)
     CNNQ_DISPATCH(v, LAUNCH_MOM);
 #undef LAUNCH_MOM
@@ -1597,10 +1608,13 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_DEV(VEC, A, J)                                                                                  \
-    do {                                                                                                       \
-        if (want_kurt) hipLaunchKernelGGL((k_absdev<VEC, A, J, true>), grid, block, 0, st, x, g, stats, part2);  \
-        else hipLaunchKernelGGL((k_absdev<VEC, A, J, false>), grid, block, 0, st, x, g, stats, part2);           \
+    const bool ntl = N * C * HW * 4 > NT_BYTES;
+#define LAUNCH_DEV(VEC, A, J)                                                                                             \
+    do {                                                                                                                  \
+        if (want_kurt && ntl) hipLaunchKernelGGL((k_absdev<VEC, A, J, true, true>), grid, block, 0, st, x, g, stats, part2);  \
+        else if (want_kurt) hipLaunchKernelGGL((k_absdev<VEC, A, J, true, false>), grid, block, 0, st, x, g, stats, part2);   \
+        else if (ntl) hipLaunchKernelGGL((k_absdev<VEC, A, J, false, true>), grid, block, 0, st, x, g, stats, part2);         \
+        else hipLaunchKernelGGL((k_absdev<VEC, A, J, false, false>), grid, block, 0, st, x, g, stats, part2);                 \
     } while (0)
     CNNQ_DISPATCH(v, LAUNCH_DEV);
 #undef LAUNCH_DEV
@@ -1648,7 +1662,12 @@ int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm,
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_MM(VEC, A, J) hipLaunchKernelGGL((k_minmax<VEC, A, J>), grid, block, 0, st, x, g, pmm)
+    const bool ntl = N * C * HW * 4 > NT_BYTES;
+#define LAUNCH_MM(VEC, A, J)                                                                         \
+    do {                                                                                             \
+        if (ntl) hipLaunchKernelGGL((k_minmax<VEC, A, J, true>), grid, block, 0, st, x, g, pmm);       \
+        else hipLaunchKernelGGL((k_minmax<VEC, A, J, false>), grid, block, 0, st, x, g, pmm);          \
+    } while (0)
     CNNQ_DISPATCH(v, LAUNCH_MM);
 #undef LAUNCH_MM
     return launch_status();

@@ -71,3 +71,37 @@ extern "C" float umemcpy(const float* x, float* y, size_t bytes, int reps) {
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); return ms / reps;
 }
+
+// read-only streaming: one-shot (each thread B float4) vs grid-stride; result folded to defeat DCE
+template <int TPB, int B, int NT>
+__global__ void __launch_bounds__(TPB) k_read(const f4* __restrict__ x, float* __restrict__ out, size_t n4) {
+    const size_t nthreads = (size_t)gridDim.x * TPB;
+    float m = -1e30f;
+    for (size_t i0 = (size_t)blockIdx.x * TPB * B + threadIdx.x; i0 < n4; i0 += nthreads * B) {
+        f4 v[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const size_t i = i0 + (size_t)b * TPB;
+            v[b] = (i < n4) ? ((NT & 1) ? __builtin_nontemporal_load(x + i) : x[i]) : f4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) m = fmaxf(m, fmaxf(fmaxf(v[b].x, v[b].y), fmaxf(v[b].z, v[b].w)));
+    }
+    if (m == 12345.678f) out[blockIdx.x] = m;
+}
+extern "C" float uread(int B, int nt, const float* x, float* out, size_t n4, int grid, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto go = [&]() {
+        if (B == 1 && nt == 0) hipLaunchKernelGGL((k_read<256, 1, 0>), dim3(grid), dim3(256), 0, 0, (const f4*)x, out, n4);
+        if (B == 4 && nt == 0) hipLaunchKernelGGL((k_read<256, 4, 0>), dim3(grid), dim3(256), 0, 0, (const f4*)x, out, n4);
+        if (B == 8 && nt == 0) hipLaunchKernelGGL((k_read<256, 8, 0>), dim3(grid), dim3(256), 0, 0, (const f4*)x, out, n4);
+        if (B == 1 && nt == 1) hipLaunchKernelGGL((k_read<256, 1, 1>), dim3(grid), dim3(256), 0, 0, (const f4*)x, out, n4);
+        if (B == 4 && nt == 1) hipLaunchKernelGGL((k_read<256, 4, 1>), dim3(grid), dim3(256), 0, 0, (const f4*)x, out, n4);
+        if (B == 8 && nt == 1) hipLaunchKernelGGL((k_read<256, 8, 1>), dim3(grid), dim3(256), 0, 0, (const f4*)x, out, n4);
+    };
+    go(); hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) go();
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); return ms / reps;
+}
