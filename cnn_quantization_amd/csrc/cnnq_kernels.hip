@@ -820,13 +820,21 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
     if constexpr (HIST) {
         for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
     }
-    // stage this workgroup's channels once (coalesced), then every lane keeps its own in registers
-    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
-        sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
-        sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
-        sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+    // stage this workgroup's channels once (coalesced), then every lane keeps its own in registers;
+    // a workgroup that owns a slice of ONE channel reads its three parameters directly (uniform
+    // address -> scalar loads) and needs neither LDS nor a barrier before it starts streaming
+    const bool single = (g.mode == 1) && !HIST;
+    if (!single) {
+        for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+            sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+            sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+            sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const float u_sc = single ? qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0] : 0.f;
+    const float u_zp = single ? qp[(size_t)CNNQ_QP_ZP * g.C + b.c0] : 0.f;
+    const float u_qm = single ? qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0] : 0.f;
     int col[J];
     bool ok[J];
     float sc[J][A], zp[J][A], qm[J][A];
@@ -841,11 +849,15 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
         col[j] = ok[j] ? c : b.col0;
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
-            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
-            sc[j][a] = sh_sc[ch];
-            zp[j][a] = sh_zp[ch];
-            qm[j][a] = sh_qm[ch];
+            if (single) {
+                sc[j][a] = u_sc; zp[j][a] = u_zp; qm[j][a] = u_qm;
+            } else {
+                const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+                const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+                sc[j][a] = sh_sc[ch];
+                zp[j][a] = sh_zp[ch];
+                qm[j][a] = sh_qm[ch];
+            }
             if constexpr (HIST) nzp[j][a] = 0u;
         }
     }
@@ -1407,24 +1419,26 @@ __device__ __forceinline__ float ptq1(float v, float scale, float shift, float q
     return etz ? (t - shift) * scale : t * scale - shift;
 }
 
+// one-shot grid in address order, non-temporal streaming (the structure that reaches the copy
+// ceiling on MI355X, tools/ubench_copy.py): every lane handles exactly one VEC-wide item
 template <int VEC, bool NOISE>
 __global__ void __launch_bounds__(TPB) k_pt_qdq(const float* __restrict__ x, float* __restrict__ y, int64_t n,
                                                 const float* __restrict__ ptp, const float* __restrict__ noise) {
     const float scale = ptp[0], shift = ptp[1], qmax = ptp[2];
     const bool etz = ptp[3] != 0.f, pass = ptp[4] != 0.f;
     const int64_t nv = n / VEC;
-    const int64_t stride = (int64_t)gridDim.x * TPB;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += stride) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < nv) {
         float v[VEC], z[VEC], o[VEC];
-        ldv<VEC>(x + i * VEC, v);
-        if constexpr (NOISE) ldv<VEC>(noise + i * VEC, z);
+        ldv_nt<VEC>(x + i * VEC, v);
+        if constexpr (NOISE) ldv_nt<VEC>(noise + i * VEC, z);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = pass ? v[e] : ptq1(v[e], scale, shift, qmax, etz, NOISE ? z[e] : 0.f);
-        stv<VEC>(y + i * VEC, o);
+        stv_nt<VEC>(y + i * VEC, o);
     }
-    if constexpr (VEC > 1) {  // tail
-        const int64_t i = nv * VEC + (int64_t)blockIdx.x * TPB + threadIdx.x;
-        if (i < n) y[i] = pass ? x[i] : ptq1(x[i], scale, shift, qmax, etz, NOISE ? noise[i] : 0.f);
+    if constexpr (VEC > 1) {  // tail (n % VEC elements), handled by the first lanes of the grid
+        const int64_t t = nv * VEC + i;
+        if (i < VEC && t < n) y[t] = pass ? x[t] : ptq1(x[t], scale, shift, qmax, etz, NOISE ? noise[t] : 0.f);
     }
 }
 
@@ -1512,7 +1526,7 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, i
         // markedly faster than long-lived ones (6.1-6.7 vs 5.4 TB/s measured)
         const int64_t cols = (g->mode == 1) ? g->w : (int64_t)g->k * HW * v.A / v.vec / v.A;
         const int64_t row_bytes = cols * v.vec * 4;
-        int64_t rows = (14336 + row_bytes / 2) / (row_bytes > 0 ? row_bytes : 1);
+        int64_t rows = (14336 + row_bytes / 2) / (row_bytes > 0 ? row_bytes : 1);   // swept 8-32 KB
         if (rows < 1) rows = 1;
         S = (N + rows - 1) / rows;
     }
@@ -1814,8 +1828,8 @@ int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const flo
     if (!x || !y || !ptp || n <= 0) return CNNQ_EINVAL;
     const bool vec = al16(x) && al16(y) && (!noise || al16(noise));
     const int64_t work = vec ? (n + 3) / 4 : n;
-    int64_t blocks = (work + TPB - 1) / TPB;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int64_t blocks = (work + TPB - 1) / TPB;
+    if (blocks >= ((int64_t)1 << 31)) return CNNQ_ERANGE;
     const dim3 grid((unsigned)blocks), block(TPB);
     hipStream_t st = (hipStream_t)stream;
     if (vec) {

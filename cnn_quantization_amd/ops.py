@@ -356,9 +356,18 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
 def tensor_row_stats(x, rows):
     """Per-row MIN/MAX (and friends) of x viewed as [rows, numel/rows]: the per-sample statistics
     of iq.py:510-517 (rows = batch) - the per-channel kernels with N = 1, C = rows."""
+    lib = L.load()
     x = _dev_f32(x, 'x')
-    stats, _ = pc_stats(x, 1, rows, x.numel() // rows)
-    return stats
+    hw = x.numel() // rows
+    G = lib.cnnq_pc_groups(1, rows, hw, int(x.data_ptr() % 16 == 0))
+    if G <= 0:
+        L.check(G, 'cnnq_pc_groups(1,%d,%d)' % (rows, hw))
+    pmm = torch.empty((G, 2, rows), dtype=torch.float32, device=x.device)
+    L.check(lib.cnnq_pc_minmax(_ptr(x), 1, rows, hw, _ptr(pmm), _stream(x)), 'cnnq_pc_minmax')
+    # rows MIN (0) and MAX (1) of a stats table with stride `rows`: what cnnq_pt_setup reads
+    table = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+    L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), G, rows, _ptr(table), _stream(x)), 'cnnq_pc_minmax_reduce')
+    return table
 
 
 def minmax_qdq_per_tensor(x, num_bits, avg_over_batch, zero_min=False, int_exp=False, enforce_true_zero=True,
