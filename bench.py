@@ -200,7 +200,7 @@ def main():
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
         'roofline': {'bound': 'hbm', 'kernel': 'k_qdq (fused per-channel Q/DQ, 8 algorithmic B/elem)',
                      'achieved': qdq_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': qdq_gbs / HBM_PEAK_GBS,
-                     'traffic': 872.6e6, 'traffic_unit': 'bytes per launch',
+                     'traffic': 864.3e6, 'traffic_unit': 'bytes per launch',
                      'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same '
                                        'command; committed in profiles/r01_pmc_summary.md (not re-measured live)',
                      'launches_per_step': n_launch, 'avg_launch_ms': t_qdq * 1e3 / n_launch,
