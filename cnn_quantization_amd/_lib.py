@@ -30,6 +30,7 @@ class ParamsCfg(ctypes.Structure):
 SIGNATURES = {
     'cnnq_version': (ctypes.c_char_p, []),
     'cnnq_pc_groups': (_I, [_L, _L, _L, _I]),
+    'cnnq_plan_describe': (_I, [_L, _L, _L, _I, _I, ctypes.POINTER(ctypes.c_int32)]),
     'cnnq_pc_moments': (_I, [_P, _L, _L, _L, _I, _P, _P]),
     'cnnq_pc_combine': (_I, [_P, _I, _L, _I, _P, _P, _P]),
     'cnnq_pc_absdev': (_I, [_P, _L, _L, _L, _P, _I, _P, _P]),

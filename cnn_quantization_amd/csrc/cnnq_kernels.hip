@@ -1585,6 +1585,17 @@ int cnnq_pc_groups(int64_t N, int64_t C, int64_t HW, int aligned16) {
     return g.S * g.nb;
 }
 
+int cnnq_plan_describe(int64_t N, int64_t C, int64_t HW, int aligned16, int fine, int32_t out[12]) {
+    if (!out) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, aligned16 != 0, 0, &v, &g, fine);
+    if (rc) return rc;
+    const int32_t vals[12] = {v.vec, v.A, v.J, g.mode, g.nb, g.w, g.k, g.ncb, g.S, TPB, g.S * g.nb, 0};
+    for (int i = 0; i < 12; ++i) out[i] = vals[i];
+    return 0;
+}
+
 int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_relu, double* part, void* stream) {
     if (!x || !part) return CNNQ_EINVAL;
     Variant v;

@@ -83,6 +83,15 @@ const char* cnnq_version(void);
  * a negative CNNQ_E*. */
 int cnnq_pc_groups(int64_t N, int64_t C, int64_t HW, int aligned16);
 
+/* Diagnostics (host only, nothing is enqueued): the launch plan the streaming kernels use for a
+ * tensor - out = {vec, A, J, mode, nb, w, k, ncb, S, threads per workgroup, G, 0}: loads of `vec`
+ * floats, A parameter sets per load (4 = a float4 may straddle two channels), J loads per lane per
+ * sample; mode 1: a workgroup owns `w` loads of ONE channel (`nb` workgroups per channel), mode 2: `k`
+ * whole channels; ncb column blocks x S batch splits workgroups; fine != 0: the short-workgroup
+ * geometry of the table-driven elementwise passes.  tests/test_plan_cpu.py checks on the CPU that
+ * these plans cover every element exactly once. */
+int cnnq_plan_describe(int64_t N, int64_t C, int64_t HW, int aligned16, int fine, int32_t out[12]);
+
 /* Pass A over x[N][C][HW]: per channel min, max, sum, sum of squares, count (and, when
  * want_relu, sum and sum of squares of relu(x)) -> part[G][CNNQ_NMOM][C].  One coalesced
  * read of x, no transposed copy.  Fuses the reductions of iq.py:534-550 (max/min/mean/std),

@@ -410,3 +410,37 @@ def test_act_bias_correction_vs_oracle(ops, shape, relu_first):
     out = ops.act_bias_correction_(dev(x), dev(xq).clone(), relu_first).cpu()
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
     assert torch.equal(out == 0, ref == 0)
+
+
+# --------------------------------------------------------------------------- edge cases, config 2 end to end
+@pytest.mark.parametrize('shape', [(1, 3, 5, 5), (7, 1, 9, 9), (2, 4097, 1, 5), (3, 5, 1, 1), (1, 1, 1, 2), (2, 300, 7, 7),
+                                   (9, 17, 13, 11), (1, 64, 112, 112)])
+@pytest.mark.parametrize('half', [False, True])
+def test_cfg2_edge_shapes_bit_exact(ops, shape, half):
+    """Single sample, single channel, 1x1 / 1xW planes, more channels than a workgroup can own,
+    odd everything: the dynamic min/max path stays bit-exact; degenerate channels (constant, all zero,
+    all negative with half range) hit the scale floor exactly like the reference."""
+    gen = torch.Generator().manual_seed(sum(shape) + half)
+    x = torch.randn(shape, generator=gen) * 2.5 + 0.3
+    C = shape[1]
+    if C >= 3:
+        x[:, 0] = 0.75            # constant channel: delta = 0 -> scale 1e-8
+        x[:, 1] = 0.              # all zeros
+        x[:, 2] = -x[:, 2].abs() - 0.1   # all negative (half range: max < 0)
+    ref, parts = O.act_per_channel_qdq(x, 4, half_range=half, return_parts=True)
+    y, codes = ops.act_qdq_per_channel(dev(x), 4, positive=half, want_codes=True)
+    assert torch.equal(codes.cpu().float(), parts['codes'])
+    assert bits_equal(y.cpu(), ref)
+
+
+def test_noncontiguous_and_offset_inputs(ops):
+    """Views with a storage offset (base pointer not 16-byte aligned) and non-contiguous inputs."""
+    gen = torch.Generator().manual_seed(77)
+    big = torch.randn(3, 10, 12, 13, generator=gen)
+    for x in (big[:, 1:9], big.transpose(2, 3), big[1:]):
+        ref = O.act_per_channel_qdq(x.contiguous(), 4)
+        y = ops.act_qdq_per_channel(dev(big)[:, 1:9] if x.shape[1] == 8 else (dev(big).transpose(2, 3) if x.shape[2] == 13 else dev(big)[1:]), 4)
+        assert bits_equal(y.cpu(), ref)
+    flat = torch.randn(1 + 4 * 6 * 49, generator=gen)
+    xo = flat[1:].view(4, 6, 7, 7)
+    assert bits_equal(ops.act_qdq_per_channel(dev(flat)[1:].view(4, 6, 7, 7), 4).cpu(), O.act_per_channel_qdq(xo.contiguous(), 4))
