@@ -145,12 +145,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one rank per GPU; CNNQ_BENCH_BACKEND=gloo (test rigs with fewer GPUs than ranks) lets several
+    # ranks share a device so the multi-rank code path can be exercised on a 1-GPU box
+    backend = os.environ.get('CNNQ_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     group = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from cnn_quantization_amd import ops, _lib
@@ -173,7 +180,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
@@ -192,15 +199,15 @@ def main():
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'ResNet-50 b512 conv activations (53 tensors, %.2f G elements per GPU), per-channel '
-                               'int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (elems / 1e9),
+        'config': {'workload': 'ResNet-50 b%d conv activations (53 tensors, %.2f G elements per GPU), per-channel '
+                               'int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (args.batch, elems / 1e9),
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                    'parallelism': 'batch-sharded dp%d, per-channel stats all_gather' % world},
         'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
         'roofline': {'bound': 'hbm', 'kernel': 'k_qdq (fused per-channel Q/DQ, 8 algorithmic B/elem)',
                      'achieved': qdq_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': qdq_gbs / HBM_PEAK_GBS,
-                     'traffic': 864.3e6, 'traffic_unit': 'bytes per launch',
+                     'traffic': 864.3e6 if args.batch == 512 else None, 'traffic_unit': 'bytes per launch',
                      'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same '
                                        'command; committed in profiles/r01_pmc_summary.md (not re-measured live)',
                      'launches_per_step': n_launch, 'avg_launch_ms': t_qdq * 1e3 / n_launch,
