@@ -15,7 +15,13 @@
 //     exactly one workgroup - no atomics, deterministic results;
 //   * three load shapes: VEC4 (H*W % 4 == 0), VEC4-straddle (H*W % 4 != 0 but C*H*W % 4 == 0,
 //     e.g. 7x7: a float4 may span two channels, per-element bookkeeping) and VEC1 (anything,
-//     incl. unaligned base pointers).
+//     incl. unaligned base pointers);
+//   * two launch geometries over that decomposition (make_geo): the REDUCTION passes (statistics)
+//     use <= 64 batch splits, i.e. ~4096 long-lived workgroups that amortise their in-workgroup
+//     reduction; the table-driven ELEMENTWISE passes (Q/DQ and friends) use ~14 KB of x per
+//     workgroup, dispatched in address order - on MI355X read+write streaming reaches 6.1-6.7 TB/s
+//     that way against 5.4 TB/s with long-lived workgroups; statistics passes over tensors too big
+//     for the Infinity Cache use non-temporal loads (read-only 7.1 vs 6.3 TB/s).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (division must stay an IEEE
 // divide followed by a separately rounded add: bit-exactness with the reference's aten ops).
@@ -645,21 +651,11 @@ __device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax
     return (q - zp) * scale;
 }
 
-// Exact per-channel min / max for config 2.  Each workgroup writes ONE {min, max} pair per
-// channel it owns into pmm[G][2][C] (plain stores, every (group, channel) entry written exactly
-// once: no atomics, no initialisation, deterministic).  The fused Q/DQ kernel reduces the G
-// pairs of its channels in its prologue.  (Device-scope atomics into a shared table were tried
-// first: ~160 K contended atomics per small layer cost ~50 us - see DESIGN.md.)
-// Floats are compared through order-preserving unsigned keys so that LDS integer atomics can do
-// the prologue reduction.
-__device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
+// Exact per-channel min / max for config 2 and the per-tensor paths.  Each workgroup writes ONE
+// {min, max} pair per channel it owns into pmm[G][2][C] (plain stores, every (group, channel) entry
+// written exactly once: no atomics, no initialisation, deterministic); k_minmax_params /
+// k_minmax_reduce merge the G pairs with one wave per channel.  (Device-scope atomics into a shared
+// table were tried first: ~160 K contended atomics per small layer cost ~50 us - see DESIGN.md.)
 template <int VEC, int A, int J, bool NTL>
 __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, const Geo g,
                                                 float* __restrict__ pmm) {
@@ -948,6 +944,88 @@ __global__ void __launch_bounds__(TPB) k_entropy(const unsigned long long* __res
     if (lane == 0) sh[wv] = e;
     __syncthreads();
     if (tid == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// packed int4 storage: the integer codes of a <= 4-bit quantization, two per
+// byte (even element in the low nibble), as the STORED activation format - 4 B read + 0.5 B written
+// per element instead of 4 + 4; k_unpack4_dq reproduces the dequantized floats of k_qdq bit for bit
+// ------------------------------------------------------------------------------------------
+template <int J>
+__global__ void __launch_bounds__(TPB) k_q_pack4(const float* __restrict__ x, uint8_t* __restrict__ packed,
+                                                 const Geo g, const float* __restrict__ qp) {
+    __shared__ float sh_sc[MAXCH], sh_zp[MAXCH], sh_qm[MAXCH];
+    const Blk b = blk_of<4>(g);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+        sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+        sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+        sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+    }
+    __syncthreads();
+    int col[J];
+    bool ok[J];
+    float sc[J], zp[J], qm[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+        const int ch = (int)(((unsigned)col[j] * 4u) / (unsigned)g.HW) - b.c0;
+        sc[j] = sh_sc[ch]; zp[j] = sh_zp[ch]; qm[j] = sh_qm[ch];
+    }
+    for (int n = b.n0; n < b.n1; ++n) {
+        const size_t off = (size_t)n * (size_t)g.P;
+        float v[J][4];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv_nt<4>(x + off + (size_t)col[j] * 4, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float cd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) (void)qdq1(v[j][e], sc[j], zp[j], qm[j], cd[e]);
+            if (ok[j]) {
+                const unsigned pk = ((unsigned)cd[0] & 15u) | (((unsigned)cd[1] & 15u) << 4) |
+                                    (((unsigned)cd[2] & 15u) << 8) | (((unsigned)cd[3] & 15u) << 12);
+                *reinterpret_cast<uint16_t*>(packed + (off + (size_t)col[j] * 4) / 2) = (uint16_t)pk;
+            }
+        }
+    }
+}
+
+template <int J>
+__global__ void __launch_bounds__(TPB) k_unpack4_dq(const uint8_t* __restrict__ packed, float* __restrict__ y,
+                                                    const Geo g, const float* __restrict__ qp) {
+    __shared__ float sh_sc[MAXCH], sh_zp[MAXCH];
+    const Blk b = blk_of<4>(g);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+        sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+        sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+    }
+    __syncthreads();
+    int col[J];
+    bool ok[J];
+    float sc[J], zp[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+        const int ch = (int)(((unsigned)col[j] * 4u) / (unsigned)g.HW) - b.c0;
+        sc[j] = sh_sc[ch]; zp[j] = sh_zp[ch];
+    }
+    for (int n = b.n0; n < b.n1; ++n) {
+        const size_t off = (size_t)n * (size_t)g.P;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const unsigned pk = *reinterpret_cast<const uint16_t*>(packed + (off + (size_t)col[j] * 4) / 2);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((float)((pk >> (4 * e)) & 15u) - zp[j]) * sc[j];   // iq.py:591-592
+            if (ok[j]) stv_nt<4>(y + off + (size_t)col[j] * 4, o);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1677,6 +1755,38 @@ int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, cons
                         &g, /*fine=*/hist ? 0 : 1);
     if (rc) return rc;
     return launch_qdq(x, y, g, v, qp, codes, reinterpret_cast<unsigned long long*>(hist), (hipStream_t)stream);
+}
+
+int cnnq_pc_quantize_pack4(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
+                           void* stream) {
+    if (!x || !packed || !qp) return CNNQ_EINVAL;
+    if (HW % 4 != 0 || !al16(x) || ((uintptr_t)packed & 1)) return CNNQ_EINVAL;   // whole float4s per channel row
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, true, 0, &v, &g, /*fine=*/1);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (v.J == 4) hipLaunchKernelGGL((k_q_pack4<4>), grid, block, 0, st, x, packed, g, qp);
+    else if (v.J == 2) hipLaunchKernelGGL((k_q_pack4<2>), grid, block, 0, st, x, packed, g, qp);
+    else hipLaunchKernelGGL((k_q_pack4<1>), grid, block, 0, st, x, packed, g, qp);
+    return launch_status();
+}
+
+int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                             void* stream) {
+    if (!packed || !y || !qp) return CNNQ_EINVAL;
+    if (HW % 4 != 0 || !al16(y) || ((uintptr_t)packed & 1)) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, true, 0, &v, &g, /*fine=*/1);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (v.J == 4) hipLaunchKernelGGL((k_unpack4_dq<4>), grid, block, 0, st, packed, y, g, qp);
+    else if (v.J == 2) hipLaunchKernelGGL((k_unpack4_dq<2>), grid, block, 0, st, packed, y, g, qp);
+    else hipLaunchKernelGGL((k_unpack4_dq<1>), grid, block, 0, st, packed, y, g, qp);
+    return launch_status();
 }
 
 int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream) {

@@ -194,6 +194,26 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def quantize_pack4(x, qp):
+    """x [N, C, H, W] + parameter table -> packed int4 codes (uint8, numel/2 bytes, two codes per byte)."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    N, C, HW = geometry(x)
+    packed = torch.empty(x.numel() // 2, dtype=torch.uint8, device=x.device)
+    L.check(lib.cnnq_pc_quantize_pack4(_ptr(x), _ptr(packed), N, C, HW, _ptr(qp), _stream(x)), 'cnnq_pc_quantize_pack4')
+    return packed
+
+
+def dequantize_pack4(packed, shape, qp):
+    """Inverse of quantize_pack4: the dequantized fp32 tensor (bit-identical to pc_qdq's output)."""
+    lib = L.load()
+    y = torch.empty(shape, dtype=torch.float32, device=packed.device)
+    N, C, HW = geometry(y)
+    L.check(lib.cnnq_pc_dequantize_pack4(_ptr(packed), _ptr(y), N, C, HW, _ptr(qp), _stream(y)),
+            'cnnq_pc_dequantize_pack4')
+    return y
+
+
 def entropy_from_hist(hist):
     """Shannon entropy (bits) of an int64 histogram tensor -> 0-dim float32 tensor on the device."""
     lib = L.load()

@@ -163,6 +163,16 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg /* 
 int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
                 uint8_t* codes, uint64_t* hist, int reverse, void* stream);
 
+/* Packed int4 as the STORED activation format (beyond the reference, which only
+ * simulates): cnnq_pc_quantize_pack4 writes the integer codes of a <= 4-bit quantization two per
+ * byte (even element in the low nibble, N*C*HW/2 bytes) - 4 B read + 0.5 B written per element;
+ * cnnq_pc_dequantize_pack4 turns them back into exactly the floats cnnq_pc_qdq would have produced.
+ * Requires HW % 4 == 0, 16-byte aligned x / y, qmax <= 15 in every channel of qp. */
+int cnnq_pc_quantize_pack4(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
+                           void* stream);
+int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                             void* stream);
+
 /* Config 2 (dynamic per-channel min/max, no clipping, uniform bit width: iq.py:409-451 with
  * bit allocation off) as three launches, two of them streaming:
  *   cnnq_pc_minmax         exact per-channel {min, max} partials pmm[G][2][C] (G = cnnq_pc_groups;

@@ -466,3 +466,17 @@ def test_per_tensor_clipping_vs_oracle(ops, shape, clip, half):
     d = (y.cpu() - ref).abs()
     assert float(d.max()) <= step * 1.01
     assert float((d > 1e-5).float().mean()) < 2e-3
+
+
+# --------------------------------------------------------------------------- f3: packed int4 storage
+@pytest.mark.parametrize('shape', [(4, 8, 14, 14), (3, 20, 12, 12), (2, 5, 2, 2), (6, 3, 56, 56), (2, 600, 4, 4)])
+def test_pack4_round_trip_equals_fused_qdq(ops, shape):
+    gen = torch.Generator().manual_seed(shape[1])
+    x = dev(torch.randn(shape, generator=gen) * 2 + 0.1)
+    y, codes, parts = ops.act_qdq_per_channel(x, 4, want_codes=True, want_parts=True)
+    packed = ops.quantize_pack4(x, parts['qp'])
+    assert packed.numel() * 2 == x.numel()
+    lo, hi = packed & 15, packed >> 4
+    c = codes.reshape(-1)
+    assert torch.equal(lo, c[0::2]) and torch.equal(hi, c[1::2])
+    assert torch.equal(ops.dequantize_pack4(packed, shape, parts['qp']), y)

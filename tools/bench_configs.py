@@ -101,3 +101,36 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def f3_line():
+    """Stored-format variant of config 2: min/max -> parameters -> quantize+pack int4 (4.5 B/elem second pass)."""
+    import ctypes
+    from cnn_quantization_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    layers, seed = [], 900
+    for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
+        if (hw * hw) % 4:
+            continue
+        for _ in range(count):
+            layers.append((laplace_activation((512, C, hw, hw), seed, dev), half)); seed += 1
+    elems = sum(x.numel() for x, _ in layers)
+    packs = [torch.empty(x.numel() // 2, dtype=torch.uint8, device=dev) for x, _ in layers]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        for (x, half), pk in zip(layers, packs):
+            N, C, HW = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+            G = lib.cnnq_pc_groups(N, C, HW, 1)
+            pmm = torch.empty((G, 2, C), device=dev); qp = torch.empty((3, C), device=dev)
+            lib.cnnq_pc_minmax(x.data_ptr(), N, C, HW, pmm.data_ptr(), st)
+            lib.cnnq_pc_minmax_params(pmm.data_ptr(), G, C, 4, int(half), qp.data_ptr(), st)
+            lib.cnnq_pc_quantize_pack4(x.data_ptr(), pk.data_ptr(), N, C, HW, qp.data_ptr(), st)
+    t = timed(run)
+    print('f3  ResNet-50 b512 (44 layers with HW%%4==0) min/max + quantize->packed int4: %.2f ms  %.1f G elem/s  '
+          '%.0f GB/s (8.5 B/elem)' % (t * 1e3, elems / t / 1e9, elems * 8.5 / t / 1e9))
+
+
+if __name__ == '__main__' and 'f3' in os.environ.get('CFGS', ''):
+    f3_line()
