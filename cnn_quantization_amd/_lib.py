@@ -17,6 +17,7 @@ DEV_ABS, DEV_Z4, NDEV = 0, 1, 2
 QP_SCALE, QP_ZP, QP_QMAX, NQP = 0, 1, 2, 3
 MT_DELTA, MT_CMIN, MT_CMAX, MT_OMEGA, MT_ALPHA, NMT = 0, 1, 2, 3, 4, 5
 MT_HIST_BINS = 131072
+KLD_BINS, KLD_QBINS, KLD_NCAND = 2001, 15, 994
 DIAG_BITS, DIAG_ALPHA, DIAG_DELTA, DIAG_OFFSET, NDIAG = 0, 1, 2, 3, 4
 
 
@@ -53,6 +54,8 @@ SIGNATURES = {
     'cnnq_entropy': (_I, [_P, _I, _P, _P]),
     'cnnq_pt_setup': (_I, [ctypes.POINTER(_F), _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'cnnq_pt_qdq': (_I, [_P, _P, _L, _P, _P, _P]),
+    'cnnq_kld_hist': (_I, [_P, _L, _L, _P, _P, _P]),
+    'cnnq_kld_search': (_I, [_P, _L, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -172,9 +172,13 @@ def run(args, quiet=False):
         print('%-22s %-22s %-22s %10s %10s %9s' % ('id', 'tag', 'shape', 'Melem', 'us', 'Gelem/s'))
         for (i, t, s, n, dt, _h) in rows:
             print('%-22s %-22s %-22s %10.2f %10.1f %9.1f' % (i, t, 'x'.join(map(str, s)), n / 1e6, dt * 1e6, n / dt / 1e9))
-        print('forward %.2f ms of which quantization path %.2f ms; conv activations: %.3f G elements in %.2f ms = '
-              '%.1f G elem/s' % (res['forward_seconds'] * 1e3, tot_t * 1e3, res['conv_elements'] / 1e9,
-                                 res['conv_quant_seconds'] * 1e3, res['conv_elements'] / res['conv_quant_seconds'] / 1e9))
+        if res['conv_quant_seconds'] > 0:
+            print('forward %.2f ms of which quantization path %.2f ms; conv activations: %.3f G elements in %.2f ms = '
+                  '%.1f G elem/s' % (res['forward_seconds'] * 1e3, tot_t * 1e3, res['conv_elements'] / 1e9,
+                                     res['conv_quant_seconds'] * 1e3,
+                                     res['conv_elements'] / res['conv_quant_seconds'] / 1e9))
+        else:   # -sm collect: statistics are gathered, nothing is quantized
+            print('forward %.2f ms (statistics collection, no quantization)' % (res['forward_seconds'] * 1e3))
         for k, v in res['entropy'].items():
             print('Average bit rate: {} - {}'.format(k, v))
     return res

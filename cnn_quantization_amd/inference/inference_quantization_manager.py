@@ -22,9 +22,11 @@ Behaviour that is part of the contract and reproduced on purpose (SURVEY.md Appe
   * the int4 "keep conv0 at 8 bit" list only applies when a stat_id is given (iqm.py:551-555).
 
 All arithmetic is in libcnnq_hip.so through cnn_quantization_amd.ops / IntQuantizer."""
+import os
 from enum import Enum
 from itertools import count
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -43,12 +45,38 @@ class StatsMode(Enum):
     use_stats = 3
 
 
-class _Measure:
-    """Stand-in for the reference's distance logger (distance_stats.py, out of scope): disabled."""
-    enabled = False
+class MeasureStatistics:
+    """Runtime distance logger (`-ms`), mirror of inference/distance_stats.py:17-59: per layer id the
+    per-sample sum of squares of every batch, written as ~/mxt-sim/distance/<folder>/distance.csv
+    (one column per layer).  The reduction is the device moments kernel (ops.row_sumsq)."""
+
+    def __init__(self, folder):
+        from pathlib import Path
+        self.enabled = False
+        self.folder = os.path.join(str(Path.home()), 'mxt-sim', 'distance', folder)
+        self.stats = {}
+        self.stats_names = ['dist']
 
     def save_measure(self, tensor, id):
-        pass
+        d = ops.row_sumsq(tensor.detach().contiguous(), tensor.shape[0]).cpu().numpy().astype(np.float64)
+        self.stats[id] = np.concatenate([self.stats[id], d]) if id in self.stats else d
+
+    def __enter__(self):
+        self.enabled = True
+        self.stats.clear()
+        return self
+
+    def __exit__(self, *args):
+        if self.enabled and len(self.stats) > 0:
+            self.enabled = False
+            import shutil
+            import pandas as pd
+            if os.path.exists(self.folder):
+                shutil.rmtree(self.folder)
+            os.makedirs(self.folder)
+            cols = list(self.stats.keys())
+            data = np.array([self.stats[c] for c in cols]).transpose()
+            pd.DataFrame(data=data, columns=cols).to_csv(os.path.join(self.folder, 'distance.csv'), index=False)
 
 
 # --------------------------------------------------------------------------------- patched layers
@@ -286,7 +314,8 @@ class QuantizationManagerInference(metaclass=Singleton):
                 self.stats_manager = StatisticManagerPerChannel(sf, load_stats=False, batch_avg=args.stats_batch_avg,
                                                                 group=group)
             else:
-                self.stats_manager = StatisticManager(sf, load_stats=False, batch_avg=args.stats_batch_avg)
+                self.stats_manager = StatisticManager(sf, load_stats=False, batch_avg=args.stats_batch_avg,
+                                                      kld_threshold=args.kld_threshold)
         elif args.stats_mode == 'use':
             self.stats_mode = StatsMode.use_stats
             if args.per_channel_quant_act:
@@ -294,7 +323,9 @@ class QuantizationManagerInference(metaclass=Singleton):
             StatisticManager(sf, load_stats=True)
         else:
             self.stats_mode = StatsMode.no_stats
-        self.measure_stats = _Measure()
+        self.measure_stats = MeasureStatistics(args.arch)
+        if getattr(args, 'measure_stats', False):
+            self.measure_stats.__enter__()
 
     # context manager / switches (quantization_manager.py:14-37)
     def __enter__(self):
@@ -305,6 +336,8 @@ class QuantizationManagerInference(metaclass=Singleton):
         self.op_manager.__exit__(args)
         if self.stats_manager is not None:
             self.stats_manager.__exit__()
+        if self.measure_stats is not None:
+            self.measure_stats.__exit__()
         self.disable()
 
     def enable(self):

@@ -4,8 +4,12 @@ pytorch_quantizer/quantization/inference/statistic_manager.py: same API and file
 id).  Serves the per-tensor quantizers (pooling, classifier, linear) in `-sm use` mode.
 
 The scalar statistics of a batch are one pass of the device kernels over the tensor viewed as a
-single channel; the error/KLD columns of the reference (mse_*, cos_*, kld_th) are calibration
-diagnostics outside the hot path and are not produced."""
+single channel.  `kld_threshold=True` adds the `kld_th` column (statistic_manager.py:80-82: the
+maximum over the batch's samples of the KLD-optimal clipping threshold) from the device
+histogram + search kernels (ops.kld_thresholds).  The error columns (mse_*/cos_*,
+statistic_manager.py:22-30) exist in the reference's files but no caller ever passes the quantized
+tensors they need (`tensors_q`), so they always hold NaN there; `collect_err=True` reproduces
+those columns, a non-empty `tensors_q` is rejected."""
 import os
 import shutil
 from pathlib import Path
@@ -28,8 +32,12 @@ class StatisticManager(metaclass=Singleton):
         self.name = folder
         self.folder = os.path.join(base_dir(), 'statistics', folder)
         self.stats_names = list(stats)
-        if kld_threshold or collect_err:
-            raise NotImplementedError('KLD thresholds / error columns are outside the hot path')
+        self.collect_err = collect_err
+        if collect_err:
+            self.stats_names += ['mse_lowp', 'mse_gaus', 'mse_laplace', 'cos_lowp', 'cos_gaus', 'cos_laplace']
+        self.kld_threshold = kld_threshold
+        if kld_threshold:
+            self.stats_names.append('kld_th')
         self.batch_avg = batch_avg
         self.stats = {}
         self.metadata = {}
@@ -42,6 +50,8 @@ class StatisticManager(metaclass=Singleton):
             self.stats_df = None
 
     def save_tensor_stats(self, tensor, tag, id, tensors_q={}, force_global_min_max=False):
+        if len(tensors_q) > 0:
+            raise NotImplementedError('error columns from quantized tensors: no caller in the reference')
         x = tensor.detach().contiguous()
         n = x.numel()
         table, mom = ops.pc_stats(x, 1, 1, n, need_b=True, need_kurt=True, need_relu=True)
@@ -55,6 +65,11 @@ class StatisticManager(metaclass=Singleton):
             r = rows.cpu().numpy()
             vals['max'] = r[L.STAT_MAX].mean(dtype=np.float32)
             vals['min'] = r[L.STAT_MIN].mean(dtype=np.float32)
+        for s in self.stats_names:
+            if s.startswith('mse_') or s.startswith('cos_'):
+                vals[s] = np.nan
+        if self.kld_threshold:
+            vals['kld_th'] = float(ops.kld_thresholds(x, x.shape[0] if x.dim() > 1 else 1)[:, 0].max().item())
         row = np.array([[vals[s] for s in self.stats_names]], dtype=np.float64)
         if id in self.stats:
             self.stats[id] = np.concatenate([self.stats[id], row])

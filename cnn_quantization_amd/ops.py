@@ -403,3 +403,32 @@ def minmax_qdq_per_tensor(x, num_bits, avg_over_batch, zero_min=False, int_exp=F
     ptp = pt_setup(x.device, num_bits, stats=stats, rows=rows, rows_mode=0 if avg_over_batch else 1,
                    zero_min=zero_min, int_exp=int_exp, enforce_true_zero=enforce_true_zero)
     return pt_qdq(x, ptp)
+
+
+def kld_thresholds(x, rows=None, want_parts=False):
+    """`-kld` calibration (inference/kld_threshold.py:6-84 per sample, statistic_manager.py:80-82):
+    x viewed as [rows, numel/rows] (rows = batch samples) -> float64 tensor [rows, 3] =
+    {optimal clipping threshold, its KL divergence, candidate index}; the `kld_th` statistic of
+    the batch is out[:, 0].max().  want_parts adds (hist [rows, 2001] int32, div [rows, 994])."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    rows = int(rows if rows is not None else (x.shape[0] if x.dim() > 1 else 1))
+    length = x.numel() // rows
+    rowmm = tensor_row_stats(x, rows)
+    hist = torch.empty((rows, L.KLD_BINS), dtype=torch.int32, device=x.device)
+    div = torch.empty((rows, L.KLD_NCAND), dtype=torch.float64, device=x.device)
+    out = torch.empty((rows, 3), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_kld_hist(_ptr(x), rows, length, _ptr(rowmm), _ptr(hist), _stream(x)), 'cnnq_kld_hist')
+    L.check(lib.cnnq_kld_search(_ptr(hist), rows, _ptr(rowmm), _ptr(div), _ptr(out), _stream(x)), 'cnnq_kld_search')
+    if want_parts:
+        return out, hist, div
+    return out
+
+
+def row_sumsq(x, rows=None):
+    """Per-sample sum of squares, the runtime distance measure of distance_stats.py:22-33
+    (`torch.sum(t**2, dim=-1)` on [N, -1]): the moments kernel with N = 1, C = rows (fp64 sums)."""
+    x = _dev_f32(x, 'x')
+    rows = int(rows if rows is not None else x.shape[0])
+    _, mom = pc_stats(x, 1, rows, x.numel() // rows, local_only=True)
+    return mom[L.MOM_SUMSQ].to(torch.float32)

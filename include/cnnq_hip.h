@@ -244,6 +244,24 @@ int cnnq_pt_setup(const float* range_offset_host, const float* stats, int64_t st
                   void* stream);
 int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const float* noise, void* stream);
 
+/* KLD calibration (`-kld` with `-sm collect`): replaces the host loops of
+ * inference/kld_threshold.py:6-84 (`get_kld_threshold_15bins`, one call per sample at
+ * statistic_manager.py:80-82).  x is [rows][len] contiguous (rows = samples of the batch),
+ * rowmm[2][rows] the per-row {min, max} (cnnq_pc_minmax + cnnq_pc_minmax_reduce with N = 1, C = rows).
+ *   cnnq_kld_hist    hist[rows][CNNQ_KLD_BINS] (uint32; zeroed here): numpy.histogram(arr, 2001,
+ *                    range = (-th, th)), th = max(|min|, |max|), float64 edges (kld_threshold.py:19-23);
+ *                    NaN elements are not counted; len < 2^31.
+ *   cnnq_kld_search  div[rows][CNNQ_KLD_NCAND] = KL(P || Q) for the 994 symmetric clipping candidates
+ *                    (kld_threshold.py:31-77, 15 quantized bins), then per row
+ *                    out[rows][3] = {optimal threshold (the upper histogram edge of the kept range),
+ *                    its divergence, candidate index}: numpy.argmin semantics (kld_threshold.py:79-81).
+ *                    The `kld_th` statistic is the maximum of out[:,0] over the batch. */
+#define CNNQ_KLD_BINS 2001
+#define CNNQ_KLD_QBINS 15
+#define CNNQ_KLD_NCAND 994
+int cnnq_kld_hist(const float* x, int64_t rows, int64_t len, const float* rowmm, uint32_t* hist, void* stream);
+int cnnq_kld_search(const uint32_t* hist, int64_t rows, const float* rowmm, double* div, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
