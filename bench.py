@@ -82,7 +82,8 @@ def run_step(ops, layers, group):
 def time_kernel_classes(layers):
     """Device time per kernel class, measured live with HIP events recorded on the launch stream
     between the launches of ONE pass that issues exactly the sequence cnnq_pc_minmax_qdq issues
-    (so cache state is the real one; the ~3 us parameter kernel is charged to k_qdq).  Returns
+    (so cache state is the real one), one event per launch boundary so that each class is the
+    duration of that kernel alone, as rocprofv3 --kernel-trace reports it.  Returns
     {class: (seconds, launches)}."""
     import ctypes
     from cnn_quantization_amd import _lib
@@ -94,18 +95,20 @@ def time_kernel_classes(layers):
         G = lib.cnnq_pc_groups(N, C, HW, 1)
         pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
         qp = torch.empty((3, C), dtype=torch.float32, device=x.device)
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         _lib.check(lib.cnnq_pc_minmax(x.data_ptr(), N, C, HW, pmm.data_ptr(), st), 'minmax')
         e[1].record()
         _lib.check(lib.cnnq_pc_minmax_params(pmm.data_ptr(), G, C, 4, int(L['half']), qp.data_ptr(), st), 'params')
-        _lib.check(lib.cnnq_pc_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, qp.data_ptr(), None, None, 1, st), 'qdq')
         e[2].record()
+        _lib.check(lib.cnnq_pc_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, qp.data_ptr(), None, None, 1, st), 'qdq')
+        e[3].record()
         recs.append(e)
     torch.cuda.synchronize()
     t_mm = sum(e[0].elapsed_time(e[1]) for e in recs) * 1e-3
-    t_q = sum(e[1].elapsed_time(e[2]) for e in recs) * 1e-3
-    return {'k_minmax': (t_mm, len(recs)), 'k_qdq': (t_q, len(recs))}
+    t_p = sum(e[1].elapsed_time(e[2]) for e in recs) * 1e-3
+    t_q = sum(e[2].elapsed_time(e[3]) for e in recs) * 1e-3
+    return {'k_minmax': (t_mm, len(recs)), 'k_minmax_params': (t_p, len(recs)), 'k_qdq': (t_q, len(recs))}
 
 
 def cpu_baseline(batch_sample=8, reps=3):

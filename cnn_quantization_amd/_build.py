@@ -9,7 +9,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, 'csrc', 'cnnq_kernels.hip')]
-HDR = [os.path.join(ROOT, 'include', 'cnnq_hip.h')]
+HDR = [os.path.join(ROOT, 'include', 'cnnq_hip.h')] + sorted(
+    os.path.join(PKG, 'csrc', f) for f in os.listdir(os.path.join(PKG, 'csrc')) if f.endswith('.cuh'))
 LIB = os.path.join(PKG, 'libcnnq_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
 

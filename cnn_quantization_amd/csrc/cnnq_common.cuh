@@ -1,0 +1,124 @@
+// cnnq_common.cuh - shared constants, the column-walk decomposition (Geo / Blk / blk_of), vector and non-temporal load/store helpers.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the design).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "cnnq_hip.h"
+
+namespace {
+
+constexpr int TPB = 256;       // 4 wave64 per workgroup
+constexpr int MAXCH = 256;     // max channels a workgroup owns (keeps the per-channel LDS tables at 1 KB each)
+
+struct Geo {
+    int N, C, HW;
+    int P;      // C*HW, elements per sample plane (< 2^31)
+    int mode;   // 1: block = slice of one channel, 2: block = k whole channels
+    int nb, w;  // mode 1: blocks per channel, columns (loads) per block
+    int k;      // mode 2: channels per block
+    int ncb;    // column blocks per plane (of the channel range)
+    int S;      // batch splits
+    int cbeg;   // first channel of the range this launch covers
+    int Cn;     // channels in the range
+    int rev;    // 1: walk blocks and samples in descending address order (re-read what the
+                //    previous pass touched LAST first: Infinity-Cache friendly)
+};
+
+struct Variant {
+    int vec, A, J;  // elements per load, accumulator sets per load, loads per thread per sample
+};
+
+struct Blk {
+    int c0, c1;      // channels [c0, c1)
+    int col0, col1;  // plane columns [col0, col1), in units of VEC elements
+    int n0, n1;      // samples [n0, n1)
+    int grp;         // partial group index
+};
+
+template <int VEC>
+__device__ __forceinline__ Blk blk_of(const Geo& g) {
+    Blk b;
+    const int bid = g.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int cb = bid % g.ncb;
+    const int s = bid / g.ncb;
+    b.n0 = (int)(((int64_t)s * g.N) / g.S);
+    b.n1 = (int)(((int64_t)(s + 1) * g.N) / g.S);
+    if (g.mode == 1) {
+        const int cpc = g.HW / VEC;
+        const int cr = cb / g.nb;
+        const int bb = cb - cr * g.nb;
+        const int c = g.cbeg + cr;
+        b.c0 = c;
+        b.c1 = c + 1;
+        b.col0 = c * cpc + bb * g.w;
+        b.col1 = min(b.col0 + g.w, (c + 1) * cpc);
+        b.grp = s * g.nb + bb;
+    } else {
+        b.c0 = g.cbeg + cb * g.k;
+        b.c1 = min(g.cbeg + g.Cn, b.c0 + g.k);
+        b.col0 = (int)(((int64_t)b.c0 * g.HW) / VEC);
+        b.col1 = (int)(((int64_t)b.c1 * g.HW) / VEC);
+        b.grp = s;
+    }
+    return b;
+}
+
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *p = v[0];
+    }
+}
+
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// streaming (non-temporal) forms.  Read-only streaming with `nt` loads runs at 7.1 TB/s on MI355X
+// against 6.3 TB/s with plain loads (tools/ubench_read.py); they do not allocate in the Infinity
+// Cache, so the statistics passes use them only for tensors too large for the next pass to find
+// anything still cached (NT_BYTES).  The Q/DQ pass always uses them: x is read for the last time and
+// y is never re-read by this path.
+constexpr int64_t NT_BYTES = (int64_t)384 << 20;   // swept 0..1000 MB on the ResNet-50 set: flat optimum 250-400
+
+template <int VEC>
+__device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = __builtin_nontemporal_load(p);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        f4_t t;
+        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<f4_t*>(p));
+    } else {
+        __builtin_nontemporal_store(v[0], p);
+    }
+}
+template <int VEC, bool NTL>
+__device__ __forceinline__ void ldv_sel(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (NTL) ldv_nt<VEC>(p, v); else ldv<VEC>(p, v);
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+}  // namespace

@@ -1,0 +1,254 @@
+// cnnq_midtread.cuh - mid-tread quantization with per-channel bin allocation and its entropy.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the design).
+#pragma once
+#include "cnnq_common.cuh"
+#include "cnnq_params.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// mid-tread quantization with per-channel bin allocation (config 5, iq.py:128-225)
+// ------------------------------------------------------------------------------------------
+struct MtCfg {
+    double target;  // bits; bins per channel on average = 2^target
+    int clip;       // 1: laplace-prior clipping around the mean (activations), 0: min/max range (weights)
+    int sym;        // 0: non-negative range (force_positive / half_range)
+};
+
+constexpr int MT_NB = CNNQ_MT_HIST_BINS;  // integer-code bins, codes -MT_NB/2 .. MT_NB/2-1
+
+__global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ stats, int C, const MtCfg cfg,
+                                                    const double* __restrict__ tabs, int ntab,
+                                                    float* __restrict__ mt) {
+    __shared__ double sh[PTPB / 64];
+    const int tid = threadIdx.x;
+    const float* vmin = stats + (size_t)CNNQ_STAT_MIN * C;
+    const float* vmax = stats + (size_t)CNNQ_STAT_MAX * C;
+    const float* vmean = stats + (size_t)CNNQ_STAT_MEAN * C;
+    const float* vstd = stats + (size_t)CNNQ_STAT_STD * C;
+    const float* vb = stats + (size_t)CNNQ_STAT_B * C;
+    const double* otab = tabs;
+    const double* atab = tabs + ntab;
+    // eq. 10 (iq.py:128-135): omega = round(C * 2^target * sigma^(2/3) / sum sigma^(2/3))
+    double psum_d = 0.;
+    for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(vstd[c], (float)(2. / 3));
+    const float psum = (float)block_sum(psum_d, sh);
+    const float B = (float)((double)C * pow(2., cfg.target));
+    for (int c = tid; c < C; c += PTPB) {
+        const float p = powf(vstd[c], (float)(2. / 3));
+        const float omega = rintf((B * p) / psum);
+        float rng, am = 0.f;
+        const float mu = vmean[c];
+        const float mu0 = fmaxf(mu, 0.f);
+        if (cfg.clip) {
+            // linear interpolation in the (omega, alpha) table, fp64 like numpy (iq.py:137-145)
+            const double om = (double)(cfg.sym ? omega : omega * 2.f);
+            int lo = 0, hi = ntab;  // searchsorted, side='left'
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (otab[mid] < om) lo = mid + 1; else hi = mid;
+            }
+            const int i = lo < ntab ? lo : ntab - 1;     // (the reference raises beyond the table)
+            const int im = i == 0 ? ntab - 1 : i - 1;    // numpy's index -1 wraps
+            const double inc = (atab[i] - atab[im]) / (otab[i] - otab[im]);
+            am = (float)(atab[i] - inc * (otab[i] - om));
+            rng = cfg.sym ? (2.f * am) * vb[c] : mu0 + am * vb[c];
+        } else {
+            rng = cfg.sym ? vmax[c] - vmin[c] : vmax[c];
+        }
+        const float delta = (omega > 0.f) ? rng / omega : 3.402823466e+38f;
+        float cmin = -INFINITY, cmax = INFINITY;
+        if (cfg.clip) {
+            const float muq = (cfg.sym ? mu : mu0) / delta;
+            cmax = muq + (cfg.sym ? omega / 2.f : omega);
+            cmin = cfg.sym ? muq - omega / 2.f : 0.f;
+        }
+        mt[(size_t)CNNQ_MT_DELTA * C + c] = delta;
+        mt[(size_t)CNNQ_MT_CMIN * C + c] = cmin;
+        mt[(size_t)CNNQ_MT_CMAX * C + c] = cmax;
+        mt[(size_t)CNNQ_MT_OMEGA * C + c] = omega;
+        mt[(size_t)CNNQ_MT_ALPHA * C + c] = am;
+    }
+}
+
+// hist layout (uint64): [0, MT_NB) integer codes -MT_NB/2.., [MT_NB] below range, [MT_NB+1] above
+// range, then C counts of "clamped to a non-integer c_min[c]" and C of "... c_max[c]".
+template <int VEC, int A, int J, bool CLIP, bool HIST, bool CODES>
+__global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
+                                                const float* __restrict__ mt, float* __restrict__ codes,
+                                                unsigned long long* __restrict__ hist) {
+    // LDS histogram window: MT_W integer codes starting at the smallest clamp bound of this
+    // workgroup's channels (codes are >= c_min), MT_REP replicas by lane to spread equal codes;
+    // codes beyond the window (a channel with > MT_W bins) go to the global bins directly.
+    // The first MT_HOT codes of the window (where the mass is) get 32 lane-replicas = conflict-free,
+    // the tail 8.
+    constexpr int MT_W = 512, MT_HOT = 64, MT_REP = 8;
+    constexpr int MT_WORDS = MT_HOT * 32 + (MT_W - MT_HOT) * MT_REP;
+    auto hidx = [](unsigned kk, int tid) -> unsigned {
+        return kk < (unsigned)MT_HOT ? kk * 32u + (unsigned)(tid & 31)
+                                     : (unsigned)(MT_HOT * 32) + (kk - MT_HOT) * MT_REP + (unsigned)(tid & (MT_REP - 1));
+    };
+    __shared__ float sh_d[MAXCH], sh_lo[MAXCH], sh_hi[MAXCH];
+    __shared__ unsigned sh_hist[HIST ? MT_WORDS : 1];
+    __shared__ unsigned sh_clo[HIST ? MAXCH : 1], sh_chi[HIST ? MAXCH : 1];
+    __shared__ int sh_wstart;
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    const int nch = b.c1 - b.c0;
+    if constexpr (HIST) {
+        for (int i = tid; i < MT_WORDS; i += TPB) sh_hist[i] = 0u;
+        for (int i = tid; i < nch; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
+        if (tid == 0) sh_wstart = CLIP ? 0x7fffffff : -MT_W / 2;
+    }
+    __syncthreads();
+    for (int i = tid; i < nch; i += TPB) {
+        sh_d[i] = mt[(size_t)CNNQ_MT_DELTA * g.C + b.c0 + i];
+        const float lo_i = mt[(size_t)CNNQ_MT_CMIN * g.C + b.c0 + i];
+        sh_lo[i] = lo_i;
+        sh_hi[i] = mt[(size_t)CNNQ_MT_CMAX * g.C + b.c0 + i];
+        if constexpr (HIST && CLIP) atomicMin(&sh_wstart, (int)floorf(fminf(fmaxf(lo_i, -1e9f), 1e9f)));
+    }
+    __syncthreads();
+    const int wstart = HIST ? max(sh_wstart, -MT_NB / 2) : 0;
+    int col[J], chl[J][A];
+    bool ok[J];
+    float d[J][A], lo[J][A], hi[J][A];
+    unsigned nzero = 0;  // code 0 (the mode of the distribution) is counted in a register, see k_qdq
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+            chl[j][a] = ch;
+            d[j][a] = sh_d[ch];
+            lo[j][a] = sh_lo[ch];
+            hi[j][a] = sh_hi[ch];
+        }
+    }
+    const int nrows = b.n1 - b.n0;
+    constexpr int NU = (J == 1) ? 4 : 2;
+#pragma unroll NU
+    for (int r = 0; r < nrows; ++r) {
+        const size_t off = (size_t)(b.n0 + r) * (size_t)g.P;
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv_nt<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float o[VEC], q[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                float t = rintf(v[j][e] / d[j][a]);          // iq.py:202-203
+                if constexpr (CLIP) {
+                    // torch.min(t, hi) = t < hi ? t : hi and torch.max(t, lo) = t > lo ? t : lo, NaN kept
+                    // (the bound wins ties: max(-0, +0) is +0, iq.py:213-214)
+                    t = (t < hi[j][a] || t != t) ? t : hi[j][a];
+                    t = (t > lo[j][a] || t != t) ? t : lo[j][a];
+                }
+                q[e] = t;
+                o[e] = t * d[j][a];                          // iq.py:224
+            }
+            if (ok[j]) {
+                stv_nt<VEC>(y + off + (size_t)col[j] * VEC, o);
+                if constexpr (CODES) stv<VEC>(codes + off + (size_t)col[j] * VEC, q);
+                if constexpr (HIST) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int a = (A == 1 ? 0 : e);
+                        const float t = q[e];
+                        // fast path (branch-light): integer code inside the LDS window
+                        const int k = (int)t;                       // saturating; NaN -> 0
+                        const bool isint = ((float)k == t);
+                        const unsigned kk = (unsigned)(k - wstart);
+                        if (t == 0.f) {
+                            ++nzero;
+                        } else if (isint && kk < (unsigned)MT_W) {
+                            atomicAdd(&sh_hist[hidx(kk, tid)], 1u);
+                        } else if (t == rintf(t)) {                 // rare: integer code outside the window
+                            if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
+                            else atomicAdd(&hist[t < 0.f ? MT_NB : MT_NB + 1], 1ull);
+                        } else if (CLIP && t == hi[j][a]) {         // rare: clamped to a non-integer bound
+                            atomicAdd(&sh_chi[chl[j][a]], 1u);
+                        } else {
+                            atomicAdd(&sh_clo[chl[j][a]], 1u);      // non-integer c_min (or NaN)
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HIST) {
+        if (nzero) {
+            const int kk = -wstart;
+            if (kk >= 0 && kk < MT_W) atomicAdd(&sh_hist[hidx((unsigned)kk, tid)], nzero);
+            else atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
+        }
+        __syncthreads();
+        for (int i = tid; i < MT_W; i += TPB) {
+            unsigned tot = 0;
+            const int nrep = i < MT_HOT ? 32 : MT_REP;
+            for (int r = 0; r < nrep; ++r) tot += sh_hist[hidx((unsigned)i, r + tid)];
+            const int k = wstart + i;
+            if (tot && k < MT_NB / 2) atomicAdd(&hist[k + MT_NB / 2], (unsigned long long)tot);
+        }
+        for (int i = tid; i < nch; i += TPB) {
+            if (sh_clo[i]) atomicAdd(&hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]);
+            if (sh_chi[i]) atomicAdd(&hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]);
+        }
+    }
+}
+
+// entropy over integer bins + the per-channel non-integer clamp values (equal values merged,
+// as torch.unique would, utils/entropy.py:10)
+__global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* __restrict__ hist,
+                                                     const float* __restrict__ mt, int C, double total,
+                                                     float* __restrict__ out) {
+    __shared__ double sh[PTPB / 64];
+    const int tid = threadIdx.x;
+    const float ftotal = (float)total;
+    double e = 0.;
+    for (int i = tid; i < MT_NB + 2; i += PTPB) {
+        const unsigned long long c = hist[i];
+        if (c) { const float pr = (float)c / ftotal; e += (double)(-pr * log2f(pr)); }
+    }
+    // non-integer clamp values: one histogram entry per (channel, bound); equal values are merged.
+    // The pairwise scan runs out of LDS (2*C <= MT_ENT entries), from global memory beyond that.
+    const unsigned long long* cl = hist + MT_NB + 2;
+    constexpr int MT_ENT = 4096;
+    __shared__ float sv[MT_ENT];
+    __shared__ unsigned sc[MT_ENT];
+    const int n2 = 2 * C;
+    const bool in_lds = n2 <= MT_ENT;
+    if (in_lds) {
+        for (int i = tid; i < n2; i += PTPB) {
+            sv[i] = mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
+            sc[i] = (unsigned)cl[i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n2; i += PTPB) {
+        const unsigned long long ci = in_lds ? sc[i] : cl[i];
+        if (!ci) continue;
+        const float vi = in_lds ? sv[i] : mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
+        bool dup = false;
+        unsigned long long cnt = ci;
+        for (int j = 0; j < n2; ++j) {
+            const unsigned long long cj = in_lds ? sc[j] : cl[j];
+            if (j == i || !cj) continue;
+            const float vj = in_lds ? sv[j] : mt[(size_t)(j < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (j < C ? j : j - C)];
+            if (vj == vi) { if (j < i) { dup = true; break; } cnt += cj; }
+        }
+        if (dup) continue;
+        const float pr = (float)cnt / ftotal;
+        e += (double)(-pr * log2f(pr));
+    }
+    const double r = block_sum(e, sh);
+    if (tid == 0) out[0] = (float)r;
+}
+
+}  // namespace

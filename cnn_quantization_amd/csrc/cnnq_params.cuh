@@ -1,0 +1,118 @@
+// cnnq_params.cuh - statistics -> ACIQ clipping -> bit allocation -> scale / zero point / qmax, on the device.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the design).
+#pragma once
+#include "cnnq_common.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// statistics -> scale / zero point / qmax (one workgroup, no host round trips)
+// ------------------------------------------------------------------------------------------
+constexpr int PTPB = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = 0.;
+    for (int i = 0; i < PTPB / 64; ++i) r += sh[i];
+    return r;
+}
+
+__constant__ float c_laplace[9] = {1.05f, 1.86f, 2.83f, 3.89f, 5.03f, 6.2f, 7.41f, 8.64f, 9.89f};
+__constant__ float c_laplace_pos[9] = {1.86f, 2.83f, 3.89f, 5.02f, 6.2f, 7.41f, 8.64f, 9.89f, 11.16f};
+__constant__ float c_gaus[9] = {0.f, 1.24f, 1.71f, 2.15f, 2.55f, 2.93f, 3.28f, 3.61f, 3.92f};
+__constant__ float c_gaus_pos[9] = {0.f, 1.71f, 2.15f, 2.55f, 2.93f, 3.28f, 3.61f, 3.92f, 4.2f};
+
+__global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats, int C, const cnnq_params_cfg cfg,
+                                                 float* __restrict__ qp, float* __restrict__ diag,
+                                                 float* __restrict__ bits_ws) {
+    __shared__ double sh[PTPB / 64];
+    const int tid = threadIdx.x;
+    const float* vmin = stats + (size_t)CNNQ_STAT_MIN * C;
+    const float* vmax = stats + (size_t)CNNQ_STAT_MAX * C;
+    const float* vmean = stats + (size_t)CNNQ_STAT_MEAN * C;
+    const float* vstd = stats + (size_t)CNNQ_STAT_STD * C;
+    const float* vb = stats + (size_t)CNNQ_STAT_B * C;
+    const bool ba = cfg.bit_alloc && cfg.num_bits <= 4;
+
+    if (ba) {
+        // fixed-target bit allocation, iq.py:381-407 (fp32 tensor math, double target)
+        const float* prior = cfg.prior_is_b ? vb : vstd;
+        const float goal = (float)cfg.target;
+        double target = cfg.target;
+        double delta = 1.;
+        // p = prior^(2/3) and its sum do not change between iterations
+        double psum_d = 0.;
+        for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(prior[c], (float)(2. / 3));
+        const float psum = (float)block_sum(psum_d, sh);
+        for (int it = 0; it < 10 && fabs(2. * delta) > 0.01; ++it) {
+            const float B = (float)((double)C * pow(2., target));
+            double bsum = 0.;
+            for (int c = tid; c < C; c += PTPB) {
+                const float p = powf(prior[c], (float)(2. / 3));
+                const float bins = (B * p) / psum;
+                float bits = cfg.round_mode ? rintf(log2f(bins)) : ceilf(log2f(bins));
+                if (bits < 0.f) bits = 0.f;
+                if (bits > 8.f) bits = 8.f;
+                bits_ws[c] = bits;
+                bsum += (double)bits;
+            }
+            const float mean_bits = (float)block_sum(bsum, sh) / (float)C;
+            delta = (double)((goal - mean_bits) / 2.f);
+            target += delta;
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < C; c += PTPB) {
+        const float bits = ba ? bits_ws[c] : (float)cfg.num_bits;
+        float alpha = 0.f, delta, offset;
+        if (cfg.clip == 0) {
+            offset = cfg.positive ? 0.f : vmin[c];
+            delta = vmax[c] - offset;
+        } else {
+            if (cfg.clip == 1) {
+                const int ib = (int)bits;  // NaN bits cannot occur: clamped comparisons leave 0..8
+                alpha = vb[c] * (cfg.positive ? c_laplace_pos[ib] : c_laplace[ib]);
+            } else if (cfg.clip == 2) {
+                alpha = vstd[c] * (cfg.positive ? c_gaus_pos[cfg.num_bits] : c_gaus[cfg.num_bits]);
+            } else {
+                alpha = cfg.pstd * vstd[c];
+            }
+            float range;
+            if (cfg.positive) {
+                range = fmaxf(vmean[c], 0.f) + alpha;
+                offset = 0.f;
+            } else {
+                range = 2.f * alpha;
+                offset = fmaxf(vmin[c], vmean[c] - alpha);
+            }
+            const float mx = offset + range;                   // iq.py:351
+            delta = cfg.direct_range ? range : mx - offset;    // iq.py:443 (per channel) / :357 (per tensor)
+        }
+        float qmax, scale;
+        if (ba) {
+            qmax = exp2f(bits) - 1.f;
+            scale = (qmax > 0.f) ? delta / qmax : 0.f;
+        } else {
+            qmax = (float)((1u << cfg.num_bits) - 1u);
+            scale = delta / qmax;
+        }
+        scale = (scale < 1e-8f) ? 1e-8f : scale;  // NaN stays NaN, as torch.max does
+        const float zp = rintf(0.f - offset / scale);
+        qp[(size_t)CNNQ_QP_SCALE * C + c] = scale;
+        qp[(size_t)CNNQ_QP_ZP * C + c] = zp;
+        qp[(size_t)CNNQ_QP_QMAX * C + c] = qmax;
+        if (diag) {
+            diag[(size_t)CNNQ_DIAG_BITS * C + c] = bits;
+            diag[(size_t)CNNQ_DIAG_ALPHA * C + c] = alpha;
+            diag[(size_t)CNNQ_DIAG_DELTA * C + c] = delta;
+            diag[(size_t)CNNQ_DIAG_OFFSET * C + c] = offset;
+        }
+    }
+}
+
+}  // namespace

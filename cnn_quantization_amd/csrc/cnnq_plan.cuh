@@ -1,0 +1,137 @@
+// cnnq_plan.cuh - host side: load-shape choice, launch geometry, template dispatch.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the design).
+#pragma once
+#include "cnnq_common.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// host side: geometry and launches
+// ------------------------------------------------------------------------------------------
+int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+constexpr int MAXG = 64;   // upper bound on batch splits S (partial groups per channel = S * nb)
+
+// Load shape for a tensor.  For the aligned float4 shape the loads per lane per sample (J) adapt
+// to the geometry: 4 when one channel row is long (H*W/4 > 1024 -> a workgroup owns a slice of a
+// channel), otherwise the largest of {4, 2, 1} that still yields >= 2048 workgroups, so that
+// small-H*W layers (14x14, 28x28 with few channels) fill the 256 CUs.
+int choose_variant(int64_t N, int64_t C, int64_t HW, bool aligned16, Variant* v) {
+    if (aligned16 && HW % 4 == 0) {
+        const int64_t cpc = HW / 4;
+        int J = 4;
+        if (cpc <= TPB * 4) {
+            const int64_t smax = N < MAXG ? N : MAXG;
+            for (J = 4; J > 1; J >>= 1) {
+                const int64_t cap = TPB * J;
+                const int64_t ncb = (cpc > cap) ? C * ((cpc + cap - 1) / cap) : (C + cap / cpc - 1) / (cap / cpc);
+                if (ncb * smax >= 2048) break;
+            }
+        }
+        *v = {4, 1, J};
+        return 0;
+    }
+    if (aligned16 && (C * HW) % 4 == 0) {
+        const int m = 4 / gcd_i((int)(HW % 4), 4);
+        if ((int64_t)m * HW <= TPB * 4) { *v = {4, 4, 1}; return 0; }
+    }
+    *v = {1, 1, 4};
+    return 0;
+}
+
+// Geometry of one launch over channels [cbeg, cbeg + Cn) of x[N][C][HW].
+// max_groups > 0 bounds the batch splits S of the passes that emit one partial record per group
+// and channel (they all use MAXG, so they share one group count G = S * nb); `fine` requests the
+// short-workgroup geometry of the table-driven elementwise passes instead.
+int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, int64_t Cn, int max_groups, int rev,
+             int fine, Geo* g) {
+    if (N <= 0 || C <= 0 || HW <= 0 || cbeg < 0 || Cn <= 0 || cbeg + Cn > C) return CNNQ_EINVAL;
+    if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    g->N = (int)N; g->C = (int)C; g->HW = (int)HW; g->P = (int)(C * HW);
+    g->cbeg = (int)cbeg; g->Cn = (int)Cn; g->rev = rev;
+    g->nb = 1; g->w = 0; g->k = 1;
+    const int cap = TPB * v.J;  // loads per block per sample
+    if (v.A == 4) {             // straddle: k whole channels with k*HW % 4 == 0
+        const int m = 4 / gcd_i((int)(HW % 4), 4);
+        if (cbeg % m != 0) return CNNQ_EINVAL;  // the range must start on a 16-byte boundary
+        int k = (int)((cap * 4) / HW);
+        if (k > MAXCH) k = MAXCH;
+        k -= k % m;
+        g->mode = 2;
+        g->k = k;
+        g->ncb = (int)((Cn + k - 1) / k);
+    } else {
+        const int64_t cpc = HW / v.vec;
+        if (cpc > cap) {
+            g->mode = 1;
+            int64_t nb = (cpc + cap - 1) / cap;
+            const int64_t w = (cpc + nb - 1) / nb;
+            nb = (cpc + w - 1) / w;
+            if (Cn * nb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+            g->nb = (int)nb;
+            g->w = (int)w;
+            g->ncb = (int)(Cn * nb);
+        } else {
+            g->mode = 2;
+            g->k = (int)(cap / cpc);
+            if (g->k > MAXCH) g->k = MAXCH;
+            g->ncb = (int)((Cn + g->k - 1) / g->k);
+        }
+    }
+    // enough workgroups to fill 256 CUs (x 6-8 resident each) a few times over
+    const int64_t target = 4096;
+    int64_t S = (target + g->ncb - 1) / g->ncb;
+    if (S > N) S = N;
+    if (max_groups > 0 && S > max_groups) S = max_groups;
+    if (fine) {
+        // table-driven elementwise passes (no per-workgroup reduction or partial record): many short
+        // workgroups dispatched in address order - about 14 KB of x per workgroup - stream read+write
+        // markedly faster than long-lived ones (6.1-6.7 vs 5.4 TB/s measured)
+        const int64_t cols = (g->mode == 1) ? g->w : (int64_t)g->k * HW * v.A / v.vec / v.A;
+        const int64_t row_bytes = cols * v.vec * 4;
+        int64_t rows = (14336 + row_bytes / 2) / (row_bytes > 0 ? row_bytes : 1);   // swept 8-32 KB
+        if (rows < 1) rows = 1;
+        S = (N + rows - 1) / rows;
+    }
+    if (S < 1) S = 1;
+    g->S = (int)S;
+    if ((int64_t)g->S * g->ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    return 0;
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline int launch_status() { return (int)hipGetLastError(); }
+
+// one plan (load shape + geometry) per tensor, shared by every pass over it
+int plan(int64_t N, int64_t C, int64_t HW, bool aligned16, int rev, Variant* v, Geo* g, int fine = 0) {
+    choose_variant(N, C, HW, aligned16, v);
+    return make_geo(N, C, HW, *v, 0, C, MAXG, rev, fine, g);
+}
+
+// dispatch on the runtime load shape: invokes F<VEC, A, J>()
+#define CNNQ_DISPATCH(v, F)                                          \
+    do {                                                             \
+        if ((v).vec == 4 && (v).A == 1) {                            \
+            if ((v).J == 4) { F(4, 1, 4); }                          \
+            else if ((v).J == 2) { F(4, 1, 2); }                     \
+            else { F(4, 1, 1); }                                     \
+        } else if ((v).vec == 4) { F(4, 4, 1); }                     \
+        else { F(1, 1, 4); }                                         \
+    } while (0)
+
+int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const float* qp, uint8_t* codes,
+               unsigned long long* h, hipStream_t st) {
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+#define LAUNCH_QDQ(VEC, A, J)                                                                                       \
+    do {                                                                                                            \
+        if (codes && h) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, true>), grid, block, 0, st, x, y, g, qp, codes, h);   \
+        else if (codes) hipLaunchKernelGGL((k_qdq<VEC, A, J, true, false>), grid, block, 0, st, x, y, g, qp, codes, h);  \
+        else if (h) hipLaunchKernelGGL((k_qdq<VEC, A, J, false, true>), grid, block, 0, st, x, y, g, qp, codes, h);      \
+        else hipLaunchKernelGGL((k_qdq<VEC, A, J, false, false>), grid, block, 0, st, x, y, g, qp, codes, h);            \
+    } while (0)
+    CNNQ_DISPATCH(v, LAUNCH_QDQ);
+#undef LAUNCH_QDQ
+    return launch_status();
+}
+
+}  // namespace

@@ -1,0 +1,317 @@
+// cnnq_qdq.cuh - config-2 pipeline: exact min/max partials, parameter table, the fused per-channel Q/DQ, code entropy.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the design).
+#pragma once
+#include "cnnq_common.cuh"
+#include "cnnq_params.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// the core: fused per-channel quantize -> clamp -> round -> dequantize on native NCHW
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax, float& code) {
+    float q = x / scale;         // IEEE divide (v_div_scale / v_rcp / v_fma.. / v_div_fixup)
+    q = q + zp;                  // separately rounded (-ffp-contract=off)
+    q = (q > qmax) ? qmax : q;   // compare+select keeps NaN like torch.clamp / torch.where
+    q = (q < 0.f) ? 0.f : q;
+    q = rintf(q);                // v_rndne_f32: half to even, as torch.round
+    code = q;
+    return (q - zp) * scale;
+}
+
+// Exact per-channel min / max for config 2 and the per-tensor paths.  Each workgroup writes ONE
+// {min, max} pair per channel it owns into pmm[G][2][C] (plain stores, every (group, channel) entry
+// written exactly once: no atomics, no initialisation, deterministic); k_minmax_params /
+// k_minmax_reduce merge the G pairs with one wave per channel.  (Device-scope atomics into a shared
+// table were tried first: ~160 K contended atomics per small layer cost ~50 us - see DESIGN.md.)
+template <int VEC, int A, int J, bool NTL>
+__global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, const Geo g,
+                                                float* __restrict__ pmm) {
+    constexpr int NE = TPB * J * A;
+    __shared__ float l_mn[NE], l_mx[NE];
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    int col[J];
+    bool ok[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+    }
+    float mn[J][A], mx[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int a = 0; a < A; ++a) { mn[j][a] = INFINITY; mx[j][a] = -INFINITY; }
+    const float* row = x + (size_t)b.n0 * (size_t)g.P;
+    constexpr int NU = (J == 1) ? 4 : 2;  // samples in flight per lane
+#pragma unroll NU
+    for (int n = b.n0; n < b.n1; ++n, row += g.P) {
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv_sel<VEC, NTL>(row + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if constexpr (A == 1 && VEC == 4) {
+                mn[j][0] = fminf(fminf(mn[j][0], fminf(v[j][0], v[j][1])), fminf(v[j][2], v[j][3]));
+                mx[j][0] = fmaxf(fmaxf(mx[j][0], fmaxf(v[j][0], v[j][1])), fmaxf(v[j][2], v[j][3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    mn[j][A == 1 ? 0 : e] = fminf(mn[j][A == 1 ? 0 : e], v[j][e]);
+                    mx[j][A == 1 ? 0 : e] = fmaxf(mx[j][A == 1 ? 0 : e], v[j][e]);
+                }
+            }
+        }
+    }
+    float* pn = pmm + (size_t)(2 * b.grp) * g.C;
+    float* px = pn + g.C;
+    const int wv = tid >> 6, lane = tid & 63;
+    if (g.mode == 1) {
+        float tn = INFINITY, tx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (ok[j]) { tn = fminf(tn, mn[j][0]); tx = fmaxf(tx, mx[j][0]); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { tn = fminf(tn, shfl_xor_f(tn, m)); tx = fmaxf(tx, shfl_xor_f(tx, m)); }
+        if (lane == 0) { l_mn[wv] = tn; l_mx[wv] = tx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < TPB / 64; ++i) { tn = fminf(tn, l_mn[i]); tx = fmaxf(tx, l_mx[i]); }
+            pn[b.c0] = tn;
+            px[b.c0] = tx;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int e = (j * TPB + tid) * A + a;
+                l_mn[e] = mn[j][a];
+                l_mx[e] = mx[j][a];
+            }
+        }
+    __syncthreads();
+    const int epc = g.HW * A / VEC;
+    if (epc <= 16) {
+        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
+            const int lo = (ch - b.c0) * epc;
+            float tn = INFINITY, tx = -INFINITY;
+            for (int e = lo; e < lo + epc; ++e) { tn = fminf(tn, l_mn[e]); tx = fmaxf(tx, l_mx[e]); }
+            pn[ch] = tn;
+            px[ch] = tx;
+        }
+        return;
+    }
+    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
+        const int lo = (ch - b.c0) * epc;
+        float tn = INFINITY, tx = -INFINITY;
+        for (int e = lo + lane; e < lo + epc; e += 64) { tn = fminf(tn, l_mn[e]); tx = fmaxf(tx, l_mx[e]); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { tn = fminf(tn, shfl_xor_f(tn, m)); tx = fmaxf(tx, shfl_xor_f(tx, m)); }
+        if (lane == 0) { pn[ch] = tn; px[ch] = tx; }
+    }
+}
+
+// one wave64 per channel reduces the G {min, max} pairs of that channel: lanes stride over the
+// groups (independent loads in flight), then a shuffle reduction - a serial loop over G in one
+// thread cost 10-26 us per call (measured), this form ~3 us
+__device__ __forceinline__ void reduce_pairs(const float* __restrict__ pmm, int G, int C, int c, float& mn, float& mx) {
+    const int lane = threadIdx.x & 63;
+    mn = INFINITY;
+    mx = -INFINITY;
+    for (int gi = lane; gi < G; gi += 64) {
+        mn = fminf(mn, pmm[(size_t)(2 * gi) * C + c]);
+        mx = fmaxf(mx, pmm[(size_t)(2 * gi + 1) * C + c]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, shfl_xor_f(mn, m)); mx = fmaxf(mx, shfl_xor_f(mx, m)); }
+}
+
+// pmm[G][2][C] -> out[2][C]: the rank-local extrema that ranks exchange (all_gather)
+__global__ void __launch_bounds__(TPB) k_minmax_reduce(const float* __restrict__ pmm, int G, int C,
+                                                       float* __restrict__ out) {
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float mn, mx;
+    reduce_pairs(pmm, G, C, c, mn, mx);
+    if ((threadIdx.x & 63) == 0) { out[c] = mn; out[C + c] = mx; }
+}
+
+// Code histogram (for the Shannon entropy of utils/entropy.py:6-17): 256 bins x 32 replicas in
+// LDS (32 KB), replica = lane & 31: address % 32 == lane % 32, so the 32 lanes of an LDS service
+// group always hit 32 different banks however skewed the codes are (measured with 8 replicas: 90 %
+// of the LDS cycles were bank conflicts, ~18 cycles per atomic); flushed once per workgroup.
+constexpr int HREP = 32;
+#ifndef QDQ_NT
+#define QDQ_NT 3  // bit 0: non-temporal loads of x, bit 1: non-temporal stores of y
+#endif
+
+// pmm[G][2][C] -> qp[3][C] for config 2 (iq.py:409-424,559-572): delta = max - min (or max with a
+// zero minimum), scale = max(delta / qmax, 1e-8), zero_point = round(0 - offset/scale).  One
+// wave per channel; G is the groups of one tensor or the world size after the all_gather.
+__global__ void __launch_bounds__(TPB) k_minmax_params(const float* __restrict__ pmm, int G, int C, int num_bits,
+                                                       int positive, float* __restrict__ qp) {
+    const int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float mn, mx;
+    reduce_pairs(pmm, G, C, c, mn, mx);
+    if ((threadIdx.x & 63) != 0) return;
+    const float offset = positive ? 0.f : mn;
+    const float delta = mx - offset;
+    const float qm = (float)((1u << num_bits) - 1u);
+    float sc = delta / qm;
+    sc = (sc < 1e-8f) ? 1e-8f : sc;
+    qp[(size_t)CNNQ_QP_SCALE * C + c] = sc;
+    qp[(size_t)CNNQ_QP_ZP * C + c] = rintf(0.f - offset / sc);
+    qp[(size_t)CNNQ_QP_QMAX * C + c] = qm;
+}
+
+// The fused Q/DQ.  Launched with MANY short workgroups in address order (about 14 KB of x each,
+// see make_geo `fine`): measured on MI355X, read+write streaming runs at 6.1-6.7 TB/s this way
+// against 5.4 TB/s when a workgroup walks 30+ samples (tools/ubench_copy.py, tools/split_probe.py).
+template <int VEC, int A, int J, bool CODES, bool HIST>
+__global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
+                                             const float* __restrict__ qp, uint8_t* __restrict__ codes,
+                                             unsigned long long* __restrict__ hist) {
+    __shared__ float sh_sc[MAXCH], sh_zp[MAXCH], sh_qm[MAXCH];
+    __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    if constexpr (HIST) {
+        for (int i = tid; i < 256 * HREP; i += TPB) sh_hist[i] = 0u;
+    }
+    // stage this workgroup's channels once (coalesced), then every lane keeps its own in registers;
+    // a workgroup that owns a slice of ONE channel reads its three parameters directly (uniform
+    // address -> scalar loads) and needs neither LDS nor a barrier before it starts streaming
+    const bool single = (g.mode == 1) && !HIST;
+    if (!single) {
+        for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+            sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+            sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+            sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+        }
+        __syncthreads();
+    }
+    const float u_sc = single ? qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0] : 0.f;
+    const float u_zp = single ? qp[(size_t)CNNQ_QP_ZP * g.C + b.c0] : 0.f;
+    const float u_qm = single ? qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0] : 0.f;
+    int col[J];
+    bool ok[J];
+    float sc[J][A], zp[J][A], qm[J][A];
+    // histogram: the code of x == 0 (the zero point) is by far the most frequent one (about half
+    // of a half-range layer); counting it in a register per lane instead of an LDS atomic removes
+    // the same-address serialisation that otherwise doubles the kernel time
+    unsigned nzp[HIST ? J : 1][HIST ? A : 1];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            if (single) {
+                sc[j][a] = u_sc; zp[j][a] = u_zp; qm[j][a] = u_qm;
+            } else {
+                const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+                const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+                sc[j][a] = sh_sc[ch];
+                zp[j][a] = sh_zp[ch];
+                qm[j][a] = sh_qm[ch];
+            }
+            if constexpr (HIST) nzp[j][a] = 0u;
+        }
+    }
+    const int nrows = b.n1 - b.n0;
+    constexpr int NU = (J == 1) ? 4 : 2;  // samples in flight per lane
+#pragma unroll NU
+    for (int r = 0; r < nrows; ++r) {
+        const int n = g.rev ? (b.n1 - 1 - r) : (b.n0 + r);
+        const size_t off = (size_t)n * (size_t)g.P;
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if constexpr ((QDQ_NT & 1) != 0) ldv_nt<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+            else ldv<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float o[VEC], cd[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                o[e] = qdq1(v[j][e], sc[j][a], zp[j][a], qm[j][a], cd[e]);
+            }
+            if (ok[j]) {
+                if constexpr ((QDQ_NT & 2) != 0) stv_nt<VEC>(y + off + (size_t)col[j] * VEC, o);
+                else stv<VEC>(y + off + (size_t)col[j] * VEC, o);
+                if constexpr (HIST) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int a = (A == 1 ? 0 : e);
+                        if (cd[e] == zp[j][a]) ++nzp[j][a];
+                        else atomicAdd(&sh_hist[((unsigned)(int)cd[e] & 255u) * HREP + (tid & (HREP - 1))], 1u);
+                    }
+                }
+                if constexpr (CODES) {
+                    uint8_t* cp = codes + off + (size_t)col[j] * VEC;
+                    if constexpr (VEC == 4) {
+                        const uint32_t pk = (uint32_t)cd[0] | ((uint32_t)cd[1] << 8) | ((uint32_t)cd[2] << 16) |
+                                            ((uint32_t)cd[3] << 24);
+                        *reinterpret_cast<uint32_t*>(cp) = pk;
+                    } else {
+                        *cp = (uint8_t)cd[0];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HIST) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+                if (nzp[j][a]) atomicAdd(&sh_hist[((unsigned)(int)zp[j][a] & 255u) * HREP + (tid & (HREP - 1))], nzp[j][a]);
+        __syncthreads();
+        unsigned tot = 0;
+#pragma unroll 8
+        for (int r = 0; r < HREP; ++r) tot += sh_hist[tid * HREP + ((r + tid) & (HREP - 1))];
+        if (tot) atomicAdd(&hist[tid], (unsigned long long)tot);
+    }
+}
+
+// Shannon entropy (bits) of a histogram: -sum p log2 p over the non-empty bins
+__global__ void __launch_bounds__(TPB) k_entropy(const unsigned long long* __restrict__ hist, int nbins,
+                                                 float* __restrict__ out) {
+    __shared__ double sh[TPB / 64];
+    __shared__ double sh_total;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    double t = 0.;
+    for (int i = tid; i < nbins; i += TPB) t += (double)hist[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += shfl_xor_d(t, m);
+    if (lane == 0) sh[wv] = t;
+    __syncthreads();
+    if (tid == 0) sh_total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    const float total = (float)sh_total;
+    double e = 0.;
+    for (int i = tid; i < nbins; i += TPB) {
+        const unsigned long long c = hist[i];
+        if (c) {
+            const float pr = (float)c / total;
+            e += (double)(-pr * log2f(pr));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) e += shfl_xor_d(e, m);
+    __syncthreads();
+    if (lane == 0) sh[wv] = e;
+    __syncthreads();
+    if (tid == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+}  // namespace

@@ -1,0 +1,394 @@
+// cnnq_stats.cuh - statistics passes: per-channel moments (pass A), mean absolute deviation / kurtosis (pass B) and their combine kernels.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the design).
+#pragma once
+#include "cnnq_common.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Pass A: per-channel min / max / sum / sumsq / count (+ relu sums)
+// ------------------------------------------------------------------------------------------
+struct Mom {
+    float mn, mx;
+    double s, ss, rs, rss;
+    __device__ __forceinline__ void init() {
+        mn = INFINITY; mx = -INFINITY; s = 0.; ss = 0.; rs = 0.; rss = 0.;
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void add(float v) {
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        const double d = (double)v;
+        s += d;
+        ss = fma(d, d, ss);
+        if constexpr (RELU) {
+            const double r = (double)fmaxf(v, 0.f);
+            rs += r;
+            rss = fma(r, r, rss);
+        }
+    }
+    // four values of ONE channel (a float4 that does not straddle): the 4-sums are formed in fp32
+    // (each rounding is unbiased and relative to a 4-term sum, far below the fp32 result precision
+    // once thousands of them are accumulated in fp64) - 4 instead of 12 fp64-rate ops per float4
+    template <bool RELU>
+    __device__ __forceinline__ void add4(const float (&v)[4]) {
+        mn = fminf(fminf(mn, fminf(v[0], v[1])), fminf(v[2], v[3]));
+        mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        s += (double)((v[0] + v[1]) + (v[2] + v[3]));
+        ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+        if constexpr (RELU) {
+            const float r0 = fmaxf(v[0], 0.f), r1 = fmaxf(v[1], 0.f), r2 = fmaxf(v[2], 0.f), r3 = fmaxf(v[3], 0.f);
+            rs += (double)((r0 + r1) + (r2 + r3));
+            rss += (double)((r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3));
+        }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void merge(const Mom& o) {
+        mn = fminf(mn, o.mn);
+        mx = fmaxf(mx, o.mx);
+        s += o.s;
+        ss += o.ss;
+        if constexpr (RELU) { rs += o.rs; rss += o.rss; }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void wave_reduce() {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            Mom o;
+            o.mn = shfl_xor_f(mn, m);
+            o.mx = shfl_xor_f(mx, m);
+            o.s = shfl_xor_d(s, m);
+            o.ss = shfl_xor_d(ss, m);
+            if constexpr (RELU) { o.rs = shfl_xor_d(rs, m); o.rss = shfl_xor_d(rss, m); }
+            merge<RELU>(o);
+        }
+    }
+};
+
+template <bool RELU>
+__device__ __forceinline__ void write_mom(double* __restrict__ part, int grp, int C, int ch, const Mom& m,
+                                          double count) {
+    double* p = part + (size_t)grp * CNNQ_NMOM * C + ch;
+    p[(size_t)CNNQ_MOM_MIN * C] = (double)m.mn;
+    p[(size_t)CNNQ_MOM_MAX * C] = (double)m.mx;
+    p[(size_t)CNNQ_MOM_SUM * C] = m.s;
+    p[(size_t)CNNQ_MOM_SUMSQ * C] = m.ss;
+    p[(size_t)CNNQ_MOM_COUNT * C] = count;
+    p[(size_t)CNNQ_MOM_SUM_RELU * C] = RELU ? m.rs : 0.;
+    p[(size_t)CNNQ_MOM_SUMSQ_RELU * C] = RELU ? m.rss : 0.;
+}
+
+template <int VEC, int A, int J, bool RELU, bool NTL>
+__global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, const Geo g,
+                                                 double* __restrict__ part) {
+    constexpr int NE = TPB * J * A;  // LDS entries (one per column, or per element when straddling)
+    __shared__ float l_mn[NE], l_mx[NE];
+    __shared__ double l_s[NE], l_ss[NE];
+    __shared__ double l_rs[RELU ? NE : 1], l_rss[RELU ? NE : 1];
+
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    int col[J];
+    bool ok[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;  // idle slots re-read the block's first column; results discarded
+    }
+    Mom acc[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc[j][a].init();
+
+    const float* row = x + (size_t)b.n0 * (size_t)g.P;
+#pragma unroll 2
+    for (int n = b.n0; n < b.n1; ++n, row += g.P) {
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv_sel<VEC, NTL>(row + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if constexpr (VEC == 4 && A == 1) {
+                acc[j][0].template add4<RELU>(v[j]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[j][A == 1 ? 0 : e].template add<RELU>(v[j][e]);
+            }
+        }
+    }
+
+    const double rows = (double)(b.n1 - b.n0);
+    if (g.mode == 1) {
+        // one channel per workgroup: registers -> wave shuffle -> 4 LDS entries
+        Mom t;
+        t.init();
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (ok[j]) t.template merge<RELU>(acc[j][0]);
+        t.template wave_reduce<RELU>();
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) {
+            l_mn[wv] = t.mn; l_mx[wv] = t.mx; l_s[wv] = t.s; l_ss[wv] = t.ss;
+            if constexpr (RELU) { l_rs[wv] = t.rs; l_rss[wv] = t.rss; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Mom r;
+            r.init();
+            for (int i = 0; i < TPB / 64; ++i) {
+                Mom o;
+                o.mn = l_mn[i]; o.mx = l_mx[i]; o.s = l_s[i]; o.ss = l_ss[i];
+                if constexpr (RELU) { o.rs = l_rs[i]; o.rss = l_rss[i]; }
+                r.template merge<RELU>(o);
+            }
+            write_mom<RELU>(part, b.grp, g.C, b.c0, r, (double)(b.col1 - b.col0) * VEC * rows);
+        }
+        return;
+    }
+    // k whole channels per workgroup: per-column results to LDS, then one wave per channel
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (ok[j]) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int e = (j * TPB + tid) * A + a;
+                l_mn[e] = acc[j][a].mn; l_mx[e] = acc[j][a].mx; l_s[e] = acc[j][a].s; l_ss[e] = acc[j][a].ss;
+                if constexpr (RELU) { l_rs[e] = acc[j][a].rs; l_rss[e] = acc[j][a].rss; }
+            }
+        }
+    }
+    __syncthreads();
+    const int epc = g.HW * A / VEC;  // LDS entries per channel
+    const int wv = tid >> 6, lane = tid & 63;
+    const double count = (double)g.HW * rows;
+    if (epc <= 16) {
+        // tiny rows: one lane per channel, serial over its few entries
+        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
+            const int lo = (ch - b.c0) * epc;
+            Mom r;
+            r.init();
+            for (int e = lo; e < lo + epc; ++e) {
+                Mom o;
+                o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
+                if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
+                r.template merge<RELU>(o);
+            }
+            write_mom<RELU>(part, b.grp, g.C, ch, r, count);
+        }
+        return;
+    }
+    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
+        const int lo = (ch - b.c0) * epc;
+        Mom r;
+        r.init();
+        for (int e = lo + lane; e < lo + epc; e += 64) {
+            Mom o;
+            o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
+            if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
+            r.template merge<RELU>(o);
+        }
+        r.template wave_reduce<RELU>();
+        if (lane == 0) write_mom<RELU>(part, b.grp, g.C, ch, r, count);
+    }
+}
+
+// merge G records per channel; one wave64 per channel, lanes stride over the groups
+__global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part, int G, int C, int has_relu,
+                                                 double* __restrict__ mom, float* __restrict__ stats) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + wv;
+    if (c >= C) return;
+    double mn = INFINITY, mx = -INFINITY, s = 0., ss = 0., cnt = 0., rs = 0., rss = 0.;
+    for (int gi = lane; gi < G; gi += 64) {
+        const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
+        mn = fmin(mn, p[(size_t)CNNQ_MOM_MIN * C]);
+        mx = fmax(mx, p[(size_t)CNNQ_MOM_MAX * C]);
+        s += p[(size_t)CNNQ_MOM_SUM * C];
+        ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
+        cnt += p[(size_t)CNNQ_MOM_COUNT * C];
+        if (has_relu) {
+            rs += p[(size_t)CNNQ_MOM_SUM_RELU * C];
+            rss += p[(size_t)CNNQ_MOM_SUMSQ_RELU * C];
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mn = fmin(mn, shfl_xor_d(mn, m));
+        mx = fmax(mx, shfl_xor_d(mx, m));
+        s += shfl_xor_d(s, m);
+        ss += shfl_xor_d(ss, m);
+        cnt += shfl_xor_d(cnt, m);
+        rs += shfl_xor_d(rs, m);
+        rss += shfl_xor_d(rss, m);
+    }
+    if (lane != 0) return;
+    if (mom) {
+        mom[(size_t)CNNQ_MOM_MIN * C + c] = mn;
+        mom[(size_t)CNNQ_MOM_MAX * C + c] = mx;
+        mom[(size_t)CNNQ_MOM_SUM * C + c] = s;
+        mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = ss;
+        mom[(size_t)CNNQ_MOM_COUNT * C + c] = cnt;
+        mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = rs;
+        mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = rss;
+    }
+    if (stats) {
+        const double mean = s / cnt;
+        double var = (ss - s * mean) / (cnt - 1.);
+        if (var < 0.) var = 0.;
+        stats[(size_t)CNNQ_STAT_MIN * C + c] = (float)mn;
+        stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)mx;
+        stats[(size_t)CNNQ_STAT_MEAN * C + c] = (float)mean;
+        stats[(size_t)CNNQ_STAT_STD * C + c] = (float)sqrt(var);
+        if (has_relu) {
+            double rv = (rss - rs * (rs / cnt)) / (cnt - 1.);
+            if (rv < 0.) rv = 0.;
+            stats[(size_t)CNNQ_STAT_STD_POS * C + c] = (float)sqrt(rv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass B: sum |x - mean| and sum ((x - mean)/std)^4 per channel
+// ------------------------------------------------------------------------------------------
+template <int VEC, int A, int J, bool KURT, bool NTL>
+__global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, const Geo g,
+                                                const float* __restrict__ stats, double* __restrict__ part2) {
+    constexpr int NE = TPB * J * A;
+    __shared__ double l_a[NE];
+    __shared__ double l_k[KURT ? NE : 1];
+    __shared__ float sh_mean[MAXCH], sh_std[MAXCH];
+
+    const Blk b = blk_of<VEC>(g);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+        sh_mean[i] = stats[(size_t)CNNQ_STAT_MEAN * g.C + b.c0 + i];
+        sh_std[i] = stats[(size_t)CNNQ_STAT_STD * g.C + b.c0 + i];
+    }
+    __syncthreads();
+    int col[J];
+    bool ok[J];
+    float mean[J][A], sd[J][A];
+    double sa[J][A], sk[J][A];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = b.col0 + j * TPB + tid;
+        ok[j] = c < b.col1;
+        col[j] = ok[j] ? c : b.col0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+            mean[j][a] = sh_mean[ch];
+            sd[j][a] = KURT ? 1.f / sh_std[ch] : 0.f;   // reciprocal of the standard deviation
+            sa[j][a] = 0.;
+            sk[j][a] = 0.;
+        }
+    }
+    const int nrows = b.n1 - b.n0;
+#pragma unroll 2
+    for (int r = 0; r < nrows; ++r) {
+        // pass B follows pass A over the same tensor: walking it backwards (g.rev) re-reads what
+        // pass A touched last from the Infinity Cache
+        const float* row = x + (size_t)(g.rev ? b.n1 - 1 - r : b.n0 + r) * (size_t)g.P;
+        float v[J][VEC];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ldv_sel<VEC, NTL>(row + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                const float d = v[j][e] - mean[j][a];
+                sa[j][a] += (double)fabsf(d);
+                if constexpr (KURT) {
+                    // (x - mean) * (1/std): one rounding more than the reference's division (<= 1 ulp in
+                    // z, 2.4e-7 relative in z^4) - far inside the sensitivity of kurtosis to the last bit
+                    // of the fp32 mean (see tests), and it removes a 10-instruction divide per element
+                    const float z = d * sd[j][a];
+                    const float z2 = z * z;
+                    sk[j][a] += (double)(z2 * z2);
+                }
+            }
+    }
+    auto emit = [&](int ch, double ta, double tk) {
+        double* p = part2 + (size_t)b.grp * CNNQ_NDEV * g.C + ch;
+        p[(size_t)CNNQ_DEV_ABS * g.C] = ta;
+        p[(size_t)CNNQ_DEV_Z4 * g.C] = KURT ? tk : 0.;
+    };
+    const int wv = tid >> 6, lane = tid & 63;
+    if (g.mode == 1) {
+        double ta = 0., tk = 0.;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (ok[j]) { ta += sa[j][0]; tk += sk[j][0]; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { ta += shfl_xor_d(ta, m); tk += shfl_xor_d(tk, m); }
+        if (lane == 0) { l_a[wv] = ta; if constexpr (KURT) l_k[wv] = tk; }
+        __syncthreads();
+        if (tid == 0) {
+            double ra = 0., rk = 0.;
+            for (int i = 0; i < TPB / 64; ++i) { ra += l_a[i]; if constexpr (KURT) rk += l_k[i]; }
+            emit(b.c0, ra, rk);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int e = (j * TPB + tid) * A + a;
+                l_a[e] = sa[j][a];
+                if constexpr (KURT) l_k[e] = sk[j][a];
+            }
+        }
+    __syncthreads();
+    const int epc = g.HW * A / VEC;
+    if (epc <= 16) {
+        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
+            const int lo = (ch - b.c0) * epc;
+            double ra = 0., rk = 0.;
+            for (int e = lo; e < lo + epc; ++e) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
+            emit(ch, ra, rk);
+        }
+        return;
+    }
+    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
+        const int lo = (ch - b.c0) * epc;
+        double ra = 0., rk = 0.;
+        for (int e = lo + lane; e < lo + epc; e += 64) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { ra += shfl_xor_d(ra, m); rk += shfl_xor_d(rk, m); }
+        if (lane == 0) emit(ch, ra, rk);
+    }
+}
+
+__global__ void __launch_bounds__(TPB) k_combine_dev(const double* __restrict__ part2, int G, int C,
+                                                     const double* __restrict__ mom, int want_kurt,
+                                                     double* __restrict__ dev_out, float* __restrict__ stats) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + wv;
+    if (c >= C) return;
+    double sa = 0., sk = 0.;
+    for (int gi = lane; gi < G; gi += 64) {
+        const double* p = part2 + (size_t)gi * CNNQ_NDEV * C + c;
+        sa += p[(size_t)CNNQ_DEV_ABS * C];
+        sk += p[(size_t)CNNQ_DEV_Z4 * C];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { sa += shfl_xor_d(sa, m); sk += shfl_xor_d(sk, m); }
+    if (lane != 0) return;
+    if (dev_out) {
+        dev_out[(size_t)CNNQ_DEV_ABS * C + c] = sa;
+        dev_out[(size_t)CNNQ_DEV_Z4 * C + c] = sk;
+    }
+    if (stats) {
+        const double cnt = mom[(size_t)CNNQ_MOM_COUNT * C + c];
+        stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sa / cnt);
+        if (want_kurt) stats[(size_t)CNNQ_STAT_KURT * C + c] = (float)(sk / cnt - 3.);
+    }
+}
+
+}  // namespace
