@@ -66,7 +66,8 @@ class CnnqError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    # CNNQ_HIP_LIB: development aid - load another build of the same library (kernel experiments)
+    return os.environ.get('CNNQ_HIP_LIB') or _build.LIB
 
 
 def load():

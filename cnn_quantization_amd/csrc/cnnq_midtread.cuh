@@ -212,40 +212,93 @@ __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* _
     const int tid = threadIdx.x;
     const float ftotal = (float)total;
     double e = 0.;
-    for (int i = tid; i < MT_NB + 2; i += PTPB) {
-        const unsigned long long c = hist[i];
-        if (c) { const float pr = (float)c / ftotal; e += (double)(-pr * log2f(pr)); }
+    // 131074 bins through one workgroup: 16 independent loads in flight per thread (a dependent
+    // load per iteration made this kernel 150 us of pure latency); each thread still adds its bins in
+    // ascending order, so the sum is unchanged
+    constexpr int UNR = 16;
+    for (int base = 0; base < MT_NB + 2; base += PTPB * UNR) {
+        unsigned long long c[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = base + u * PTPB + tid;
+            c[u] = i < MT_NB + 2 ? hist[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (c[u]) { const float pr = (float)c[u] / ftotal; e += (double)(-pr * log2f(pr)); }
     }
     // non-integer clamp values: one histogram entry per (channel, bound); equal values are merged.
-    // The pairwise scan runs out of LDS (2*C <= MT_ENT entries), from global memory beyond that.
+    // Entries with hits are compacted (in index order) into an LDS list, then every thread owning a
+    // list entry walks the whole list with broadcast reads, branch-free: the entry represents its value
+    // if no earlier list entry has the same value, and then carries the hits of all equal entries.
+    // (2*C <= MT_ENT entries; beyond that a plain global-memory scan.)
     const unsigned long long* cl = hist + MT_NB + 2;
     constexpr int MT_ENT = 4096;
-    __shared__ float sv[MT_ENT];
-    __shared__ unsigned sc[MT_ENT];
+    __shared__ float lv[MT_ENT];
+    __shared__ unsigned long long lc[MT_ENT];
+    __shared__ int wcnt[PTPB / 64];
     const int n2 = 2 * C;
-    const bool in_lds = n2 <= MT_ENT;
-    if (in_lds) {
+    auto val = [&](int i) -> float {
+        return mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
+    };
+    if (n2 <= MT_ENT) {
+        const int wv = tid >> 6, lane = tid & 63;
+        const int seg = ((n2 + PTPB - 1) / PTPB) * 64;        // entries per wave, whole 64-lane steps
+        int mine = 0;
+        for (int k = 0; k < seg; k += 64) {
+            const int i = wv * seg + k + lane;
+            mine += __popcll(__ballot(i < n2 && cl[i] != 0ull));
+        }
+        if (lane == 0) wcnt[wv] = mine;
+        __syncthreads();
+        int base = 0, nl = 0;
+        for (int w = 0; w < PTPB / 64; ++w) {
+            if (w < wv) base += wcnt[w];
+            nl += wcnt[w];
+        }
+        for (int k = 0; k < seg; k += 64) {
+            const int i = wv * seg + k + lane;
+            const unsigned long long c = i < n2 ? cl[i] : 0ull;
+            const unsigned long long mask = __ballot(c != 0ull);
+            if (c) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                lv[pos] = val(i);
+                lc[pos] = c;
+            }
+            base += __popcll(mask);
+        }
+        __syncthreads();
+        for (int m0 = tid; m0 < nl; m0 += PTPB) {
+            const float vi = lv[m0];
+            unsigned long long cnt = 0;
+            bool dup = false;
+#pragma unroll 8
+            for (int m = 0; m < nl; ++m) {
+                const bool same = lv[m] == vi;
+                cnt += same ? lc[m] : 0ull;
+                dup |= same && m < m0;
+            }
+            if (!dup) {
+                const float pr = (float)cnt / ftotal;
+                e += (double)(-pr * log2f(pr));
+            }
+        }
+    } else {
         for (int i = tid; i < n2; i += PTPB) {
-            sv[i] = mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
-            sc[i] = (unsigned)cl[i];
+            const unsigned long long ci = cl[i];
+            if (!ci) continue;
+            const float vi = val(i);
+            bool dup = false;
+            unsigned long long cnt = ci;
+            for (int j = 0; j < n2; ++j) {
+                const unsigned long long cj = cl[j];
+                if (j == i || !cj) continue;
+                if (val(j) == vi) { if (j < i) { dup = true; break; } cnt += cj; }
+            }
+            if (dup) continue;
+            const float pr = (float)cnt / ftotal;
+            e += (double)(-pr * log2f(pr));
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < n2; i += PTPB) {
-        const unsigned long long ci = in_lds ? sc[i] : cl[i];
-        if (!ci) continue;
-        const float vi = in_lds ? sv[i] : mt[(size_t)(i < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (i < C ? i : i - C)];
-        bool dup = false;
-        unsigned long long cnt = ci;
-        for (int j = 0; j < n2; ++j) {
-            const unsigned long long cj = in_lds ? sc[j] : cl[j];
-            if (j == i || !cj) continue;
-            const float vj = in_lds ? sv[j] : mt[(size_t)(j < C ? CNNQ_MT_CMIN : CNNQ_MT_CMAX) * C + (j < C ? j : j - C)];
-            if (vj == vi) { if (j < i) { dup = true; break; } cnt += cj; }
-        }
-        if (dup) continue;
-        const float pr = (float)cnt / ftotal;
-        e += (double)(-pr * log2f(pr));
     }
     const double r = block_sum(e, sh);
     if (tid == 0) out[0] = (float)r;

@@ -49,6 +49,10 @@ def test_argument_validation_needs_no_device():
     assert lib.cnnq_pc_moments(None, 1, 1, 1, 0, None, None) == -1
     assert lib.cnnq_pc_qdq(None, None, 1, 1, 1, None, None, None, 0, None) == -1
     assert lib.cnnq_pt_qdq(None, None, 0, None, None, None) == -1
+    assert lib.cnnq_kld_hist(None, 1, 1, None, None, None) == -1
+    assert lib.cnnq_kld_hist(8, 70000, 16, 8, 8, None) == -2         # rows beyond the grid's y extent
+    assert lib.cnnq_kld_hist(8, 4, 1 << 31, 8, 8, None) == -2        # row length >= 2^31
+    assert lib.cnnq_kld_search(None, 1, None, None, None, None) == -1
     with pytest.raises(L.CnnqError):
         L.check(-2, 'x')
 
