@@ -129,7 +129,8 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg, fl
     if (cfg->num_bits < 1 || cfg->num_bits > 8 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
     if (cfg->bit_alloc && cfg->num_bits <= 4 && !diag) return CNNQ_EINVAL;  // bit table lives in diag
     float* bits_ws = diag ? diag + (size_t)CNNQ_DIAG_BITS * C : nullptr;
-    hipLaunchKernelGGL(k_params, dim3(1), dim3(PTPB), 0, (hipStream_t)stream, stats, (int)C, *cfg, qp, diag,
+    const int threads = (int)(C >= PTPB ? PTPB : ((C + 63) / 64) * 64);
+    hipLaunchKernelGGL(k_params, dim3(1), dim3(threads), 0, (hipStream_t)stream, stats, (int)C, *cfg, qp, diag,
                        bits_ws);
     return launch_status();
 }

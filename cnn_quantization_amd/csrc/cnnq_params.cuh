@@ -10,6 +10,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int PTPB = 1024;
 
+// sum over the workgroup (blockDim.x a multiple of 64, <= PTPB); every thread gets the result
 __device__ __forceinline__ double block_sum(double v, double* sh) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -18,7 +19,8 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     if (lane == 0) sh[wv] = v;
     __syncthreads();
     double r = 0.;
-    for (int i = 0; i < PTPB / 64; ++i) r += sh[i];
+    const int nw = (int)(blockDim.x >> 6);
+    for (int i = 0; i < nw; ++i) r += sh[i];
     return r;
 }
 
@@ -32,6 +34,7 @@ __global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats
                                                  float* __restrict__ bits_ws) {
     __shared__ double sh[PTPB / 64];
     const int tid = threadIdx.x;
+    const int T = (int)blockDim.x;   // min(1024, C rounded up to whole waves): small layers skip idle waves
     const float* vmin = stats + (size_t)CNNQ_STAT_MIN * C;
     const float* vmax = stats + (size_t)CNNQ_STAT_MAX * C;
     const float* vmean = stats + (size_t)CNNQ_STAT_MEAN * C;
@@ -45,19 +48,40 @@ __global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats
         const float goal = (float)cfg.target;
         double target = cfg.target;
         double delta = 1.;
-        // p = prior^(2/3) and its sum do not change between iterations
+        // p = prior^(2/3) and its sum do not change between iterations: the first PK per thread stay in
+        // registers (C <= PK * 1024 covers every CNN layer), the rest are recomputed
+        constexpr int PK = 4;
+        float pc[PK];
         double psum_d = 0.;
-        for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(prior[c], (float)(2. / 3));
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            const int c = tid + k * T;
+            pc[k] = c < C ? powf(prior[c], (float)(2. / 3)) : 0.f;
+            if (c < C) psum_d += (double)pc[k];
+        }
+        for (int c = tid + PK * T; c < C; c += T) psum_d += (double)powf(prior[c], (float)(2. / 3));
         const float psum = (float)block_sum(psum_d, sh);
+        auto bits_of = [&](float B, float p) -> float {
+            const float bins = (B * p) / psum;
+            float bits = cfg.round_mode ? rintf(log2f(bins)) : ceilf(log2f(bins));
+            if (bits < 0.f) bits = 0.f;
+            if (bits > 8.f) bits = 8.f;
+            return bits;
+        };
+        float bk[PK];
         for (int it = 0; it < 10 && fabs(2. * delta) > 0.01; ++it) {
-            const float B = (float)((double)C * pow(2., target));
+            // C * 2**target (iq.py:383): exp2 instead of the generic pow - both are within an ulp of the
+            // double result, which is then rounded to float
+            const float B = (float)((double)C * exp2(target));
             double bsum = 0.;
-            for (int c = tid; c < C; c += PTPB) {
-                const float p = powf(prior[c], (float)(2. / 3));
-                const float bins = (B * p) / psum;
-                float bits = cfg.round_mode ? rintf(log2f(bins)) : ceilf(log2f(bins));
-                if (bits < 0.f) bits = 0.f;
-                if (bits > 8.f) bits = 8.f;
+#pragma unroll
+            for (int k = 0; k < PK; ++k) {
+                if (k * T >= C) break;                         // uniform: slots no thread uses
+                bk[k] = bits_of(B, pc[k]);
+                if (tid + k * T < C) bsum += (double)bk[k];
+            }
+            for (int c = tid + PK * T; c < C; c += T) {
+                const float bits = bits_of(B, powf(prior[c], (float)(2. / 3)));
                 bits_ws[c] = bits;
                 bsum += (double)bits;
             }
@@ -65,9 +89,12 @@ __global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats
             delta = (double)((goal - mean_bits) / 2.f);
             target += delta;
         }
+#pragma unroll
+        for (int k = 0; k < PK; ++k)
+            if (tid + k * T < C) bits_ws[tid + k * T] = bk[k];
         __syncthreads();
     }
-    for (int c = tid; c < C; c += PTPB) {
+    for (int c = tid; c < C; c += T) {
         const float bits = ba ? bits_ws[c] : (float)cfg.num_bits;
         float alpha = 0.f, delta, offset;
         if (cfg.clip == 0) {
