@@ -412,6 +412,18 @@ def test_act_bias_correction_vs_oracle(ops, shape, relu_first):
     assert torch.equal(out == 0, ref == 0)
 
 
+@pytest.mark.parametrize('name', ['relu_first', 'full_range', 'one_channel_dead'])
+def test_act_bias_correction_golden(ops, golden, name):
+    """iqm.py:188-196 against tensors recorded from the reference's Conv2dWithId.forward (incl. a channel
+    without any positive element: count 0 -> bias = sum / 1e-8).  Sums are fp64 here, fp32 in torch."""
+    g = golden('bca')
+    ref = g.np(name + '/corrected')
+    out = ops.act_bias_correction_(dev(g.t(name + '/out')), dev(g.t(name + '/out_q')).clone(),
+                                   bool(g.np(name + '/relu_first'))).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-5)
+    assert np.array_equal(out == 0, ref == 0)
+
+
 # --------------------------------------------------------------------------- edge cases, config 2 end to end
 @pytest.mark.parametrize('shape', [(1, 3, 5, 5), (7, 1, 9, 9), (2, 4097, 1, 5), (3, 5, 1, 1), (1, 1, 1, 2), (2, 300, 7, 7),
                                    (9, 17, 13, 11), (1, 64, 112, 112)])

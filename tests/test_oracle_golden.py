@@ -150,3 +150,11 @@ def test_float2gemmlowp_restatement_vs_torch_path():
     t = torch.tensor([0.5, 1.5, 2.5, 3.5, -0.5])
     assert O.float2gemmlowp(t, 255., 0., 8, False, False).tolist() == [1., 2., 3., 4., 0.]
     assert O.qdq_core(t, torch.tensor(255.), torch.tensor(0.), num_bits=8).tolist() == [0., 2., 2., 4., 0.]
+
+
+@pytest.mark.parametrize('name', ['relu_first', 'full_range', 'one_channel_dead'])
+def test_act_bias_correction(golden, name):
+    """Row a12 against the reference's Conv2dWithId.forward (tests/golden/make_golden_bca.py)."""
+    g = golden('bca')
+    got = O.act_bias_correction(g.t(name + '/out'), g.t(name + '/out_q').clone(), bool(g.np(name + '/relu_first')))
+    assert bits_equal(got.numpy(), g.np(name + '/corrected'))
