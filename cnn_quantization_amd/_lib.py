@@ -46,6 +46,8 @@ SIGNATURES = {
     'cnnq_pc_minmax_qdq': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),
     'cnnq_pc_bcorr_sums': (_I, [_P, _P, _L, _L, _L, _I, _P, _P]),
+    'cnnq_pc_qdq_bcorr_sums': (_I, [_P, _L, _L, _L, _P, _I, _P, _P]),
+    'cnnq_pc_qdq_bcorr': (_I, [_P, _P, _L, _L, _L, _P, _P, _I, _P]),
     'cnnq_pc_bcorr_bias': (_I, [_P, _I, _L, _P, _P, _P]),
     'cnnq_pc_bcorr_apply': (_I, [_P, _L, _L, _L, _P, _P]),
     'cnnq_pc_midtread_params': (_I, [_P, _L, ctypes.c_double, _I, _I, _P, _I, _P, _P]),

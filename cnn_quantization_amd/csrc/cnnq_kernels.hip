@@ -247,15 +247,55 @@ int cnnq_pc_bcorr_sums(const float* x, const float* y, int64_t N, int64_t C, int
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_BS(VEC, A, J) hipLaunchKernelGGL((k_bcorr_sums<VEC, A, J>), grid, block, 0, st, x, y, g, relu_first, part3)
+#define LAUNCH_BS(VEC, A, J) \
+    hipLaunchKernelGGL((k_bcorr_sums<VEC, A, J, false, false>), grid, block, 0, st, x, y, g, relu_first, nullptr, part3)
     CNNQ_DISPATCH(v, LAUNCH_BS);
 #undef LAUNCH_BS
     return launch_status();
 }
 
+int cnnq_pc_qdq_bcorr_sums(const float* x, int64_t N, int64_t C, int64_t HW, const float* qp, int relu_first,
+                           double* part3, void* stream) {
+    if (!x || !qp || !part3) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, al16(x), 0, &v, &g);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ntl = N * C * HW * 4 > NT_BYTES;
+#define LAUNCH_BS(VEC, A, J)                                                                                          \
+    do {                                                                                                              \
+        if (ntl)                                                                                                      \
+            hipLaunchKernelGGL((k_bcorr_sums<VEC, A, J, true, true>), grid, block, 0, st, x, nullptr, g, relu_first,  \
+                               qp, part3);                                                                            \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_bcorr_sums<VEC, A, J, true, false>), grid, block, 0, st, x, nullptr, g, relu_first, \
+                               qp, part3);                                                                            \
+    } while (0)
+    CNNQ_DISPATCH(v, LAUNCH_BS);
+#undef LAUNCH_BS
+    return launch_status();
+}
+
+int cnnq_pc_qdq_bcorr(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, const float* bias,
+                      int reverse, void* stream) {
+    if (!x || !y || !qp || !bias) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, al16(x) && al16(y), reverse != 0, &v, &g, /*fine=*/1);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_QB(VEC, A, J) hipLaunchKernelGGL((k_qdq_bias<VEC, A, J>), grid, block, 0, st, x, y, g, qp, bias)
+    CNNQ_DISPATCH(v, LAUNCH_QB);
+#undef LAUNCH_QB
+    return launch_status();
+}
+
 int cnnq_pc_bcorr_bias(const double* part3, int G, int64_t C, double* sums, float* bias, void* stream) {
     if (!part3 || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!sums && !bias)) return CNNQ_EINVAL;
-    hipLaunchKernelGGL(k_bcorr_bias, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, part3, G,
+    hipLaunchKernelGGL(k_bcorr_bias, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, (hipStream_t)stream, part3, G,
                        (int)C, sums, bias);
     return launch_status();
 }

@@ -80,7 +80,8 @@ class MeasureStatistics:
 
 
 # --------------------------------------------------------------------------------- patched layers
-def _route(layer, out, out_id, tag, *, shifted=False, half_range=False, collect_tag=None, force_global=False):
+def _route(layer, out, out_id, tag, *, shifted=False, half_range=False, collect_tag=None, force_global=False,
+           bcorr=None):
     """Common tail of every patched layer's forward: collect statistics, or quantize the output
     with (use) / without (no) calibration statistics.  `shifted` reproduces the reference's calls
     that pass (tensor, tag) positionally, leaving the tag in the id slot and the tag empty."""
@@ -94,7 +95,8 @@ def _route(layer, out, out_id, tag, *, shifted=False, half_range=False, collect_
     stat_id = out_id if qm.stats_mode is StatsMode.use_stats else None
     if shifted:
         return qm.quantize_instant(out, tag, stat_id=stat_id, half_range=half_range, verbose=qm.verbose)
-    return qm.quantize_instant(out, out_id, tag, stat_id=stat_id, half_range=half_range, verbose=qm.verbose)
+    return qm.quantize_instant(out, out_id, tag, stat_id=stat_id, half_range=half_range, verbose=qm.verbose,
+                               bcorr=bcorr)
 
 
 class ReLUWithId(nn.ReLU):
@@ -160,12 +162,14 @@ class Conv2dWithId(nn.Conv2d):
             tag = 'activation_classifier' if out.shape[1] == 1000 else 'activation'
             half = hasattr(self, 'before_relu')
             raw = out
+            correct = qm.stats_mode is StatsMode.use_stats and qm.bcorr_act
+            relu_first = half or qm.op_manager.fused_relu
             out = _route(self, raw, act_id, tag, half_range=half,
-                         collect_tag=getattr(self, 'internal_name', act_id))
-            if qm.stats_mode is StatsMode.use_stats and qm.bcorr_act:
-                # iqm.py:180-196: shift the positive outputs so the channel sums match the fp32 ones
-                out = ops.act_bias_correction_(raw, out.contiguous(), half or qm.op_manager.fused_relu,
-                                               group=qm.group)
+                         collect_tag=getattr(self, 'internal_name', act_id), bcorr=relu_first if correct else None)
+            if correct and not qm.op_manager.last_bcorr_fused:
+                # iqm.py:180-196: shift the positive outputs so the channel sums match the fp32 ones (the
+                # per-channel quantizers fold this into their own passes, see IntQuantizer.fuse_bcorr)
+                out = ops.act_bias_correction_(raw, out.contiguous(), relu_first, group=qm.group)
         if qm.measure_stats.enabled:
             qm.measure_stats.save_measure(out, act_id)
         return out
@@ -227,6 +231,7 @@ class TruncationOpManagerInference:
     def __init__(self, args, qparams, group=None):
         self.verbose = False
         self.ignore_ids = []
+        self.last_bcorr_fused = False
         self._orig = {name: getattr(nn, name) for name in _PATCHED}
         qm = qparams.get('qmanager', {}) if isinstance(qparams, dict) else {}
         self.rho_act, self.rho_weight = qm.get('rho_act'), qm.get('rho_weight')
@@ -280,13 +285,24 @@ class TruncationOpManagerInference:
             setattr(nn, name, cls)
 
     def quantize_instant(self, tensor, id, tag="", stat_id=None, half_range=False, override_att=None,
-                         verbose=False):
+                         verbose=False, bcorr=None):
         ignored = stat_id is not None and any(l == stat_id for l in self.ignore_ids)
         q = self.get_quantizer('ignored' if ignored else tag)
         q.half_range = half_range
         if verbose:
             print("Quantize {0:21} | Id - {1:18} | {2:} | {3:}".format(tag, str(stat_id), str(q), str(tensor.device)))
-        return q(tensor, id, tag, stat_id, override_att)
+        # bcorr (not in the reference's signature): the calling layer wants iqm.py:180-196 applied to the
+        # result; quantizers that can fold it into their passes do and report so
+        self.last_bcorr_fused = False
+        if bcorr is None or not hasattr(q, 'fuse_bcorr'):
+            return q(tensor, id, tag, stat_id, override_att)
+        q.fuse_bcorr, q.bcorr_fused = bool(bcorr), False
+        try:
+            res = q(tensor, id, tag, stat_id, override_att)
+            self.last_bcorr_fused = q.bcorr_fused
+        finally:
+            q.fuse_bcorr, q.bcorr_fused = None, False
+        return res
 
 
 # --------------------------------------------------------------------------------- the manager
@@ -364,8 +380,8 @@ class QuantizationManagerInference(metaclass=Singleton):
         return op_manager
 
     def quantize_instant(self, tensor, id, tag="", stat_id=None, half_range=False, override_att=None,
-                         verbose=False):
-        return self.op_manager.quantize_instant(tensor, id, tag, stat_id, half_range, override_att, verbose)
+                         verbose=False, bcorr=None):
+        return self.op_manager.quantize_instant(tensor, id, tag, stat_id, half_range, override_att, verbose, bcorr)
 
     def set_8bit_list(self, ignore_ids):
         self.op_manager.set_8bit_list(ignore_ids)

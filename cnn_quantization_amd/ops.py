@@ -252,27 +252,36 @@ def pt_qdq(x, ptp, noise=None, out=None):
 # ------------------------------------------------------------------------------------- pipelines
 def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False, prior_is_b=False, target=None,
                         round_mode=True, per_channel_dim=1, group=None, want_codes=False, want_parts=False,
-                        stats=None, want_entropy=False, whole_tensor=False, out=None):
+                        stats=None, want_entropy=False, whole_tensor=False, out=None, bcorr=None):
     """The dynamic per-channel hot path end to end: statistics (one or two coalesced reads of
     x) -> parameters (one workgroup) -> fused Q/DQ (one read, one write).  Covers iq.py:409-451
     (clip='no'), iq.py:327-352 (ACIQ) and, with per_channel_dim=0, the weights of iq.py:453-476;
     whole_tensor=True treats the tensor as ONE channel (per-tensor clipping, iq.py:353-357).
     `stats` (optional [NSTAT, C] table, e.g. from a calibration file) replaces the dynamic
     statistics.  group=False: never exchange (replicated data such as weights).
+    bcorr (None, or the relu-first flag): also apply the activation bias correction of iqm.py:180-196,
+    fused into the passes where the parameter table is at hand (qdq_bias_corrected).
     Returns y [, codes] [, entropy (0-dim device tensor)] [, parts].  No host synchronisation."""
     x = _dev_f32(x, 'x')
     N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x, per_channel_dim)
     use_ba = bool(bit_alloc) and num_bits <= 4 and not whole_tensor
     world = 1 if group is False else D.world_size(group)
+    if bcorr is not None and (want_codes or want_entropy or want_parts or whole_tensor or per_channel_dim != 1):
+        raise L.CnnqError('bcorr combines only with the plain per-channel activation Q/DQ')
     if stats is None and clip == 'no' and not use_ba and not whole_tensor:
-        return minmax_qdq_fused(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out,
-                                want_parts=want_parts, group=None if world == 1 else group)
+        res = minmax_qdq_fused(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out,
+                               want_parts=want_parts, group=None if world == 1 else group)
+        if bcorr is not None:
+            res = act_bias_correction_(x, res, bool(bcorr), group=None if group is False else group)
+        return res
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)
         stats, _ = pc_stats(x, N, C, HW, need_b=need_b, group=None if group is False else group,
                             local_only=group is False)
     qp, diag = pc_params(stats, num_bits, positive, clip, use_ba, prior_is_b, target, round_mode,
                          direct_range=whole_tensor)
+    if bcorr is not None:
+        return qdq_bias_corrected(x, N, C, HW, qp, bool(bcorr), group=None if group is False else group, out=out)
     hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
     res = pc_qdq(x, N, C, HW, qp, want_codes, out=out, hist=hist)
     out = list(res) if want_codes else [res]
@@ -322,6 +331,31 @@ def act_bias_correction_(out, out_q, relu_first, group=None):
     L.check(lib.cnnq_pc_bcorr_bias(_ptr(part3), G, C, None, _ptr(bias), _stream(x)), 'cnnq_pc_bcorr_bias')
     L.check(lib.cnnq_pc_bcorr_apply(_ptr(out_q), N, C, HW, _ptr(bias), _stream(x)), 'cnnq_pc_bcorr_apply')
     return out_q
+
+
+def qdq_bias_corrected(x, N, C, HW, qp, relu_first, group=None, out=None):
+    """Q/DQ with the parameter table qp followed by the activation bias correction, without ever
+    storing the uncorrected tensor: one read-only pass over x for the per-channel sums (the quantized
+    value is recomputed on the fly) and one fused quantize+correct pass - 12 B/elem instead of 24, the
+    same floats as pc_qdq + act_bias_correction_."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    y = torch.empty_like(x) if out is None else out
+    G = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+    if G <= 0:
+        L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    part3 = torch.empty((G, 3, C), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_pc_qdq_bcorr_sums(_ptr(x), N, C, HW, _ptr(qp), int(bool(relu_first)), _ptr(part3), _stream(x)),
+            'cnnq_pc_qdq_bcorr_sums')
+    bias = torch.empty(C, dtype=torch.float32, device=x.device)
+    if D.world_size(group) > 1:
+        sums = torch.empty((3, C), dtype=torch.float64, device=x.device)
+        L.check(lib.cnnq_pc_bcorr_bias(_ptr(part3), G, C, _ptr(sums), None, _stream(x)), 'cnnq_pc_bcorr_bias')
+        part3 = D.all_gather_records(sums, group)
+        G = part3.shape[0]
+    L.check(lib.cnnq_pc_bcorr_bias(_ptr(part3), G, C, None, _ptr(bias), _stream(x)), 'cnnq_pc_bcorr_bias')
+    L.check(lib.cnnq_pc_qdq_bcorr(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(bias), 1, _stream(x)), 'cnnq_pc_qdq_bcorr')
+    return y
 
 
 _MT_TABLES = {}

@@ -64,6 +64,11 @@ class IntQuantizer:
         # torch.distributed is initialised, single process otherwise); see distributed.py
         self.group = None
         self._table_cache = {}
+        # activation bias correction hand-off (iqm.py:180-196): a layer that wants its output corrected sets
+        # fuse_bcorr to the relu-first flag before the call; a per-channel path that folds the correction
+        # into its own passes resets it to None and raises bcorr_fused, otherwise the layer corrects after
+        self.fuse_bcorr = None
+        self.bcorr_fused = False
 
     # ------------------------------------------------------------------ dispatch, iq.py:92-122
     def __call__(self, tensor, id, tag="", stat_id=None, override_att=None):
@@ -119,6 +124,13 @@ class IntQuantizer:
             self._table_cache[key] = tab
         return tab
 
+    def _take_bcorr(self):
+        """The pending bias-correction request, if this call can fold it in (no entropy measurement)."""
+        if self.fuse_bcorr is None or self.measure_entropy:
+            return None
+        flag, self.fuse_bcorr, self.bcorr_fused = self.fuse_bcorr, None, True
+        return flag
+
     def _log_entropy(self, id, entropy, meter, weight):
         if entropy is not None and self.logger is not None:
             self.logger.log_metric(id + '.entropy', float(entropy), step='auto', meterId=meter, weight=weight)
@@ -144,7 +156,8 @@ class IntQuantizer:
         out = ops.act_qdq_per_channel(tensor, self.num_bits, positive=self._positive, clip='no',
                                       bit_alloc=self.bit_alloc_act, prior_is_b=prior_b,
                                       target=self.bit_alloc_target_act, round_mode=self.bit_alloc_round,
-                                      group=self.group, stats=table, want_entropy=self.measure_entropy)
+                                      group=self.group, stats=table, want_entropy=self.measure_entropy,
+                                      bcorr=self._take_bcorr())
         if self.measure_entropy:
             out, entropy = out
             self._log_entropy(id, entropy, 'avg.entropy.act', out.numel())
@@ -164,7 +177,8 @@ class IntQuantizer:
             out = ops.act_qdq_per_channel(tensor, self.num_bits, positive=self._positive, clip=clip_type,
                                           bit_alloc=self.bit_alloc_act, prior_is_b=prior_b,
                                           target=self.bit_alloc_target_act, round_mode=self.bit_alloc_round,
-                                          group=self.group, stats=table, want_entropy=self.measure_entropy)
+                                          group=self.group, stats=table, want_entropy=self.measure_entropy,
+                                          bcorr=self._take_bcorr())
             if self.measure_entropy:
                 out, entropy = out
                 self._log_entropy(id, entropy, 'avg.entropy.act', out.numel())

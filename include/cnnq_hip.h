@@ -203,9 +203,17 @@ int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_
  *                        -> part3[G][3][C] fp64 (G = cnnq_pc_groups);
  *   cnnq_pc_bcorr_bias   merges G records (or W ranks' sums) -> sums[3][C] (optional, for the
  *                        cross-rank exchange) and bias[c] = (sum x' - sum y)/(count + 1e-8);
- *   cnnq_pc_bcorr_apply  y += (y > 0) * bias[c], in place. */
+ *   cnnq_pc_bcorr_apply  y += (y > 0) * bias[c], in place.
+ * Fused form for per-channel quantizers with a parameter table qp (12 instead of 24 bytes per element,
+ * the same floats): the quantized value is recomputed from x instead of stored and re-read -
+ *   cnnq_pc_qdq_bcorr_sums  the sums of cnnq_pc_bcorr_sums with y = Q/DQ(x; qp) computed on the fly;
+ *   cnnq_pc_qdq_bcorr       y = q + (q > 0) * bias[c], q = Q/DQ(x; qp) (iq.py:573-592 then iqm.py:196). */
 int cnnq_pc_bcorr_sums(const float* x, const float* y, int64_t N, int64_t C, int64_t HW, int relu_first,
                        double* part3, void* stream);
+int cnnq_pc_qdq_bcorr_sums(const float* x, int64_t N, int64_t C, int64_t HW, const float* qp, int relu_first,
+                           double* part3, void* stream);
+int cnnq_pc_qdq_bcorr(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, const float* bias,
+                      int reverse, void* stream);
 int cnnq_pc_bcorr_bias(const double* part3, int G, int64_t C, double* sums, float* bias, void* stream);
 int cnnq_pc_bcorr_apply(float* y, int64_t N, int64_t C, int64_t HW, const float* bias, void* stream);
 

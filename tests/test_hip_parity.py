@@ -424,6 +424,25 @@ def test_act_bias_correction_golden(ops, golden, name):
     assert np.array_equal(out == 0, ref == 0)
 
 
+@pytest.mark.parametrize('shape', [(4, 8, 7, 7), (3, 20, 14, 14), (2, 5, 33, 31), (6, 64, 56, 56), (5, 300, 7, 7)])
+@pytest.mark.parametrize('relu_first', [False, True])
+@pytest.mark.parametrize('clip', ['no', 'laplace'])
+def test_fused_bias_correction_equals_two_step(ops, shape, relu_first, clip):
+    """qdq_bias_corrected (statistics pass recomputing q + one fused quantize+correct pass) must give the
+    floats of pc_qdq followed by act_bias_correction_ (same sums, same expression)."""
+    gen = torch.Generator().manual_seed(5)
+    x = dev(torch.randn(shape, generator=gen) * 1.7 + 0.3)
+    N, C, HW = shape[0], shape[1], shape[2] * shape[3]
+    stats, _ = ops.pc_stats(x, N, C, HW, need_b=True)
+    qp, _ = ops.pc_params(stats, 4, relu_first, clip, clip != 'no')
+    two = ops.act_bias_correction_(x, ops.pc_qdq(x, N, C, HW, qp), relu_first)
+    one = ops.qdq_bias_corrected(x, N, C, HW, qp, relu_first)
+    assert bits_equal(one.cpu().numpy(), two.cpu().numpy())
+    via = ops.act_qdq_per_channel(x, 4, positive=relu_first, clip=clip, bit_alloc=clip != 'no', stats=stats,
+                                  bcorr=relu_first)
+    assert bits_equal(via.cpu().numpy(), two.cpu().numpy())
+
+
 # --------------------------------------------------------------------------- edge cases, config 2 end to end
 @pytest.mark.parametrize('shape', [(1, 3, 5, 5), (7, 1, 9, 9), (2, 4097, 1, 5), (3, 5, 1, 1), (1, 1, 1, 2), (2, 300, 7, 7),
                                    (9, 17, 13, 11), (1, 64, 112, 112)])
