@@ -73,6 +73,9 @@ def build_parser():
     p.add_argument('--rho_weight', '-rw', default=None, type=float)
     p.add_argument('--no-bn-folding', action='store_true')
     p.add_argument('--verbose', action='store_true')
+    p.add_argument('--graph', action='store_true',
+                   help='also capture the quantized forward into a HIP graph and time its replay (small batches: '
+                        'removes the per-launch host overhead; the library only enqueues kernels, so it is capturable)')
     return p
 
 
@@ -145,7 +148,7 @@ def run(args, quiet=False):
         if args.arch.startswith('resnet'):
             models.mark_before_relu(model)
         model = model.to(dev).eval()
-        if not args.no_bn_folding:
+        if not args.no_bn_folding and args.qtype is not None:   # folded BN layers are skipped by the patched class only
             model_prep.absorb_bn(model)
             qm.bn_folding = True
         qm.quantize_model(model)                     # weights (verbose=True inside, like the reference)
@@ -163,10 +166,34 @@ def run(args, quiet=False):
                 torch.cuda.synchronize()
                 t_fwd.append(time.perf_counter() - t0)
         rows = timer.summary()
+        t_graph = None
+        if args.graph and qm.stats_mode.name != 'collect_stats' and not args.measure_entropy:
+            qm.op_manager.quantize_instant = timer._orig           # no event pairs inside the capture
+            static_x = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                model(static_x)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                static_out = model(static_x)
+            graph.replay()
+            torch.cuda.synchronize()
+            # not asserted equal: MIOpen's convolutions are not run-to-run reproducible on this stack (an fp32
+            # ResNet-50 forward differs from itself by ~1e-8), and quantization amplifies a flipped code
+            graph_diff = float((static_out - out).abs().max())
+            t_graph = 1e9
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                graph.replay()
+                torch.cuda.synchronize()
+                t_graph = min(t_graph, time.perf_counter() - t0)
     act = [r for r in rows if 'conv' in r[0]]
     tot_t = sum(r[4] for r in rows)
     res = dict(rows=rows, quant_seconds=tot_t, forward_seconds=t_fwd[-1], conv_elements=sum(r[3] for r in act),
-               conv_quant_seconds=sum(r[4] for r in act), entropy=logger.averages(),
+               conv_quant_seconds=sum(r[4] for r in act), entropy=logger.averages(), graph_seconds=t_graph, graph_max_abs_diff=graph_diff if t_graph is not None else None,
                output_finite=bool(torch.isfinite(out).all()))
     if not quiet:
         print('%-22s %-22s %-22s %10s %10s %9s' % ('id', 'tag', 'shape', 'Melem', 'us', 'Gelem/s'))
@@ -179,6 +206,10 @@ def run(args, quiet=False):
                                      res['conv_elements'] / res['conv_quant_seconds'] / 1e9))
         else:   # -sm collect: statistics are gathered, nothing is quantized
             print('forward %.2f ms (statistics collection, no quantization)' % (res['forward_seconds'] * 1e3))
+        if t_graph is not None:
+            print('HIP-graph replay of the same forward: %.2f ms (eager %.2f ms); max |logit difference| to the eager '
+                  'run %.3g (MIOpen convolutions are not run-to-run reproducible)' % (
+                      t_graph * 1e3, res['forward_seconds'] * 1e3, res['graph_max_abs_diff']))
         for k, v in res['entropy'].items():
             print('Average bit rate: {} - {}'.format(k, v))
     return res

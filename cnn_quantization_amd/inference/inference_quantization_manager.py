@@ -393,7 +393,7 @@ class QuantizationManagerInference(metaclass=Singleton):
         """Quantize every Conv2d / Linear weight in place (iqm.py:352-393): per-channel Q/DQ (first
         layer, the one with 3 input channels, at 8 bit; Inception's first two convs likewise), then the
         optional variance / bias correction per output channel."""
-        if self.args.stats_mode == 'collect':
+        if self.args.stats_mode == 'collect' or not self.quantize:
             return
         inception = type(model).__name__ == 'Inception3'
         for n, m in model.named_modules():
