@@ -1,0 +1,76 @@
+"""Property-based parity (hypothesis, derandomised so every run draws the same cases): random tensor
+geometries - odd H*W (float4 loads straddling channels), single samples, more channels than a
+workgroup owns, unaligned base pointers - through the config-2 pipeline and the packed / corrected /
+per-tensor variants, against the oracle.  Integer work: bit-exact."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from conftest import bits_equal
+from oracle import quant_oracle as O
+
+pytestmark = pytest.mark.gpu
+CFG = dict(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+shapes = st.tuples(st.integers(1, 6), st.integers(1, 40), st.integers(1, 19), st.integers(1, 19)).filter(
+    lambda s: s[2] * s[3] > 1)
+
+
+def make(shape, seed, offset):
+    g = torch.Generator().manual_seed(seed)
+    n = int(np.prod(shape))
+    base = torch.empty(n + 3).cuda()
+    x = torch.randn(shape, generator=g) * (0.2 + 3 * torch.rand(1, shape[1], 1, 1, generator=g)) \
+        + torch.randn(1, shape[1], 1, 1, generator=g)
+    view = base[offset:offset + n].view(shape)              # offset != 0: base pointer not 16-byte aligned
+    view.copy_(x)
+    return x, view
+
+
+@settings(**CFG)
+@given(shape=shapes, seed=st.integers(0, 2 ** 16), bits=st.sampled_from([2, 3, 4, 8]), half=st.booleans(),
+       offset=st.integers(0, 3))
+def test_cfg2_random_geometry_bit_exact(shape, seed, bits, half, offset):
+    from cnn_quantization_amd import ops
+    x, xd = make(shape, seed, offset)
+    ref = O.act_per_channel_qdq(x, bits, half_range=half)
+    y, codes = ops.act_qdq_per_channel(xd, bits, positive=half, want_codes=True)
+    assert bits_equal(y.cpu().numpy(), ref.numpy())
+    assert int(codes.max()) <= 2 ** bits - 1
+    again = ops.act_qdq_per_channel(xd, bits, positive=half)   # deterministic
+    assert torch.equal(again, y)
+
+
+@settings(**CFG)
+@given(shape=shapes, seed=st.integers(0, 2 ** 16), half=st.booleans())
+def test_pack4_and_bias_correction_random_geometry(shape, seed, half):
+    from cnn_quantization_amd import ops
+    x, xd = make(shape, seed, 0)
+    N, C, HW = shape[0], shape[1], shape[2] * shape[3]
+    stats, _ = ops.pc_stats(xd, N, C, HW)
+    qp, _ = ops.pc_params(stats, 4, half, 'no', False)
+    y = ops.pc_qdq(xd, N, C, HW, qp)
+    if HW % 4 == 0:
+        packed = ops.quantize_pack4(xd, qp)
+        assert torch.equal(ops.dequantize_pack4(packed, tuple(shape), qp), y)
+    two = ops.act_bias_correction_(xd, y.clone(), half)
+    one = ops.qdq_bias_corrected(xd, N, C, HW, qp, half)
+    assert bits_equal(one.cpu().numpy(), two.cpu().numpy())
+    ref = O.act_bias_correction(x, O.act_per_channel_qdq(x, 4, half_range=half), half)
+    # the bias is a difference of two nearly equal channel sums: torch's fp32 reductions (the oracle) carry
+    # ~1e-7 * sum|x| of error into it, the fp64 sums here do not - hence the wider absolute allowance
+    np.testing.assert_allclose(one.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+
+
+@settings(**CFG)
+@given(n=st.integers(1, 5000), seed=st.integers(0, 2 ** 16), bits=st.sampled_from([4, 8]), etz=st.booleans(),
+       rng=st.floats(0.05, 9.0), off=st.floats(-5.0, 1.0))
+def test_float2gemmlowp_random(n, seed, bits, etz, rng, off):
+    from cnn_quantization_amd import int_quantization
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, generator=g) * 2
+    ref = O.float2gemmlowp(x, rng, off, bits, False, etz)
+    out = int_quantization.float2gemmlowp(x.cuda(), rng, off, bits, False, etz, None)
+    assert bits_equal(out.cpu(), ref)
