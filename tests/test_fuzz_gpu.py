@@ -74,3 +74,43 @@ def test_float2gemmlowp_random(n, seed, bits, etz, rng, off):
     ref = O.float2gemmlowp(x, rng, off, bits, False, etz)
     out = int_quantization.float2gemmlowp(x.cuda(), rng, off, bits, False, etz, None)
     assert bits_equal(out.cpu(), ref)
+
+
+@settings(**CFG)
+@given(shape=shapes.filter(lambda s: s[0] * s[2] * s[3] >= 4), seed=st.integers(0, 2 ** 16), offset=st.integers(0, 3))
+def test_statistics_random_geometry(shape, seed, offset):
+    """The seven collect-mode statistics (both reduction passes, relu sums, kurtosis) on random geometry."""
+    from cnn_quantization_amd import _lib as L
+    from cnn_quantization_amd import ops
+    x, xd = make(shape, seed, offset)
+    ref = O.collect_stats_perchannel(x)
+    st_, _ = ops.pc_stats(xd, shape[0], shape[1], shape[2] * shape[3], need_b=True, need_kurt=True, need_relu=True)
+    st_ = st_.cpu()
+    assert bits_equal(st_[L.STAT_MIN], ref['min']) and bits_equal(st_[L.STAT_MAX], ref['max'])
+    for row, name in ((L.STAT_MEAN, 'mean'), (L.STAT_STD, 'std'), (L.STAT_B, 'b'), (L.STAT_STD_POS, 'std_pos')):
+        np.testing.assert_allclose(st_[row], ref[name], rtol=1e-5, atol=4e-6, err_msg=name)
+    ok = np.isfinite(ref['kurtosis'].numpy())
+    np.testing.assert_allclose(st_[L.STAT_KURT].numpy()[ok], ref['kurtosis'].numpy()[ok], rtol=2e-3, atol=2e-3,
+                               err_msg='kurtosis')
+
+
+@settings(**CFG)
+@given(shape=shapes.filter(lambda s: s[0] * s[2] * s[3] >= 8), seed=st.integers(0, 2 ** 16), half=st.booleans(),
+       clip=st.sampled_from(['laplace', 'gaus']), ba=st.booleans())
+def test_aciq_bit_exact_given_oracle_stats_random_geometry(shape, seed, half, clip, ba):
+    """ACIQ clipping (+ bit allocation) with the oracle's statistics injected: parameters, codes and floats
+    must then be bit-identical for any geometry."""
+    from cnn_quantization_amd import _lib as L
+    from cnn_quantization_amd import ops
+    x, xd = make(shape, seed, 0)
+    C = shape[1]
+    st_ = O.act_stats_perchannel(x, ['min', 'max', 'b', 'std'])
+    st_['mean'] = O.act_stats_perchannel(x, ['mean'], avg_over_batch=True)['mean']     # iq.py:335
+    if not all(bool(torch.isfinite(v).all()) for v in st_.values()) or not bool((st_['b'] > 0).all()):
+        return
+    table = torch.zeros(L.NSTAT, C)
+    for row, nm in ((L.STAT_MIN, 'min'), (L.STAT_MAX, 'max'), (L.STAT_MEAN, 'mean'), (L.STAT_B, 'b'), (L.STAT_STD, 'std')):
+        table[row] = st_[nm]
+    ref = O.act_clipping_qdq(x, 4, clip, half_range=half, bit_alloc_act=ba)
+    y = ops.act_qdq_per_channel(xd, 4, positive=half, clip=clip, bit_alloc=ba, stats=table.cuda())
+    assert bits_equal(y.cpu().numpy(), ref.numpy())
