@@ -135,16 +135,29 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg, fl
     return launch_status();
 }
 
-int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, uint8_t* codes,
-                uint64_t* hist, int reverse, void* stream) {
-    if (!x || !y || !qp) return CNNQ_EINVAL;
+// channel-slice views: `sample_stride` floats between consecutive samples (>= C*HW; 0 = contiguous).  The
+// kernels only ever use the plane size as that stride, so a slice x[:, c0:c1] of a wider NCHW tensor is just
+// (x + c0*HW, C = c1 - c0, sample_stride = C_total*HW).
+static int strided_ok(int64_t C, int64_t HW, int64_t sample_stride) {
+    return sample_stride == 0 || (sample_stride >= C * HW && sample_stride < ((int64_t)1 << 31));
+}
+
+int cnnq_pc_qdq_strided(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int64_t sample_stride,
+                        const float* qp, uint8_t* codes, uint64_t* hist, int reverse, void* stream) {
+    if (!x || !y || !qp || !strided_ok(C, HW, sample_stride)) return CNNQ_EINVAL;
     Variant v;
     Geo g;
+    const bool al = al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0) && sample_stride % 4 == 0;
     // the histogram variant zeroes and flushes an LDS table per workgroup: keep its workgroups long
-    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || ((uintptr_t)codes & 3) == 0), reverse ? 1 : 0, &v,
-                        &g, /*fine=*/hist ? 0 : 1);
+    const int rc = plan(N, C, HW, al, reverse ? 1 : 0, &v, &g, /*fine=*/hist ? 0 : 1);
     if (rc) return rc;
+    if (sample_stride) g.P = (int)sample_stride;
     return launch_qdq(x, y, g, v, qp, codes, reinterpret_cast<unsigned long long*>(hist), (hipStream_t)stream);
+}
+
+int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, uint8_t* codes,
+                uint64_t* hist, int reverse, void* stream) {
+    return cnnq_pc_qdq_strided(x, y, N, C, HW, 0, qp, codes, hist, reverse, stream);
 }
 
 int cnnq_pc_quantize_pack4(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
@@ -179,12 +192,14 @@ int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t
     return launch_status();
 }
 
-int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream) {
-    if (!x || !pmm) return CNNQ_EINVAL;
+int cnnq_pc_minmax_strided(const float* x, int64_t N, int64_t C, int64_t HW, int64_t sample_stride, float* pmm,
+                           void* stream) {
+    if (!x || !pmm || !strided_ok(C, HW, sample_stride)) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-    const int rc = plan(N, C, HW, al16(x), 0, &v, &g);
+    const int rc = plan(N, C, HW, al16(x) && sample_stride % 4 == 0, 0, &v, &g);
     if (rc) return rc;
+    if (sample_stride) g.P = (int)sample_stride;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
     const bool ntl = N * C * HW * 4 > NT_BYTES;
@@ -196,6 +211,10 @@ int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm,
     CNNQ_DISPATCH(v, LAUNCH_MM);
 #undef LAUNCH_MM
     return launch_status();
+}
+
+int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream) {
+    return cnnq_pc_minmax_strided(x, N, C, HW, 0, pmm, stream);
 }
 
 int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* stream) {

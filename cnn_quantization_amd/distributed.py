@@ -50,6 +50,20 @@ def all_gather_records(rec, group=None):
     return out
 
 
+def all_gather_records_async(rec, group=None):
+    """Non-blocking all_gather_records: returns (out [W, K, C], work).  The collective runs on the backend's
+    own stream (RCCL) while the caller keeps enqueuing kernels; `work.wait()` orders the caller's stream
+    behind it."""
+    w = world_size(group)
+    rec = rec.contiguous()
+    out = torch.empty((w,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+    try:
+        work = dist.all_gather_into_tensor(out.view(-1), rec.view(-1), group=group, async_op=True)
+    except RuntimeError:
+        work = dist.all_gather([out[i] for i in range(w)], rec, group=group, async_op=True)
+    return out, work
+
+
 def merge_row_minmax(stats, rows, avg_over_batch, group=None):
     """Per-sample MIN/MAX rows of every rank's shard -> one table whose first two rows list all
     samples of the global batch (equal shard sizes), ready for cnnq_pt_setup."""

@@ -4,6 +4,7 @@ current HIP stream go straight to libcnnq_hip.so.  torch supplies memory and str
 No function here synchronises with the host; none has a CPU path - CPU tensors are rejected
 and a missing library raises (cnn_quantization_amd._lib.load)."""
 import ctypes
+import math
 import os
 
 import torch
@@ -167,6 +168,9 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     if world == 1:
         L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
                                        _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
+    elif (os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') == '1' and C >= 8 and not want_codes and not want_entropy
+          and not want_parts):
+        _minmax_qdq_pipelined(x, y, N, C, HW, num_bits, positive, group)
     else:
         g_used = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
         L.check(lib.cnnq_pc_minmax(_ptr(x), N, C, HW, _ptr(pmm), _stream(x)), 'cnnq_pc_minmax')
@@ -192,6 +196,75 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]
         res.append(dict(stats=stats, qp=qp, diag=None))
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def _slice_ptr(t, c0, HW):
+    return ctypes.c_void_p(t.data_ptr() + 4 * c0 * HW)
+
+
+def _slice_aligned(t, c0, HW, stride):
+    return int((t.data_ptr() + 4 * c0 * HW) % 16 == 0 and stride % 4 == 0)
+
+
+def minmax_qdq_channel_slice(x, c0, c1, num_bits, positive=False, out=None):
+    """Config 2 on the channel slice x[:, c0:c1] of a contiguous NCHW tensor, read and written in place of
+    the parent (no slice copy): e.g. the branches of a concatenated output, each with its own quantizer
+    settings.  Returns `out` (default: a new tensor shaped like x; only the slice is written)."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    N, C, HW = geometry(x)
+    if not 0 <= c0 < c1 <= C:
+        raise L.CnnqError('bad channel slice [%d, %d) of %d' % (c0, c1, C))
+    y = torch.empty_like(x) if out is None else out
+    Cs, stride = c1 - c0, C * HW
+    G = lib.cnnq_pc_groups(N, Cs, HW, _slice_aligned(x, c0, HW, stride))
+    if G <= 0:
+        L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, Cs, HW))
+    pmm = torch.empty((G, 2, Cs), dtype=torch.float32, device=x.device)
+    qp = torch.empty((L.NQP, Cs), dtype=torch.float32, device=x.device)
+    st = _stream(x)
+    L.check(lib.cnnq_pc_minmax_strided(_slice_ptr(x, c0, HW), N, Cs, HW, stride, _ptr(pmm), st), 'cnnq_pc_minmax_strided')
+    L.check(lib.cnnq_pc_minmax_params(_ptr(pmm), G, Cs, int(num_bits), int(bool(positive)), _ptr(qp), st),
+            'cnnq_pc_minmax_params')
+    L.check(lib.cnnq_pc_qdq_strided(_slice_ptr(x, c0, HW), _slice_ptr(y, c0, HW), N, Cs, HW, stride, _ptr(qp), None,
+                                    None, 1, st), 'cnnq_pc_qdq_strided')
+    return y
+
+
+def _minmax_qdq_pipelined(x, y, N, C, HW, num_bits, positive, group):
+    """World size > 1, CNNQ_EXCHANGE_OVERLAP=1: the channels are cut in two halves; while the first half's
+    local extrema travel (RCCL on its own stream) the second half's statistics pass runs, and while the
+    second half's travel the first half is quantized - the exchange latency leaves the critical path.
+    Same arithmetic, hence the same bits as the unsplit path."""
+    lib = L.load()
+    st = _stream(x)
+    world = D.world_size(group)
+    stride = C * HW
+    m = 4 // math.gcd(HW % 4, 4) if HW % 4 else 1       # channels per 16 bytes: keep both halves aligned
+    ca = (C // 2) - (C // 2) % m
+    halves = [(0, ca), (ca, C)]
+    pending = []
+    for c0, c1 in halves:
+        Cs = c1 - c0
+        G = lib.cnnq_pc_groups(N, Cs, HW, _slice_aligned(x, c0, HW, stride))
+        if G <= 0:
+            L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, Cs, HW))
+        pmm = torch.empty((G, 2, Cs), dtype=torch.float32, device=x.device)
+        local = torch.empty((2, Cs), dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_pc_minmax_strided(_slice_ptr(x, c0, HW), N, Cs, HW, stride, _ptr(pmm), st),
+                'cnnq_pc_minmax_strided')
+        L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), G, Cs, _ptr(local), st), 'cnnq_pc_minmax_reduce')
+        pending.append((c0, Cs) + D.all_gather_records_async(local, group))
+    qps = []
+    for c0, Cs, gathered, work in pending:
+        work.wait()
+        qp = torch.empty((L.NQP, Cs), dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_pc_minmax_params(_ptr(gathered), world, Cs, int(num_bits), int(bool(positive)), _ptr(qp), st),
+                'cnnq_pc_minmax_params')
+        L.check(lib.cnnq_pc_qdq_strided(_slice_ptr(x, c0, HW), _slice_ptr(y, c0, HW), N, Cs, HW, stride, _ptr(qp), None,
+                                        None, 1, st), 'cnnq_pc_qdq_strided')
+        qps.append(qp)
+    return torch.cat(qps, dim=1)
 
 
 def quantize_pack4(x, qp):

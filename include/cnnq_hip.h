@@ -186,6 +186,15 @@ int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t
  *                          the gathered [W][2][C] as pmm and G = W -> qdq (exact, so any world size
  *                          gives the bit-identical result of one GPU holding the whole batch). */
 int cnnq_pc_minmax(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* stream);
+/* Channel-slice views of a wider NCHW tensor (x[:, c0:c1]: pass x + c0*HW, C = c1 - c0 and the parent's
+ * sample stride C_total*HW; 0 = contiguous): the same kernels, the plane size only ever served as that
+ * stride.  For a (pointer, stride) pair `aligned16` of cnnq_pc_groups is (x % 16 == 0 && stride % 4 == 0).
+ * Used to quantize concatenated outputs in place and to pipeline the multi-GPU exchange (half the
+ * channels' statistics travel while the other half is being read). */
+int cnnq_pc_minmax_strided(const float* x, int64_t N, int64_t C, int64_t HW, int64_t sample_stride, float* pmm,
+                           void* stream);
+int cnnq_pc_qdq_strided(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int64_t sample_stride,
+                        const float* qp, uint8_t* codes, uint64_t* hist, int reverse, void* stream);
 int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* stream);
 int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int positive, float* qp, void* stream);
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,

@@ -36,6 +36,10 @@ def _worker(rank, world, port, tmp):
         out['cfg2_y_%d' % half], out['cfg2_codes_%d' % half], out['cfg2_ent_%d' % half] = y.cpu(), codes.cpu(), ent.cpu()
     y = ops.act_qdq_per_channel(xs, 4, clip='laplace', bit_alloc=True)
     out['cfg3_y'] = y.cpu()
+    os.environ['CNNQ_EXCHANGE_OVERLAP'] = '1'          # pipelined exchange: two channel halves in flight
+    for half in (False, True):
+        out['cfg2_overlap_y_%d' % half] = ops.act_qdq_per_channel(xs, 4, positive=half).cpu()
+    os.environ['CNNQ_EXCHANGE_OVERLAP'] = '0'
     st, mom = ops.pc_stats(xs, xs.shape[0], xs.shape[1], 14 * 14, need_b=True, need_kurt=True, need_relu=True)
     out['stats'] = st.cpu()
     torch.cuda.synchronize()
@@ -57,6 +61,7 @@ def test_two_ranks_equal_one_gpu(tmp_path):
         y = torch.cat([p['cfg2_y_%d' % half] for p in parts])
         codes = torch.cat([p['cfg2_codes_%d' % half] for p in parts])
         assert torch.equal(y, ref)                                   # bit-identical to the full batch
+        assert torch.equal(torch.cat([p['cfg2_overlap_y_%d' % half] for p in parts]), ref)
         assert torch.equal(codes.float(), rp['codes'])
         ent_ref = O.shannon_entropy(rp['codes'].int())
         for p in parts:                                              # every rank holds the GLOBAL entropy

@@ -443,6 +443,23 @@ def test_fused_bias_correction_equals_two_step(ops, shape, relu_first, clip):
     assert bits_equal(via.cpu().numpy(), two.cpu().numpy())
 
 
+@pytest.mark.parametrize('shape,c0,c1', [((4, 16, 14, 14), 0, 8), ((4, 16, 14, 14), 8, 16), ((3, 10, 7, 7), 4, 8),
+                                         ((3, 10, 7, 7), 3, 10), ((2, 6, 5, 9), 1, 5), ((2, 64, 56, 56), 16, 48)])
+@pytest.mark.parametrize('half', [False, True])
+def test_channel_slice_in_place(ops, shape, c0, c1, half):
+    """Config 2 on x[:, c0:c1] through the strided entry points (pointer offset + parent sample stride, no
+    slice copy) == the same slice quantized as a contiguous tensor; the rest of `out` is untouched."""
+    gen = torch.Generator().manual_seed(9)
+    x = dev(torch.randn(shape, generator=gen) * 2 + 0.1)
+    out = torch.full_like(x, -777.)
+    ops.minmax_qdq_channel_slice(x, c0, c1, 4, positive=half, out=out)
+    ref = ops.act_qdq_per_channel(x[:, c0:c1].contiguous(), 4, positive=half)
+    assert torch.equal(out[:, c0:c1], ref)
+    mask = torch.ones(shape[1], dtype=torch.bool)
+    mask[c0:c1] = False
+    assert bool((out[:, mask.cuda()] == -777.).all())
+
+
 # --------------------------------------------------------------------------- edge cases, config 2 end to end
 @pytest.mark.parametrize('shape', [(1, 3, 5, 5), (7, 1, 9, 9), (2, 4097, 1, 5), (3, 5, 1, 1), (1, 1, 1, 2), (2, 300, 7, 7),
                                    (9, 17, 13, 11), (1, 64, 112, 112)])
