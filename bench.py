@@ -111,7 +111,7 @@ def time_kernel_classes(layers):
     return {'k_minmax': (t_mm, len(recs)), 'k_minmax_params': (t_p, len(recs)), 'k_qdq': (t_q, len(recs))}
 
 
-def cpu_baseline(batch_sample=8, reps=3):
+def cpu_baseline(batch_sample=32, reps=3):
     """The oracle (op-for-op CPU restatement of iq.py:409-451) on the same layer set at a small
     batch: ~10-30 s of CPU work on all host cores."""
     from oracle import quant_oracle as O
