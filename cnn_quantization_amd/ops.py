@@ -26,7 +26,21 @@ def _dev_f32(x, what='tensor'):
         raise L.CnnqError('%s must be a CUDA/HIP tensor (there is no CPU path)' % what)
     if x.dtype != torch.float32:
         raise L.CnnqError('%s must be float32, got %s' % (what, x.dtype))
+    if x.device.index != torch.cuda.current_device():
+        # kernels are enqueued in the calling thread's current device context (one process per GPU is the
+        # deployment model; in-process multi-GPU callers must enter torch.cuda.device(x.device) first)
+        raise L.CnnqError('%s is on %s but the current device is cuda:%d' % (what, x.device, torch.cuda.current_device()))
     return x.detach().contiguous()
+
+
+def _out_like(x, out):
+    """The result buffer: a new tensor like x, or the caller's - which must match x exactly."""
+    if out is None:
+        return torch.empty_like(x)
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+            and out.shape == x.shape and out.device == x.device):
+        raise L.CnnqError('out must be a contiguous float32 tensor on %s shaped like the input' % (x.device,))
+    return out
 
 
 def geometry(x, per_channel_dim=1):
@@ -139,7 +153,7 @@ def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None, reverse=False
     (optional zeroed int64[256] tensor) receives the code histogram; reverse: descending addresses."""
     lib = L.load()
     x = _dev_f32(x, 'x')
-    y = torch.empty_like(x) if out is None else out
+    y = _out_like(x, out)
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
     L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), int(bool(reverse)),
                             _stream(x)), 'cnnq_pc_qdq')
@@ -156,7 +170,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     a single GPU holding the whole batch."""
     lib = L.load()
     x = _dev_f32(x, 'x')
-    y = torch.empty_like(x) if out is None else out
+    y = _out_like(x, out)
     G = max(lib.cnnq_pc_groups(N, C, HW, 1), lib.cnnq_pc_groups(N, C, HW, 0))
     if G <= 0:
         L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
@@ -189,7 +203,6 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     if want_entropy:
         res.append(entropy_from_hist(hist))
     if want_parts:
-        al = x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and (codes is None or codes.data_ptr() % 4 == 0)
         g_used = world if world > 1 else lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
         stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
         stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
@@ -215,7 +228,7 @@ def minmax_qdq_channel_slice(x, c0, c1, num_bits, positive=False, out=None):
     N, C, HW = geometry(x)
     if not 0 <= c0 < c1 <= C:
         raise L.CnnqError('bad channel slice [%d, %d) of %d' % (c0, c1, C))
-    y = torch.empty_like(x) if out is None else out
+    y = _out_like(x, out)
     Cs, stride = c1 - c0, C * HW
     G = lib.cnnq_pc_groups(N, Cs, HW, _slice_aligned(x, c0, HW, stride))
     if G <= 0:
@@ -313,7 +326,7 @@ def pt_setup(device, num_bits, range_offset=None, stats=None, rows=0, rows_mode=
 def pt_qdq(x, ptp, noise=None, out=None):
     lib = L.load()
     x = _dev_f32(x, 'x')
-    y = torch.empty_like(x) if out is None else out
+    y = _out_like(x, out)
     if noise is not None:
         noise = _dev_f32(noise, 'noise')
     if x.numel() == 0:
@@ -413,7 +426,7 @@ def qdq_bias_corrected(x, N, C, HW, qp, relu_first, group=None, out=None):
     same floats as pc_qdq + act_bias_correction_."""
     lib = L.load()
     x = _dev_f32(x, 'x')
-    y = torch.empty_like(x) if out is None else out
+    y = _out_like(x, out)
     G = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
     if G <= 0:
         L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
