@@ -187,6 +187,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
+    from cnn_quantization_amd import distributed as D
+    exchange_name = 'none (1 GPU)' if world == 1 else (
+        'peer-to-peer stores over xGMI (CNNQ_P2P_EXCHANGE=1, verified against the collective)'
+        if D.p2p_exchange(group) is not None else '%s all_gather' % ('RCCL' if backend == 'nccl' else backend))
     value = elems * world * args.steps / dt
 
     # roofline of the dominant kernel (fused Q/DQ), measured live with HIP events on its stream
@@ -205,7 +209,8 @@ def main():
         'config': {'workload': 'ResNet-50 b%d conv activations (53 tensors, %.2f G elements per GPU), per-channel '
                                'int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (args.batch, elems / 1e9),
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
-                   'parallelism': 'batch-sharded dp%d, per-channel stats all_gather' % world},
+                   'parallelism': 'batch-sharded dp%d, per-channel stats all_gather' % world,
+                   'exchange': exchange_name},
         'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
         'roofline': {'bound': 'hbm', 'kernel': 'k_qdq (fused per-channel Q/DQ, 8 algorithmic B/elem)',

@@ -29,6 +29,8 @@
 // Layout: the kernels live in the cnnq_*.cuh files next to this one (one file per stage of the path),
 // all in one anonymous namespace of this single translation unit; below them is the C ABI.
 
+#include <string.h>
+
 #include "cnnq_common.cuh"
 #include "cnnq_stats.cuh"
 #include "cnnq_params.cuh"
@@ -39,6 +41,7 @@
 #include "cnnq_pertensor.cuh"
 #include "cnnq_plan.cuh"
 #include "cnnq_kld.cuh"
+#include "cnnq_p2p.cuh"
 
 extern "C" {
 
@@ -433,6 +436,45 @@ int cnnq_kld_search(const uint32_t* hist, int64_t rows, const float* rowmm, doub
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_kld_search, dim3(KC, (unsigned)rows), dim3(TPB), 0, st, hist, div);
     hipLaunchKernelGGL(k_kld_pick, dim3((unsigned)rows), dim3(64), 0, st, div, rowmm, (int)rows, out);
+    return launch_status();
+}
+
+// ---- peer-to-peer statistics exchange (opt-in; the only entry points that allocate: explicit setup calls) ----
+size_t cnnq_p2p_window_bytes(int world, int slot_floats) {
+    return (world > 0 && slot_floats > 0) ? p2p_window_bytes(world, slot_floats) : 0;
+}
+
+int cnnq_p2p_alloc(int world, int slot_floats, void** window, unsigned char handle[64]) {
+    if (!window || !handle || world <= 0 || slot_floats <= 0) return CNNQ_EINVAL;
+    const size_t bytes = p2p_window_bytes(world, slot_floats);
+    hipError_t e = hipExtMallocWithFlags(window, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(*window, 0, bytes);
+    if (e != hipSuccess) return (int)e;
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, *window);
+    if (e != hipSuccess) return (int)e;
+    memcpy(handle, &h, 64);
+    return (int)hipDeviceSynchronize();
+}
+
+int cnnq_p2p_open(const unsigned char handle[64], void** window) {
+    if (!handle || !window) return CNNQ_EINVAL;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    return (int)hipIpcOpenMemHandle(window, h, hipIpcMemLazyEnablePeerAccess);
+}
+
+int cnnq_p2p_close(void* window) { return window ? (int)hipIpcCloseMemHandle(window) : CNNQ_EINVAL; }
+int cnnq_p2p_free(void* window) { return window ? (int)hipFree(window) : CNNQ_EINVAL; }
+
+int cnnq_p2p_all_gather(const float* rec, int nfloat, void* const* windows, int rank, int world, int slot_floats,
+                        uint32_t seq, float* out, int* status, void* stream) {
+    if (!rec || !windows || !out || !status || nfloat <= 0 || nfloat > slot_floats || world <= 0 || rank < 0 ||
+        rank >= world || !seq)
+        return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_p2p_all_gather, dim3((unsigned)world), dim3(TPB), 0, (hipStream_t)stream, rec, nfloat, windows,
+                       rank, world, slot_floats, seq, out, status);
     return launch_status();
 }
 

@@ -35,7 +35,16 @@ def shard_batch(n, rank_, world):
 
 
 def all_gather_records(rec, group=None):
-    """rec [K, C] on every rank -> [W, K, C] in rank order (the G axis cnnq_pc_combine merges)."""
+    """rec [K, C] on every rank -> [W, K, C] in rank order (the G axis cnnq_pc_combine merges): the verified
+    peer-to-peer exchange when CNNQ_P2P_EXCHANGE=1, otherwise the backend's all_gather."""
+    ex = p2p_exchange(group)
+    if ex is not None and ex.fits(rec):
+        return ex.all_gather(rec)
+    return collective_all_gather(rec, group)
+
+
+def collective_all_gather(rec, group=None):
+    """all_gather_records through torch.distributed (RCCL / gloo)."""
     w = world_size(group)
     rec = rec.contiguous()
     out = torch.empty((w,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
@@ -62,6 +71,114 @@ def all_gather_records_async(rec, group=None):
     except RuntimeError:
         work = dist.all_gather([out[i] for i in range(w)], rec, group=group, async_op=True)
     return out, work
+
+
+class P2PExchange:
+    """One-shot all-gather of small fp32 records over xGMI peer-to-peer stores (cnnq_p2p_*), an opt-in
+    alternative to the RCCL all_gather for the per-layer statistics exchange: one post kernel + one wait
+    kernel on the caller's stream, no collective launch, no stream hop.  One process per GPU, all ranks
+    of `group` on one node.  `verify()` cross-checks it against the group's own all_gather and must be
+    called once before use; on any failure the caller keeps RCCL."""
+    SLOT_FLOATS = 32768                                 # 128 KB: fp64 moment records [7][C] up to C = 2340
+
+    def __init__(self, group=None):
+        import ctypes
+        from . import _lib as L
+        self.group, self.L, self.lib = group, L, L.load()
+        self.world, self.rank = world_size(group), rank(group)
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        own = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        L.check(self.lib.cnnq_p2p_alloc(self.world, self.SLOT_FLOATS, ctypes.byref(own), handle), 'cnnq_p2p_alloc')
+        self.own = own
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=group)
+        self.mapped = []
+        ptrs = []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs.append(own.value)
+                continue
+            w = ctypes.c_void_p()
+            L.check(self.lib.cnnq_p2p_open(ctypes.create_string_buffer(h, 64), ctypes.byref(w)), 'cnnq_p2p_open')
+            self.mapped.append(w)
+            ptrs.append(w.value)
+        self.windows = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.seq = 0
+        dist.barrier(group=group)                       # every window is mapped before anyone posts
+
+    def fits(self, rec):
+        return rec.is_cuda and rec.element_size() % 4 == 0 and rec.numel() * rec.element_size() <= 4 * self.SLOT_FLOATS
+
+    def all_gather(self, rec):
+        """rec [K, C] (fp32 / fp64 / int32 / int64: moved as 32-bit words) on every rank -> [W, K, C] in rank
+        order; enqueued on the current stream."""
+        import ctypes
+        rec = rec.contiguous()
+        if not self.fits(rec):
+            raise self.L.CnnqError('P2PExchange carries device records of at most %d bytes' % (4 * self.SLOT_FLOATS))
+        n = rec.numel() * rec.element_size() // 4
+        out = torch.empty((self.world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+        self.seq += 1
+        st = ctypes.c_void_p(torch.cuda.current_stream(rec.device).cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        self.L.check(self.lib.cnnq_p2p_all_gather(p(rec), n, p(self.windows), self.rank, self.world, self.SLOT_FLOATS,
+                                                  self.seq, p(out), p(self.status), st), 'cnnq_p2p_all_gather')
+        return out
+
+    def healthy(self):
+        """Host check (synchronises): no wait has timed out so far."""
+        return int(self.status.item()) == 0
+
+    def verify(self, rounds=64):
+        """Random records of varying size through both paths; True iff every round matches bit for bit."""
+        g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
+        ok = True
+        for i in range(rounds):
+            c = (1, 7, 64, 256, 2048, 4096)[i % 6]
+            rec = torch.randn((2, c), generator=g, device=self.device)
+            if i % 3 == 2:
+                rec = rec.double()
+            ref = collective_all_gather(rec, self.group)
+            got = self.all_gather(rec)
+            ok = ok and bool(torch.equal(ref, got))
+        ok = ok and self.healthy()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        except RuntimeError:                             # gloo without device tensors
+            cpu = flag.cpu()
+            dist.all_reduce(cpu, op=dist.ReduceOp.MIN, group=self.group)
+            flag = cpu
+        return bool(int(flag.item()))
+
+    def close(self):
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        for w in self.mapped:
+            self.lib.cnnq_p2p_close(w)
+        self.lib.cnnq_p2p_free(self.own)
+        self.mapped, self.own = [], None
+
+
+_P2P = {}
+
+
+def p2p_exchange(group=None):
+    """The process-wide P2PExchange of `group` when CNNQ_P2P_EXCHANGE=1 and it verified; else None (RCCL)."""
+    import os
+    if os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' or world_size(group) == 1:
+        return None
+    key = id(group)
+    if key not in _P2P:
+        try:
+            ex = P2PExchange(group)
+            _P2P[key] = ex if ex.verify() else None
+        except Exception as e:                           # no peer access, IPC refused, ...: keep RCCL
+            print('cnn_quantization_amd: peer-to-peer exchange unavailable (%s); using the collective' % (e,))
+            _P2P[key] = None
+    return _P2P[key]
 
 
 def merge_row_minmax(stats, rows, avg_over_batch, group=None):

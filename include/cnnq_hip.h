@@ -279,6 +279,25 @@ int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const flo
 int cnnq_kld_hist(const float* x, int64_t rows, int64_t len, const float* rowmm, uint32_t* hist, void* stream);
 int cnnq_kld_search(const uint32_t* hist, int64_t rows, const float* rowmm, double* div, double* out, void* stream);
 
+/* Peer-to-peer statistics exchange (opt-in alternative to the RCCL all_gather of SURVEY.md 8e; one process
+ * per GPU, all on one node).  Each rank owns a window of fine-grained uncached device memory holding
+ * slots[2][W][slot_floats] floats + flags[2][W]; peers map it through hipIpc.
+ *   cnnq_p2p_alloc / _open / _close / _free   setup (the only entry points that allocate or synchronise):
+ *                     allocate + zero the own window and export its 64-byte IPC handle; map a peer's window;
+ *   cnnq_p2p_all_gather  exchange number seq (1, 2, ... consecutive): ONE launch of W workgroups - workgroup b
+ *                     writes rec[nfloat] into slot [seq & 1][rank] of rank b's window (`windows`: device array of
+ *                     the W mapped window pointers, own one at [rank]), releases the matching flag at system scope,
+ *                     then acquire-spins on the own window's flag of rank b and copies that record to
+ *                     out[b][nfloat] (out[W][nfloat] is the G axis cnnq_pc_minmax_params / cnnq_pc_combine merge).
+ *                     A spin gives up after 2 s and sets bit 0 of *status (device int) - it never hangs. */
+size_t cnnq_p2p_window_bytes(int world, int slot_floats);
+int cnnq_p2p_alloc(int world, int slot_floats, void** window, unsigned char handle[64]);
+int cnnq_p2p_open(const unsigned char handle[64], void** window);
+int cnnq_p2p_close(void* window);
+int cnnq_p2p_free(void* window);
+int cnnq_p2p_all_gather(const float* rec, int nfloat, void* const* windows, int rank, int world, int slot_floats,
+                        uint32_t seq, float* out, int* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
