@@ -127,3 +127,28 @@ def test_c_restatement_matches_torch_oracle():
         out = torch.empty_like(v)
         lib.oracle_pt_qdq(v.data_ptr(), out.data_ptr(), v.numel(), float(scale_f), float(shift), qmaxf, int(etz))
         assert torch.equal(out, ref), etz
+
+
+def test_header_is_plain_c99_and_a_c_client_links(tmp_path):
+    """include/cnnq_hip.h must be consumable by a C compiler (the boundary is a C ABI), and a plain C program
+    must link against libcnnq_hip.so without any C++ runtime of its own (tests/c/cabi_demo.c; run on the GPU by
+    tests/test_cabi_c_gpu.py)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    inc = os.path.join(ROOT, 'include')
+    src = tmp_path / 't.c'
+    src.write_text('#include "cnnq_hip.h"\nint main(void) { return cnnq_pc_groups(1, 1, 1, 1) > 0 ? 0 : 1; }\n')
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-I', inc, str(src)],
+                   check=True)
+    if not os.path.isdir('/opt/rocm/include/hip'):
+        pytest.skip('no HIP headers')
+    from cnn_quantization_amd import _build
+    _build.build()
+    exe = tmp_path / 'cabi_demo'
+    subprocess.run([gcc, '-std=c99', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I', inc,
+                    os.path.join(ROOT, 'tests', 'c', 'cabi_demo.c'), '-L', os.path.dirname(_build.LIB), '-lcnnq_hip',
+                    '-L/opt/rocm/lib', '-lamdhip64', '-lm', '-o', str(exe)], check=True)
+    assert exe.exists()
