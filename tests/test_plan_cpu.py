@@ -45,8 +45,7 @@ SHAPES = [(512, 64, 112 * 112), (512, 256, 56 * 56), (512, 512, 28 * 28), (512, 
           (1, 1, 25690112), (7, 3, 1), (1, 1, 1), (9, 5, 2), (2, 4097, 5), (3, 2, 1000001)]
 
 
-@pytest.mark.parametrize('shape', SHAPES)
-def test_plans_partition_the_tensor(shape):
+def check_plans(shape):
     N, C, HW = shape
     for aligned, fine in itertools.product((1, 0), (0, 1)):
         p = describe(N, C, HW, aligned, fine)
@@ -82,6 +81,26 @@ def test_plans_partition_the_tensor(shape):
         else:
             per_wg = (N / p['S']) * min(cap, (HW if p['mode'] == 1 else p['k'] * HW)) * 4
             assert per_wg <= 64 * 1024 or p['S'] == N              # short workgroups (about 14 KB)
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_plans_partition_the_tensor(shape):
+    check_plans(shape)
+
+
+def test_plans_partition_random_shapes():
+    """The same partition properties on random geometries (hypothesis, derandomised): odd H*W, channel counts
+    around the workgroup capacity, single samples, planes from a few elements to ~100 K."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(N=st.integers(1, 70), C=st.integers(1, 600),
+           HW=st.one_of(st.integers(1, 64), st.sampled_from([49, 81, 121, 169, 196, 289, 784, 1024, 3136, 12544, 12545])))
+    def run(N, C, HW):
+        if C * HW <= 400000:
+            check_plans((N, C, HW))
+    run()
 
 
 def test_fine_geometry_targets_short_workgroups():
