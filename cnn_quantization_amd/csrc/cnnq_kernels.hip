@@ -163,36 +163,66 @@ int cnnq_pc_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, cons
     return cnnq_pc_qdq_strided(x, y, N, C, HW, 0, qp, codes, hist, reverse, stream);
 }
 
-int cnnq_pc_quantize_pack4(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
-                           void* stream) {
+// stored-format codes: bits = 4 (two per byte) or 8 (one per byte)
+static int quantize_codes(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp, int bits,
+                          void* stream) {
     if (!x || !packed || !qp) return CNNQ_EINVAL;
-    if (HW % 4 != 0 || !al16(x) || ((uintptr_t)packed & 1)) return CNNQ_EINVAL;   // whole float4s per channel row
+    if (HW % 4 != 0 || !al16(x) || ((uintptr_t)packed & (bits == 4 ? 1 : 3))) return CNNQ_EINVAL;   // whole float4s
     Variant v;
     Geo g;
     const int rc = plan(N, C, HW, true, 0, &v, &g, /*fine=*/1);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-    if (v.J == 4) hipLaunchKernelGGL((k_q_pack4<4>), grid, block, 0, st, x, packed, g, qp);
-    else if (v.J == 2) hipLaunchKernelGGL((k_q_pack4<2>), grid, block, 0, st, x, packed, g, qp);
-    else hipLaunchKernelGGL((k_q_pack4<1>), grid, block, 0, st, x, packed, g, qp);
+#define LAUNCH_QP(J)                                                                              \
+    do {                                                                                          \
+        if (bits == 4) hipLaunchKernelGGL((k_q_pack4<J, 4>), grid, block, 0, st, x, packed, g, qp); \
+        else hipLaunchKernelGGL((k_q_pack4<J, 8>), grid, block, 0, st, x, packed, g, qp);           \
+    } while (0)
+    if (v.J == 4) LAUNCH_QP(4);
+    else if (v.J == 2) LAUNCH_QP(2);
+    else LAUNCH_QP(1);
+#undef LAUNCH_QP
     return launch_status();
 }
 
-int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
-                             void* stream) {
+static int dequantize_codes(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp, int bits,
+                            void* stream) {
     if (!packed || !y || !qp) return CNNQ_EINVAL;
-    if (HW % 4 != 0 || !al16(y) || ((uintptr_t)packed & 1)) return CNNQ_EINVAL;
+    if (HW % 4 != 0 || !al16(y) || ((uintptr_t)packed & (bits == 4 ? 1 : 3))) return CNNQ_EINVAL;
     Variant v;
     Geo g;
     const int rc = plan(N, C, HW, true, 0, &v, &g, /*fine=*/1);
     if (rc) return rc;
     const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
     hipStream_t st = (hipStream_t)stream;
-    if (v.J == 4) hipLaunchKernelGGL((k_unpack4_dq<4>), grid, block, 0, st, packed, y, g, qp);
-    else if (v.J == 2) hipLaunchKernelGGL((k_unpack4_dq<2>), grid, block, 0, st, packed, y, g, qp);
-    else hipLaunchKernelGGL((k_unpack4_dq<1>), grid, block, 0, st, packed, y, g, qp);
+#define LAUNCH_UP(J)                                                                                 \
+    do {                                                                                             \
+        if (bits == 4) hipLaunchKernelGGL((k_unpack4_dq<J, 4>), grid, block, 0, st, packed, y, g, qp); \
+        else hipLaunchKernelGGL((k_unpack4_dq<J, 8>), grid, block, 0, st, packed, y, g, qp);           \
+    } while (0)
+    if (v.J == 4) LAUNCH_UP(4);
+    else if (v.J == 2) LAUNCH_UP(2);
+    else LAUNCH_UP(1);
+#undef LAUNCH_UP
     return launch_status();
+}
+
+int cnnq_pc_quantize_pack4(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
+                           void* stream) {
+    return quantize_codes(x, packed, N, C, HW, qp, 4, stream);
+}
+int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                             void* stream) {
+    return dequantize_codes(packed, y, N, C, HW, qp, 4, stream);
+}
+int cnnq_pc_quantize_u8(const float* x, uint8_t* codes, int64_t N, int64_t C, int64_t HW, const float* qp,
+                        void* stream) {
+    return quantize_codes(x, codes, N, C, HW, qp, 8, stream);
+}
+int cnnq_pc_dequantize_u8(const uint8_t* codes, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                          void* stream) {
+    return dequantize_codes(codes, y, N, C, HW, qp, 8, stream);
 }
 
 int cnnq_pc_minmax_strided(const float* x, int64_t N, int64_t C, int64_t HW, int64_t sample_stride, float* pmm,

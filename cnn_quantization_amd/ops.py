@@ -300,6 +300,26 @@ def dequantize_pack4(packed, shape, qp):
     return y
 
 
+def quantize_u8(x, qp):
+    """x [N, C, H, W] + parameter table -> uint8 codes (one byte each, numel bytes): the stored format for
+    quantizations of up to 8 bits."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    N, C, HW = geometry(x)
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    L.check(lib.cnnq_pc_quantize_u8(_ptr(x), _ptr(codes), N, C, HW, _ptr(qp), _stream(x)), 'cnnq_pc_quantize_u8')
+    return codes
+
+
+def dequantize_u8(codes, qp):
+    """Inverse of quantize_u8: the dequantized fp32 tensor (bit-identical to pc_qdq's output)."""
+    lib = L.load()
+    y = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    N, C, HW = geometry(y)
+    L.check(lib.cnnq_pc_dequantize_u8(_ptr(codes), _ptr(y), N, C, HW, _ptr(qp), _stream(y)), 'cnnq_pc_dequantize_u8')
+    return y
+
+
 def entropy_from_hist(hist):
     """Shannon entropy (bits) of an int64 histogram tensor -> 0-dim float32 tensor on the device."""
     lib = L.load()

@@ -172,6 +172,12 @@ int cnnq_pc_quantize_pack4(const float* x, uint8_t* packed, int64_t N, int64_t C
                            void* stream);
 int cnnq_pc_dequantize_pack4(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
                              void* stream);
+/* The same with one byte per code (quantizations of up to 8 bits, e.g. the first layer the reference keeps at
+ * 8 bit, iqm.py:551-555): 4 + 1 bytes per element; `codes` 4-byte aligned, H*W % 4 == 0. */
+int cnnq_pc_quantize_u8(const float* x, uint8_t* codes, int64_t N, int64_t C, int64_t HW, const float* qp,
+                        void* stream);
+int cnnq_pc_dequantize_u8(const uint8_t* codes, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                          void* stream);
 
 /* Config 2 (dynamic per-channel min/max, no clipping, uniform bit width: iq.py:409-451 with
  * bit allocation off) as three launches, two of them streaming:

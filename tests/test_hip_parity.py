@@ -443,6 +443,21 @@ def test_fused_bias_correction_equals_two_step(ops, shape, relu_first, clip):
     assert bits_equal(via.cpu().numpy(), two.cpu().numpy())
 
 
+@pytest.mark.parametrize('shape', [(4, 8, 14, 14), (3, 20, 12, 12), (2, 5, 2, 2), (6, 3, 56, 56), (2, 600, 4, 4)])
+@pytest.mark.parametrize('bits', [8, 5])
+def test_u8_round_trip_equals_fused_qdq(ops, shape, bits):
+    """One byte per code as the stored format: codes == the codes of the fused Q/DQ, dequantized == its floats."""
+    gen = torch.Generator().manual_seed(3)
+    x = dev(torch.randn(shape, generator=gen) * 2 + 0.2)
+    N, C, HW = shape[0], shape[1], shape[2] * shape[3]
+    stats, _ = ops.pc_stats(x, N, C, HW)
+    qp, _ = ops.pc_params(stats, bits, False, 'no', False)
+    y, codes = ops.pc_qdq(x, N, C, HW, qp, want_codes=True)
+    stored = ops.quantize_u8(x, qp)
+    assert torch.equal(stored, codes)
+    assert torch.equal(ops.dequantize_u8(stored, qp), y)
+
+
 @pytest.mark.parametrize('shape,c0,c1', [((4, 16, 14, 14), 0, 8), ((4, 16, 14, 14), 8, 16), ((3, 10, 7, 7), 4, 8),
                                          ((3, 10, 7, 7), 3, 10), ((2, 6, 5, 9), 1, 5), ((2, 64, 56, 56), 16, 48)])
 @pytest.mark.parametrize('half', [False, True])
