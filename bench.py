@@ -61,9 +61,8 @@ def laplace_activation(shape, gen_seed, device):
     return x
 
 
-def build_workload(batch, device):
+def build_workload(batch, device, seed=12345):
     layers = []
-    seed = 12345
     for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
         for _ in range(count):
             x = laplace_activation((batch, C, hw, hw), seed, device)
@@ -165,7 +164,7 @@ def main():
 
     from cnn_quantization_amd import ops, _lib
     _lib.load()                                         # fail loudly if the HIP library is missing
-    layers = build_workload(args.batch, device)
+    layers = build_workload(args.batch, device, seed=12345 + 1000 * rank)    # every rank its own batch shard
     elems = sum(L['x'].numel() for L in layers)
     torch.cuda.synchronize()
 
