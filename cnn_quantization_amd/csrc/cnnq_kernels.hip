@@ -278,6 +278,47 @@ int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t H
     return cnnq_pc_qdq(x, y, N, C, HW, qp, codes, hist, /*reverse=*/1, stream);
 }
 
+// The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B
+// when b is needed, merge, parameters (ACIQ clipping, bit allocation, scale / zero point), fused Q/DQ - six
+// launches, one host call, one caller workspace.  ws layout (doubles first): part[G][NMOM][C], mom[NMOM][C],
+// part2[G][NDEV][C], then floats stats[NSTAT][C].
+size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16) {
+    const int G = cnnq_pc_groups(N, C, HW, aligned16);
+    if (G <= 0) return 0;
+    return ((size_t)G * CNNQ_NMOM + CNNQ_NMOM + (size_t)G * CNNQ_NDEV) * (size_t)C * sizeof(double) +
+           (size_t)CNNQ_NSTAT * (size_t)C * sizeof(float);
+}
+
+int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                     float* qp, float* diag, void* stream) {
+    if (!x || !y || !cfg || !ws || !qp || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    double* mom = part + (size_t)G * CNNQ_NMOM * C;
+    double* part2 = mom + (size_t)CNNQ_NMOM * C;
+    float* stats = reinterpret_cast<float*>(part2 + (size_t)G * CNNQ_NDEV * C);
+    const bool use_ba = cfg->bit_alloc && cfg->num_bits <= 4;
+    const bool need_b = cfg->clip == 1 || (use_ba && cfg->prior_is_b);
+    hipStream_t st = (hipStream_t)stream;
+    // rows nobody writes (KURT, STD_POS; B without pass B) must not hold NaN garbage for the parameter kernel
+    if (hipMemsetAsync(stats, 0, (size_t)CNNQ_NSTAT * C * sizeof(float), st) != hipSuccess) return launch_status();
+    int rc = cnnq_pc_moments(x, N, C, HW, 0, part, stream);
+    if (rc) return rc;
+    rc = cnnq_pc_combine(part, G, C, 0, mom, stats, stream);
+    if (rc) return rc;
+    if (need_b) {
+        rc = cnnq_pc_absdev(x, N, C, HW, stats, 0, part2, stream);
+        if (rc) return rc;
+        rc = cnnq_pc_combine_dev(part2, G, C, mom, 0, nullptr, stats, stream);
+        if (rc) return rc;
+    }
+    rc = cnnq_pc_params(stats, C, cfg, qp, diag, stream);
+    if (rc) return rc;
+    // pass B walks the tensor descending, so the Q/DQ after it ascends; straight after pass A it descends
+    return cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, /*reverse=*/need_b ? 0 : 1, stream);
+}
+
 int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_w, const float* stats_q, int vcorr,
                            int bcorr, void* stream) {
     if (!wq || !stats_w || !stats_q || C <= 0 || HW <= 0 || C > 65535 * 1024 || HW >= ((int64_t)1 << 31))

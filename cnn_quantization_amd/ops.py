@@ -121,11 +121,7 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
 CLIP_CODES = {'no': 0, 'laplace': 1, 'gaus': 2}
 
 
-def pc_params(stats, num_bits, positive=False, clip='no', bit_alloc=False, prior_is_b=False, target=None,
-              round_mode=True, direct_range=False):
-    """stats [NSTAT, C] -> (qp [NQP, C], diag [NDIAG, C]); see cnnq_pc_params."""
-    lib = L.load()
-    C = stats.shape[1]
+def _params_cfg(num_bits, positive, clip, bit_alloc, prior_is_b, target, round_mode, direct_range):
     cfg = L.ParamsCfg()
     cfg.num_bits = int(num_bits)
     cfg.positive = int(bool(positive))
@@ -140,6 +136,15 @@ def pc_params(stats, num_bits, positive=False, clip='no', bit_alloc=False, prior
     cfg.target = float(num_bits if target is None else target)
     cfg.round_mode = int(bool(round_mode))
     cfg.direct_range = int(bool(direct_range))
+    return cfg
+
+
+def pc_params(stats, num_bits, positive=False, clip='no', bit_alloc=False, prior_is_b=False, target=None,
+              round_mode=True, direct_range=False):
+    """stats [NSTAT, C] -> (qp [NQP, C], diag [NDIAG, C]); see cnnq_pc_params."""
+    lib = L.load()
+    C = stats.shape[1]
+    cfg = _params_cfg(num_bits, positive, clip, bit_alloc, prior_is_b, target, round_mode, direct_range)
     qp = torch.empty((L.NQP, C), dtype=torch.float32, device=stats.device)
     diag = torch.empty((L.NDIAG, C), dtype=torch.float32, device=stats.device)
     L.check(lib.cnnq_pc_params(_ptr(stats), C, ctypes.byref(cfg), _ptr(qp), _ptr(diag), _stream(stats)),
@@ -380,6 +385,17 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         if bcorr is not None:
             res = act_bias_correction_(x, res, bool(bcorr), group=None if group is False else group)
         return res
+    if (stats is None and world == 1 and bcorr is None and not (want_codes or want_entropy or want_parts)):
+        # one host call for the whole chain (cnnq_pc_aciq_qdq): the six launches are the same
+        lib = L.load()
+        cfg = _params_cfg(num_bits, positive, clip, use_ba, prior_is_b, target, round_mode, whole_tensor)
+        y = _out_like(x, out)
+        ws = torch.empty(lib.cnnq_pc_aciq_workspace(N, C, HW, int(x.data_ptr() % 16 == 0)), dtype=torch.uint8,
+                         device=x.device)
+        qd = torch.empty((L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_pc_aciq_qdq(_ptr(x), _ptr(y), N, C, HW, ctypes.byref(cfg), _ptr(ws), _ptr(qd),
+                                     _ptr(qd[L.NQP:]), _stream(x)), 'cnnq_pc_aciq_qdq')
+        return y
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)
         stats, _ = pc_stats(x, N, C, HW, need_b=need_b, group=None if group is False else group,

@@ -206,6 +206,15 @@ int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int 
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                        float* pmm, float* qp, uint8_t* codes, uint64_t* hist, void* stream);
 
+/* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
+ * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace
+ * prior) -> merge -> cnnq_pc_params(cfg) -> fused Q/DQ.  `ws`: caller workspace of cnnq_pc_aciq_workspace(...)
+ * bytes, 8-byte aligned (0 = invalid geometry); qp[CNNQ_NQP][C] and diag[CNNQ_NDIAG][C] (diag required with
+ * bit allocation) are outputs.  Single process only: the cross-rank exchange sits between the launches. */
+size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16);
+int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                     float* qp, float* diag, void* stream);
+
 /* Weight bias / variance correction after quantization (iqm.py:374-391), in place on
  * wq[C][HW]: vcorr: wq = (wq - mean_q) * std_w/(std_q + 1e-8) + mean_q; bcorr: wq = wq - mean_q + mean_w
  * (mean_q is the pre-correction mean in both), with the reference's operation order.  stats_w /
