@@ -82,31 +82,54 @@ class P2PExchange:
     SLOT_FLOATS = 32768                                 # 128 KB: fp64 moment records [7][C] up to C = 2340
 
     def __init__(self, group=None):
+        """Collective: every rank of `group` must call it.  Local failures (allocation, IPC export / import)
+        never skip a collective step; `self.ok` is the group-wide verdict (all ranks agree on it)."""
         import ctypes
         from . import _lib as L
         self.group, self.L, self.lib = group, L, L.load()
         self.world, self.rank = world_size(group), rank(group)
         self.device = torch.device('cuda', torch.cuda.current_device())
+        self.mapped, self.own, self.why = [], None, ''
         own = ctypes.c_void_p()
         handle = ctypes.create_string_buffer(64)
-        L.check(self.lib.cnnq_p2p_alloc(self.world, self.SLOT_FLOATS, ctypes.byref(own), handle), 'cnnq_p2p_alloc')
-        self.own = own
+        local_ok = True
+        try:
+            L.check(self.lib.cnnq_p2p_alloc(self.world, self.SLOT_FLOATS, ctypes.byref(own), handle), 'cnnq_p2p_alloc')
+            self.own = own
+        except Exception as e:
+            local_ok, self.why = False, str(e)
         handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle.raw), group=group)
-        self.mapped = []
+        dist.all_gather_object(handles, bytes(handle.raw) if local_ok else b'', group=group)
         ptrs = []
-        for r, h in enumerate(handles):
-            if r == self.rank:
-                ptrs.append(own.value)
-                continue
-            w = ctypes.c_void_p()
-            L.check(self.lib.cnnq_p2p_open(ctypes.create_string_buffer(h, 64), ctypes.byref(w)), 'cnnq_p2p_open')
-            self.mapped.append(w)
-            ptrs.append(w.value)
-        self.windows = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
-        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if local_ok and all(len(h) == 64 for h in handles):
+            try:
+                for r, h in enumerate(handles):
+                    if r == self.rank:
+                        ptrs.append(own.value)
+                        continue
+                    w = ctypes.c_void_p()
+                    L.check(self.lib.cnnq_p2p_open(ctypes.create_string_buffer(h, 64), ctypes.byref(w)), 'cnnq_p2p_open')
+                    self.mapped.append(w)
+                    ptrs.append(w.value)
+            except Exception as e:
+                local_ok, self.why = False, str(e)
+        else:
+            local_ok = False
+        self.ok = self._all_agree(local_ok)             # also: every window is mapped before anyone posts
+        if self.ok:
+            self.windows = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
-        dist.barrier(group=group)                       # every window is mapped before anyone posts
+
+    def _all_agree(self, flag):
+        """Group-wide AND of a local boolean (a collective)."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        try:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        except RuntimeError:                             # gloo without device tensors
+            t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
 
     def fits(self, rec):
         return rec.is_cuda and rec.element_size() % 4 == 0 and rec.numel() * rec.element_size() <= 4 * self.SLOT_FLOATS
@@ -143,23 +166,17 @@ class P2PExchange:
             ref = collective_all_gather(rec, self.group)
             got = self.all_gather(rec)
             ok = ok and bool(torch.equal(ref, got))
-        ok = ok and self.healthy()
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
-        try:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        except RuntimeError:                             # gloo without device tensors
-            cpu = flag.cpu()
-            dist.all_reduce(cpu, op=dist.ReduceOp.MIN, group=self.group)
-            flag = cpu
-        return bool(int(flag.item()))
+        return self._all_agree(ok and self.healthy())
 
     def close(self):
+        """Collective: unmap the peers' windows and free the own one once nobody uses them any more."""
         torch.cuda.synchronize()
         dist.barrier(group=self.group)
         for w in self.mapped:
             self.lib.cnnq_p2p_close(w)
-        self.lib.cnnq_p2p_free(self.own)
-        self.mapped, self.own = [], None
+        if self.own is not None:
+            self.lib.cnnq_p2p_free(self.own)
+        self.mapped, self.own, self.ok = [], None, False
 
 
 _P2P = {}
@@ -172,12 +189,14 @@ def p2p_exchange(group=None):
         return None
     key = id(group)
     if key not in _P2P:
-        try:
-            ex = P2PExchange(group)
-            _P2P[key] = ex if ex.verify() else None
-        except Exception as e:                           # no peer access, IPC refused, ...: keep RCCL
-            print('cnn_quantization_amd: peer-to-peer exchange unavailable (%s); using the collective' % (e,))
-            _P2P[key] = None
+        ex = P2PExchange(group)                          # collective; never raises for a local failure
+        good = ex.ok and ex.verify()
+        if not good:
+            if rank(group) == 0:
+                print('cnn_quantization_amd: peer-to-peer exchange unavailable or not verified (%s); using the '
+                      'collective' % (ex.why or 'see other ranks',))
+            ex.close()
+        _P2P[key] = ex if good else None
     return _P2P[key]
 
 
