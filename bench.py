@@ -190,6 +190,8 @@ def main():
     exchange_name = 'none (1 GPU)' if world == 1 else (
         'peer-to-peer stores over xGMI (CNNQ_P2P_EXCHANGE=1, verified against the collective)'
         if D.p2p_exchange(group) is not None else '%s all_gather' % ('RCCL' if backend == 'nccl' else backend))
+    if world > 1 and D.p2p_exchange(group) is not None and not D.p2p_exchange(group).healthy():
+        exchange_name += ' - UNHEALTHY: a wait timed out, results of this run are invalid'
     value = elems * world * args.steps / dt
 
     # roofline of the dominant kernel (fused Q/DQ), measured live with HIP events on its stream
