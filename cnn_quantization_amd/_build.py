@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, 'csrc', 'cnnq_kernels.hip')]
 HDR = [os.path.join(ROOT, 'include', 'cnnq_hip.h')] + sorted(
-    os.path.join(PKG, 'csrc', f) for f in os.listdir(os.path.join(PKG, 'csrc')) if f.endswith('.cuh'))
+    os.path.join(PKG, 'csrc', f) for f in os.listdir(os.path.join(PKG, 'csrc')) if f.endswith('.hip.h'))
 LIB = os.path.join(PKG, 'libcnnq_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
 

@@ -1,4 +1,4 @@
-// cnnq_common.cuh - shared constants, the column-walk decomposition (Geo / Blk / blk_of), vector and non-temporal load/store helpers.
+// cnnq_common.hip.h - shared constants, the column-walk decomposition (Geo / Blk / blk_of), vector and non-temporal load/store helpers.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
 #include <hip/hip_runtime.h>

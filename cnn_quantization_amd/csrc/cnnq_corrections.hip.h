@@ -1,9 +1,9 @@
-// cnnq_corrections.cuh - weight bias/variance correction and activation bias correction.
+// cnnq_corrections.hip.h - weight bias/variance correction and activation bias correction.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
-#include "cnnq_stats.cuh"
-#include "cnnq_qdq.cuh"
+#include "cnnq_common.hip.h"
+#include "cnnq_stats.hip.h"
+#include "cnnq_qdq.hip.h"
 
 namespace {
 

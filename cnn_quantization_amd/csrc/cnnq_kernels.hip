@@ -26,22 +26,22 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (division must stay an IEEE
 // divide followed by a separately rounded add: bit-exactness with the reference's aten ops).
 //
-// Layout: the kernels live in the cnnq_*.cuh files next to this one (one file per stage of the path),
+// Layout: the kernels live in the cnnq_*.hip.h files next to this one (one file per stage of the path),
 // all in one anonymous namespace of this single translation unit; below them is the C ABI.
 
 #include <string.h>
 
-#include "cnnq_common.cuh"
-#include "cnnq_stats.cuh"
-#include "cnnq_params.cuh"
-#include "cnnq_qdq.cuh"
-#include "cnnq_pack4.cuh"
-#include "cnnq_midtread.cuh"
-#include "cnnq_corrections.cuh"
-#include "cnnq_pertensor.cuh"
-#include "cnnq_plan.cuh"
-#include "cnnq_kld.cuh"
-#include "cnnq_p2p.cuh"
+#include "cnnq_common.hip.h"
+#include "cnnq_stats.hip.h"
+#include "cnnq_params.hip.h"
+#include "cnnq_qdq.hip.h"
+#include "cnnq_pack4.hip.h"
+#include "cnnq_midtread.hip.h"
+#include "cnnq_corrections.hip.h"
+#include "cnnq_pertensor.hip.h"
+#include "cnnq_plan.hip.h"
+#include "cnnq_kld.hip.h"
+#include "cnnq_p2p.hip.h"
 
 extern "C" {
 

@@ -1,7 +1,7 @@
-// cnnq_kld.cuh - KLD calibration: per-sample histogram and threshold search.
+// cnnq_kld.hip.h - KLD calibration: per-sample histogram and threshold search.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
+#include "cnnq_common.hip.h"
 
 namespace {
 

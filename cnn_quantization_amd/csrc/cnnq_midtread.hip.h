@@ -1,8 +1,8 @@
-// cnnq_midtread.cuh - mid-tread quantization with per-channel bin allocation and its entropy.
+// cnnq_midtread.hip.h - mid-tread quantization with per-channel bin allocation and its entropy.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
-#include "cnnq_params.cuh"
+#include "cnnq_common.hip.h"
+#include "cnnq_params.hip.h"
 
 namespace {
 

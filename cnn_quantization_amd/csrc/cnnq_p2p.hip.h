@@ -1,4 +1,4 @@
-// cnnq_p2p.cuh - one-shot all-gather of small per-channel records over xGMI peer-to-peer stores (opt-in
+// cnnq_p2p.hip.h - one-shot all-gather of small per-channel records over xGMI peer-to-peer stores (opt-in
 // alternative to the RCCL all_gather of the statistics exchange; see distributed.P2PExchange).
 // Part of the single translation unit cnnq_kernels.hip.
 //
@@ -13,7 +13,7 @@
 // consuming seq.  A spin gives up after P2P_TIMEOUT_TICKS of the constant 100 MHz clock and reports through
 // `status` instead of hanging the device; once set, later exchanges return NaN records immediately.
 #pragma once
-#include "cnnq_common.cuh"
+#include "cnnq_common.hip.h"
 
 namespace {
 

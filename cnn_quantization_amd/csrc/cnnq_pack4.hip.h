@@ -1,8 +1,8 @@
-// cnnq_pack4.cuh - integer codes (packed int4, or one byte each) as the stored activation format.
+// cnnq_pack4.hip.h - integer codes (packed int4, or one byte each) as the stored activation format.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
-#include "cnnq_qdq.cuh"
+#include "cnnq_common.hip.h"
+#include "cnnq_qdq.hip.h"
 
 namespace {
 

@@ -1,7 +1,7 @@
-// cnnq_params.cuh - statistics -> ACIQ clipping -> bit allocation -> scale / zero point / qmax, on the device.
+// cnnq_params.hip.h - statistics -> ACIQ clipping -> bit allocation -> scale / zero point / qmax, on the device.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
+#include "cnnq_common.hip.h"
 
 namespace {
 

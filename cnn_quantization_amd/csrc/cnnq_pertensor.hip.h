@@ -1,7 +1,7 @@
-// cnnq_pertensor.cuh - per-tensor GEMMLOWP path (the replacement of kernels/gemmlowp.cu).
+// cnnq_pertensor.hip.h - per-tensor GEMMLOWP path (the replacement of kernels/gemmlowp.cu).
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
+#include "cnnq_common.hip.h"
 
 namespace {
 

@@ -1,7 +1,7 @@
-// cnnq_plan.cuh - host side: load-shape choice, launch geometry, template dispatch.
+// cnnq_plan.hip.h - host side: load-shape choice, launch geometry, template dispatch.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
+#include "cnnq_common.hip.h"
 
 namespace {
 

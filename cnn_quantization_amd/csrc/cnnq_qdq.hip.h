@@ -1,8 +1,8 @@
-// cnnq_qdq.cuh - config-2 pipeline: exact min/max partials, parameter table, the fused per-channel Q/DQ, code entropy.
+// cnnq_qdq.hip.h - config-2 pipeline: exact min/max partials, parameter table, the fused per-channel Q/DQ, code entropy.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
-#include "cnnq_params.cuh"
+#include "cnnq_common.hip.h"
+#include "cnnq_params.hip.h"
 
 namespace {
 

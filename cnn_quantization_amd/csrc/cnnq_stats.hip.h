@@ -1,7 +1,7 @@
-// cnnq_stats.cuh - statistics passes: per-channel moments (pass A), mean absolute deviation / kurtosis (pass B) and their combine kernels.
+// cnnq_stats.hip.h - statistics passes: per-channel moments (pass A), mean absolute deviation / kurtosis (pass B) and their combine kernels.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
-#include "cnnq_common.cuh"
+#include "cnnq_common.hip.h"
 
 namespace {
 

@@ -1,7 +1,7 @@
 """Host logic of the kernels, checked without a GPU: the launch plan (cnnq_plan_describe) must cut
 x[N][C][HW] into workgroups that cover every element exactly once, keep every workgroup inside
 channel boundaries as its mode promises, and give every (group, channel) partial exactly one writer.
-The block -> range arithmetic below restates `blk_of` of csrc/cnnq_common.cuh."""
+The block -> range arithmetic below restates `blk_of` of csrc/cnnq_common.hip.h."""
 import ctypes
 import itertools
 
