@@ -48,6 +48,9 @@ SIGNATURES = {
     'cnnq_pc_minmax_reduce': (_I, [_P, _I, _L, _P, _P]),
     'cnnq_pc_minmax_params': (_I, [_P, _I, _L, _I, _I, _P, _P]),
     'cnnq_pc_minmax_qdq': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
+    'cnnq_pc_resident_workspace': (ctypes.c_size_t, [_L, _L, _L]),
+    'cnnq_pc_resident_describe': (_I, [_L, _L, _L, ctypes.POINTER(ctypes.c_int32)]),
+    'cnnq_pc_minmax_qdq_resident': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, ctypes.c_uint32, _P]),
     'cnnq_pc_aciq_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_aciq_qdq': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),
@@ -73,6 +76,9 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+ENOTSUP = -3
 
 
 class CnnqError(RuntimeError):
@@ -104,5 +110,5 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        kind = {-1: 'CNNQ_EINVAL', -2: 'CNNQ_ERANGE'}.get(rc, 'hipError %d' % rc)
+        kind = {-1: 'CNNQ_EINVAL', -2: 'CNNQ_ERANGE', -3: 'CNNQ_ENOTSUP'}.get(rc, 'hipError %d' % rc)
         raise CnnqError('%s failed: %s' % (what, kind))

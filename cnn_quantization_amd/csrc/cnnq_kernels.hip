@@ -39,6 +39,7 @@
 #include "cnnq_midtread.hip.h"
 #include "cnnq_corrections.hip.h"
 #include "cnnq_pertensor.hip.h"
+#include "cnnq_resident.hip.h"
 #include "cnnq_plan.hip.h"
 #include "cnnq_kld.hip.h"
 #include "cnnq_p2p.hip.h"
@@ -276,6 +277,31 @@ int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t H
     if (rc) return rc;
     // descending address order: what the statistics pass read last is re-read first
     return cnnq_pc_qdq(x, y, N, C, HW, qp, codes, hist, /*reverse=*/1, stream);
+}
+
+// Config 2 in one launch and one read of x (cnnq_resident.hip.h)
+size_t cnnq_pc_resident_workspace(int64_t N, int64_t C, int64_t HW) {
+    RPlan p;
+    return plan_resident(N, C, HW, true, &p) ? 0 : p.ws_bytes;
+}
+
+int cnnq_pc_resident_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
+    if (!out) return CNNQ_EINVAL;
+    RPlan p;
+    const int rc = plan_resident(N, C, HW, true, &p);
+    if (rc) return rc;
+    const int32_t vals[8] = {p.v.A, p.K, p.g.mode, p.g.S, p.g.ncb, p.Gs, p.ngroups, p.g.S * p.g.ncb};
+    for (int i = 0; i < 8; ++i) out[i] = vals[i];
+    return 0;
+}
+
+int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                                void* ws, float* qp, float* mm, unsigned flags, void* stream) {
+    if (!x || !y || !ws || !qp || num_bits < 1 || num_bits > 8 || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
+    RPlan p;
+    const int rc = plan_resident(N, C, HW, al16(x) && al16(y), &p);
+    if (rc) return rc;
+    return launch_resident(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
 }
 
 // The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B

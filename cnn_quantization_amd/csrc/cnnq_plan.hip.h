@@ -2,6 +2,7 @@
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
 #include "cnnq_common.hip.h"
+#include "cnnq_resident.hip.h"
 
 namespace {
 
@@ -131,6 +132,96 @@ int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const f
     } while (0)
     CNNQ_DISPATCH(v, LAUNCH_QDQ);
 #undef LAUNCH_QDQ
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// the register-resident single-launch form of config 2 (cnnq_resident.hip.h)
+// ------------------------------------------------------------------------------------------
+struct RPlan {
+    Variant v;     // {4, A, 1}
+    Geo g;         // column blocks of <= 256 float4 columns, S = batch splits of <= K samples
+    int K;         // samples (16-byte loads) a lane holds
+    int Gs;        // workgroups per group (the ones that exchange extrema)
+    int ngroups;   // groups = arrival counters
+    size_t ws_bytes;
+};
+
+// development knobs (kernel sweeps): CNNQ_RES_K forces K, CNNQ_RES_WGS the workgroup target
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+constexpr size_t RES_WS_HDR = 256;   // status word (+ padding) in front of the counters
+
+int plan_resident(int64_t N, int64_t C, int64_t HW, bool aligned16, RPlan* p) {
+    if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
+    if (!aligned16) return CNNQ_ENOTSUP;
+    if (HW % 4 == 0) {
+        p->v = {4, 1, 1};
+    } else if ((C * HW) % 4 == 0) {
+        const int m = 4 / gcd_i((int)(HW % 4), 4);
+        if ((int64_t)m * HW > TPB * 4) return CNNQ_ENOTSUP;
+        p->v = {4, 4, 1};
+    } else {
+        return CNNQ_ENOTSUP;
+    }
+    const int rc = make_geo(N, C, HW, p->v, 0, C, 0, 0, 0, &p->g);
+    if (rc) return rc;
+    Geo& g = p->g;
+    static const int forceK = env_int("CNNQ_RES_K", 0);
+    static const int target = env_int("CNNQ_RES_WGS", 1024);
+    const int members_per_split = (g.mode == 1) ? g.nb : 1;
+    int K = 4;
+    if (forceK == 4 || forceK == 8 || forceK == 16 || forceK == 32) {
+        K = forceK;
+    } else {
+        // the largest tile that still yields `target` workgroups
+        for (K = 32; K > 4; K >>= 1)
+            if ((int64_t)g.ncb * ((N + K - 1) / K) >= target) break;
+    }
+    // a group must stay small enough to be co-resident
+    while (K < 32 && ((N + K - 1) / K) * members_per_split > RES_GS_MAX) K <<= 1;
+    const int64_t S = (N + K - 1) / K;
+    if (S * members_per_split > RES_GS_MAX) return CNNQ_ENOTSUP;
+    if (S * g.ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    g.S = (int)S;
+    p->K = K;
+    p->Gs = (int)(S * members_per_split);
+    p->ngroups = (g.mode == 1) ? g.Cn : g.ncb;
+    p->ws_bytes = RES_WS_HDR + (((size_t)p->ngroups * 4 + 255) / 256) * 256 + (size_t)C * p->Gs * 8;
+    return 0;
+}
+
+int launch_resident(const float* x, float* y, const RPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
+                    unsigned flags, hipStream_t st) {
+    RWs w;
+    w.status = reinterpret_cast<unsigned*>(ws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + RES_WS_HDR);
+    w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + RES_WS_HDR +
+                                                   (((size_t)p.ngroups * 4 + 255) / 256) * 256);
+    const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
+#define LAUNCH_RES2(A, K)                                                                                             \
+    do {                                                                                                              \
+        if (p.Gs > 1)                                                                                                 \
+            hipLaunchKernelGGL((k_mmq_resident<A, K, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, \
+                               qp, mm, flags);                                                                        \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_mmq_resident<A, K, false>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, \
+                               w, qp, mm, flags);                                                                     \
+    } while (0)
+#define LAUNCH_RES(A)                         \
+    do {                                      \
+        if (p.K == 32) LAUNCH_RES2(A, 32);    \
+        else if (p.K == 16) LAUNCH_RES2(A, 16); \
+        else if (p.K == 8) LAUNCH_RES2(A, 8);  \
+        else LAUNCH_RES2(A, 4);               \
+    } while (0)
+    if (p.v.A == 4) LAUNCH_RES(4);
+    else LAUNCH_RES(1);
+#undef LAUNCH_RES
+#undef LAUNCH_RES2
     return launch_status();
 }
 

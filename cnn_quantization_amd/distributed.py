@@ -200,14 +200,26 @@ def p2p_exchange(group=None):
     return _P2P[key]
 
 
+def gather_counts(n, device, group=None):
+    """The integer `n` of every rank as a host list in rank order (one tiny all_gather + a host sync; used only by
+    the per-tensor path, whose tables have one row per local sample and shards may differ by a sample)."""
+    t = torch.tensor([[int(n)]], dtype=torch.int64, device=device)
+    return [int(v) for v in collective_all_gather(t, group).flatten().tolist()]
+
+
 def merge_row_minmax(stats, rows, avg_over_batch, group=None):
-    """Per-sample MIN/MAX rows of every rank's shard -> one table whose first two rows list all
-    samples of the global batch (equal shard sizes), ready for cnnq_pt_setup."""
+    """Per-sample MIN/MAX rows of every rank's shard -> one table whose first two rows list all samples of the
+    global batch in rank order, ready for cnnq_pt_setup (which takes their batch mean, or their extrema).
+    Shards may hold different numbers of samples (shard_batch: sizes differ by at most one): the row counts
+    travel first, the tables are padded to the largest shard for the all_gather and un-padded afterwards."""
     w = world_size(group)
-    local = stats[:2, :rows].contiguous()                       # [2, rows]
-    allr = all_gather_records(local, group)                     # [W, 2, rows]
-    merged = torch.zeros((stats.shape[0], w * rows), dtype=stats.dtype, device=stats.device)
-    merged[:2] = allr.permute(1, 0, 2).reshape(2, w * rows)
+    counts = gather_counts(rows, stats.device, group)
+    rmax = max(counts)
+    local = torch.zeros((2, rmax), dtype=stats.dtype, device=stats.device)
+    local[:, :rows] = stats[:2, :rows]
+    allr = all_gather_records(local, group)                     # [W, 2, rmax]
+    merged = torch.zeros((stats.shape[0], sum(counts)), dtype=stats.dtype, device=stats.device)
+    merged[:2] = torch.cat([allr[r, :, :counts[r]] for r in range(w)], dim=1)
     return merged
 
 

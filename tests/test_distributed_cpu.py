@@ -73,6 +73,15 @@ def _worker(rank, world, port, tmp):
     m = D.merge_row_minmax(st, 5, True, None)
     assert m.shape == (7, 5 * world)
     assert m[0].tolist() == [float(v + 10 * r) for r in range(world) for v in range(5)]
+    # uneven shards (10 samples over 3 ranks = 4 + 3 + 3): every rank ends up with all 10 rows in batch order
+    per_sample_min = x.reshape(10, -1).min(-1)[0]
+    per_sample_max = x.reshape(10, -1).max(-1)[0]
+    rows = n1 - n0
+    st = torch.zeros(7, rows)
+    st[0], st[1] = per_sample_min[n0:n1], per_sample_max[n0:n1]
+    m = D.merge_row_minmax(st, rows, True, None)
+    assert m.shape == (7, 10)
+    assert torch.equal(m[0], per_sample_min) and torch.equal(m[1], per_sample_max)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, 'ok%d' % rank), 'w').write('ok')
