@@ -304,6 +304,17 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
     return launch_resident(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
 }
 
+// experiment: exchange workspace in fine-grained (uncached) device memory
+int cnnq_ws_alloc_uncached(size_t bytes, void** out) {
+    if (!out || !bytes) return CNNQ_EINVAL;
+    hipError_t e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(*out, 0, bytes);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipDeviceSynchronize();
+}
+int cnnq_ws_free(void* p) { return p ? (int)hipFree(p) : CNNQ_EINVAL; }
+
 // The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B
 // when b is needed, merge, parameters (ACIQ clipping, bit allocation, scale / zero point), fused Q/DQ - six
 // launches, one host call, one caller workspace.  ws layout (doubles first): part[G][NMOM][C], mom[NMOM][C],

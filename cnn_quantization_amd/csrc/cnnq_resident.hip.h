@@ -29,6 +29,9 @@
 
 namespace {
 
+#ifndef RES_POLL_RMW
+#define RES_POLL_RMW 0    // experiment: poll the arrival counter with a returning atomic instead of an sc1 load
+#endif
 #ifndef RES_K32_WAVES
 #define RES_K32_WAVES 3   // waves per SIMD the K = 32 tile is compiled for (168 VGPRs; 2 = no register cap)
 #endif
@@ -148,7 +151,7 @@ __device__ __forceinline__ void lane_acc(const float (&v)[4], float (&mn)[A], fl
 
 // cold path (a wait timed out, or the test flag): the extrema of the group's channels straight from x, all samples
 template <int A>
-__device__ __noinline__ void group_minmax_from_x(const float* __restrict__ x, const Geo& g, const Blk& b, float* l_mn,
+__device__ __forceinline__ void group_minmax_from_x(const float* __restrict__ x, const Geo& g, const Blk& b, float* l_mn,
                                                  float* l_mx, float* sh_mn, float* sh_mx) {
     const int tid = threadIdx.x;
     float mn[A], mx[A];
@@ -237,8 +240,16 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? RES_K32_WAVES : 1)) k_mmq_resi
             if (!timed_out && seen < (unsigned)Gs) {
                 const long long t0 = wall_clock64();
                 for (int spins = 0;; ++spins) {
-                    __builtin_amdgcn_s_sleep(4);
+                    // every poll is a memory-side access: back off (0.1 us -> 1.7 us) so that a few hundred waiting
+                    // workgroups do not eat the bandwidth the others need to get here
+                    if (spins < 4) __builtin_amdgcn_s_sleep(4);
+                    else if (spins < 12) __builtin_amdgcn_s_sleep(16);
+                    else __builtin_amdgcn_s_sleep(64);
+#if RES_POLL_RMW
+                    seen = __hip_atomic_fetch_add(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                     seen = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                     if (seen >= (unsigned)Gs) break;
                     // two independent bounds: the constant-rate clock, and a plain iteration count
                     if (wall_clock64() - t0 > RES_TIMEOUT_TICKS || spins > RES_TIMEOUT_SPINS) { timed_out = 1; break; }
@@ -256,9 +267,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? RES_K32_WAVES : 1)) k_mmq_resi
             group_minmax_from_x<A>(x, g, b, l_mn, l_mx, sh_mn, sh_mx);
         } else if (g.mode == 1) {
             float tn = INFINITY, tx = -INFINITY;
+            // after the acquire: plain loads (this CU's L1 was invalidated, the pairs were written through)
+            const unsigned long long* pp = ws.part + (size_t)b.c0 * Gs;
             for (int m = tid; m < Gs; m += TPB) {
                 float a, c;
-                unpack_pair(__hip_atomic_load(ws.part + (size_t)b.c0 * Gs + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, c);
+                unpack_pair(pp[m], a, c);
                 tn = pmin(tn, a);
                 tx = pmax(tx, c);
             }
@@ -268,10 +281,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? RES_K32_WAVES : 1)) k_mmq_resi
         } else {
             for (int ch = tid; ch < nch; ch += TPB) {
                 float tn = INFINITY, tx = -INFINITY;
-#pragma unroll 4
+                const unsigned long long* pp = ws.part + b.c0 + ch;
+#pragma unroll 8
                 for (int s = 0; s < Gs; ++s) {
                     float a, c;
-                    unpack_pair(__hip_atomic_load(ws.part + (size_t)s * g.C + b.c0 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, c);
+                    unpack_pair(pp[(size_t)s * g.C], a, c);
                     tn = pmin(tn, a);
                     tx = pmax(tx, c);
                 }

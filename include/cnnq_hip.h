@@ -225,6 +225,9 @@ int cnnq_pc_resident_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                                 void* ws, float* qp, float* mm, unsigned flags, void* stream);
 
+int cnnq_ws_alloc_uncached(size_t bytes, void** out);
+int cnnq_ws_free(void* p);
+
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace
  * prior) -> merge -> cnnq_pc_params(cfg) -> fused Q/DQ.  `ws`: caller workspace of cnnq_pc_aciq_workspace(...)

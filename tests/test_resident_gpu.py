@@ -50,6 +50,9 @@ def test_resident_golden_bit_exact(ops, golden):
         bits, half = int(g.np(key + '_bits')), bool(g.np(key + '_half'))
         for flags in (0, 1):
             res = ops.minmax_qdq_resident(x, N, C, x[0, 0].numel(), bits, half, want_parts=True, flags=flags)
+            if describe(N, C, x[0, 0].numel())[0] != 0:      # [3,16,5,9]: H*W = 45, no resident kernel
+                assert res is None
+                break
             assert res is not None, key
             y, parts = res
             assert bits_equal(y.cpu(), g.np(key + '_y')), (key, flags)
@@ -58,8 +61,9 @@ def test_resident_golden_bit_exact(ops, golden):
                 assert bits_equal(parts['stats'][L.STAT_MIN].cpu(), g.np('s%s_stat_min' % si)), key
             yc, pc = classic(ops, x, bits, half)
             assert torch.equal(parts['qp'], pc['qp']), key
-        n += 1
-    assert n == 15
+        else:
+            n += 1
+    assert n == 12
 
 
 SHAPES = [
