@@ -280,40 +280,24 @@ int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t H
 }
 
 // Config 2 in one launch and one read of x (cnnq_resident.hip.h)
-size_t cnnq_pc_resident_workspace(int64_t N, int64_t C, int64_t HW) {
-    RPlan p;
-    return plan_resident(N, C, HW, true, &p) ? 0 : p.ws_bytes;
-}
-
 int cnnq_pc_resident_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
     if (!out) return CNNQ_EINVAL;
-    RPlan p;
-    const int rc = plan_resident(N, C, HW, true, &p);
+    WPlan p;
+    const int rc = plan_whole(N, C, HW, true, &p);
     if (rc) return rc;
-    const int32_t vals[8] = {p.v.A, p.K, p.g.mode, p.g.S, p.g.ncb, p.Gs, p.ngroups, p.g.S * p.g.ncb};
+    const int32_t vals[8] = {p.A, p.T, p.K, p.g.k, p.g.CL, p.g.RL, p.wgs, 0};
     for (int i = 0; i < 8; ++i) out[i] = vals[i];
     return 0;
 }
 
 int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                                void* ws, float* qp, float* mm, unsigned flags, void* stream) {
-    if (!x || !y || !ws || !qp || num_bits < 1 || num_bits > 8 || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
-    RPlan p;
-    const int rc = plan_resident(N, C, HW, al16(x) && al16(y), &p);
+                                float* qp, float* mm, void* stream) {
+    if (!x || !y || !qp || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
+    WPlan p;
+    const int rc = plan_whole(N, C, HW, al16(x) && al16(y), &p);
     if (rc) return rc;
-    return launch_resident(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
+    return launch_whole(x, y, p, num_bits, positive ? 1 : 0, qp, mm, (hipStream_t)stream);
 }
-
-// experiment: exchange workspace in fine-grained (uncached) device memory
-int cnnq_ws_alloc_uncached(size_t bytes, void** out) {
-    if (!out || !bytes) return CNNQ_EINVAL;
-    hipError_t e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemset(*out, 0, bytes);
-    if (e != hipSuccess) return (int)e;
-    return (int)hipDeviceSynchronize();
-}
-int cnnq_ws_free(void* p) { return p ? (int)hipFree(p) : CNNQ_EINVAL; }
 
 // The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B
 // when b is needed, merge, parameters (ACIQ clipping, bit allocation, scale / zero point), fused Q/DQ - six

@@ -138,90 +138,80 @@ int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const f
 // ------------------------------------------------------------------------------------------
 // the register-resident single-launch form of config 2 (cnnq_resident.hip.h)
 // ------------------------------------------------------------------------------------------
-struct RPlan {
-    Variant v;     // {4, A, 1}
-    Geo g;         // column blocks of <= 256 float4 columns, S = batch splits of <= K samples
-    int K;         // samples (16-byte loads) a lane holds
-    int Gs;        // workgroups per group (the ones that exchange extrema)
-    int ngroups;   // groups = arrival counters
-    size_t ws_bytes;
+struct WPlan {
+    int A, T, K;   // parameter sets per float4, threads per workgroup, samples (16-byte loads) per lane
+    WGeo g;
+    int wgs;       // workgroups = ceil(C / k)
 };
 
-// development knobs (kernel sweeps): CNNQ_RES_K forces K, CNNQ_RES_WGS the workgroup target
+// development knob (kernel sweeps): CNNQ_RES_T forces the workgroup size
 inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
 }
 
-constexpr size_t RES_WS_HDR = 256;   // status word (+ padding) in front of the counters
-
-int plan_resident(int64_t N, int64_t C, int64_t HW, bool aligned16, RPlan* p) {
+// A channel block (k channels, a multiple of the m channels that share float4s) of the WHOLE batch must fit
+// RL x K samples of T / CL row lanes.  Smallest workgroup first; CNNQ_ENOTSUP when nothing fits.
+int plan_whole(int64_t N, int64_t C, int64_t HW, bool aligned16, WPlan* p) {
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
+    if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31) return CNNQ_ERANGE;
     if (!aligned16) return CNNQ_ENOTSUP;
+    int m = 1;
     if (HW % 4 == 0) {
-        p->v = {4, 1, 1};
+        p->A = 1;
     } else if ((C * HW) % 4 == 0) {
-        const int m = 4 / gcd_i((int)(HW % 4), 4);
-        if ((int64_t)m * HW > TPB * 4) return CNNQ_ENOTSUP;
-        p->v = {4, 4, 1};
+        m = 4 / gcd_i((int)(HW % 4), 4);
+        p->A = 4;
     } else {
         return CNNQ_ENOTSUP;
     }
-    const int rc = make_geo(N, C, HW, p->v, 0, C, 0, 0, 0, &p->g);
-    if (rc) return rc;
-    Geo& g = p->g;
-    static const int forceK = env_int("CNNQ_RES_K", 0);
-    static const int target = env_int("CNNQ_RES_WGS", 1024);
-    const int members_per_split = (g.mode == 1) ? g.nb : 1;
-    int K = 4;
-    if (forceK == 4 || forceK == 8 || forceK == 16 || forceK == 32) {
-        K = forceK;
-    } else {
-        // the largest tile that still yields `target` workgroups
-        for (K = 32; K > 4; K >>= 1)
-            if ((int64_t)g.ncb * ((N + K - 1) / K) >= target) break;
+    const int64_t u = m * HW / 4;   // float4 columns of the smallest channel block
+    if (u > 1024) return CNNQ_ENOTSUP;
+    static const int forceT = env_int("CNNQ_RES_T", 0);
+    static const int Ts[3] = {256, 512, 1024};
+    for (int ti = 0; ti < 3; ++ti) {
+        const int T = Ts[ti];
+        if (forceT && T != forceT) continue;
+        if (p->A == 4 && T == 512) continue;   // not instantiated
+        if (u > T) continue;
+        // at least ~512 contiguous bytes per sample and workgroup when the layer has the channels for it
+        int64_t units = (32 + u - 1) / u;
+        if (units > T / u) units = T / u;
+        if (units * m > C) units = (C + m - 1) / m;
+        if (units * m > MAXCH) units = MAXCH / m;
+        if (units < 1) continue;
+        const int64_t CL = units * u;
+        int64_t RL = T / CL;
+        if (RL > N) RL = N;
+        const int64_t need = (N + RL - 1) / RL;
+        const int K = need <= 8 ? 8 : need <= 16 ? 16 : 32;
+        if (need > 32 || (T == 1024 && K > 16) || (T == 512 && K < 16)) continue;
+        p->T = T;
+        p->K = K;
+        p->g.N = (int)N; p->g.C = (int)C; p->g.HW = (int)HW; p->g.P = (int)(C * HW);
+        p->g.k = (int)(units * m);
+        p->g.CL = (int)CL;
+        p->g.RL = (int)RL;
+        p->wgs = (int)((C + p->g.k - 1) / p->g.k);
+        return 0;
     }
-    // a group must stay small enough to be co-resident
-    while (K < 32 && ((N + K - 1) / K) * members_per_split > RES_GS_MAX) K <<= 1;
-    const int64_t S = (N + K - 1) / K;
-    if (S * members_per_split > RES_GS_MAX) return CNNQ_ENOTSUP;
-    if (S * g.ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
-    g.S = (int)S;
-    p->K = K;
-    p->Gs = (int)(S * members_per_split);
-    p->ngroups = (g.mode == 1) ? g.Cn : g.ncb;
-    p->ws_bytes = RES_WS_HDR + (((size_t)p->ngroups * 4 + 255) / 256) * 256 + (size_t)C * p->Gs * 8;
-    return 0;
+    return CNNQ_ENOTSUP;
 }
 
-int launch_resident(const float* x, float* y, const RPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
-                    unsigned flags, hipStream_t st) {
-    RWs w;
-    w.status = reinterpret_cast<unsigned*>(ws);
-    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + RES_WS_HDR);
-    w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + RES_WS_HDR +
-                                                   (((size_t)p.ngroups * 4 + 255) / 256) * 256);
-    const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
-#define LAUNCH_RES2(A, K)                                                                                             \
-    do {                                                                                                              \
-        if (p.Gs > 1)                                                                                                 \
-            hipLaunchKernelGGL((k_mmq_resident<A, K, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, \
-                               qp, mm, flags);                                                                        \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_mmq_resident<A, K, false>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, \
-                               w, qp, mm, flags);                                                                     \
-    } while (0)
-#define LAUNCH_RES(A)                         \
-    do {                                      \
-        if (p.K == 32) LAUNCH_RES2(A, 32);    \
-        else if (p.K == 16) LAUNCH_RES2(A, 16); \
-        else if (p.K == 8) LAUNCH_RES2(A, 8);  \
-        else LAUNCH_RES2(A, 4);               \
-    } while (0)
-    if (p.v.A == 4) LAUNCH_RES(4);
-    else LAUNCH_RES(1);
-#undef LAUNCH_RES
-#undef LAUNCH_RES2
+int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int positive, float* qp, float* mm,
+                 hipStream_t st) {
+    const dim3 grid((unsigned)p.wgs);
+#define LAUNCH_W(A, T, K) \
+    hipLaunchKernelGGL((k_mmq_whole<A, T, K>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm)
+    if (p.A == 1) {
+        if (p.T == 256) { if (p.K == 8) LAUNCH_W(1, 256, 8); else if (p.K == 16) LAUNCH_W(1, 256, 16); else LAUNCH_W(1, 256, 32); }
+        else if (p.T == 512) { if (p.K == 16) LAUNCH_W(1, 512, 16); else LAUNCH_W(1, 512, 32); }
+        else { if (p.K == 8) LAUNCH_W(1, 1024, 8); else LAUNCH_W(1, 1024, 16); }
+    } else {
+        if (p.T == 256) { if (p.K == 8) LAUNCH_W(4, 256, 8); else if (p.K == 16) LAUNCH_W(4, 256, 16); else LAUNCH_W(4, 256, 32); }
+        else { if (p.K == 8) LAUNCH_W(4, 1024, 8); else LAUNCH_W(4, 1024, 16); }
+    }
+#undef LAUNCH_W
     return launch_status();
 }
 

@@ -1,137 +1,37 @@
 // cnnq_resident.hip.h - config 2 (dynamic per-channel min/max -> scale / zero point -> Q/DQ, iq.py:409-451,557-603)
-// in ONE launch that reads x ONCE: 8 bytes per element instead of the 12 of the statistics pass + Q/DQ pass chain.
-// Part of the single translation unit cnnq_kernels.hip (see its header for the shared decomposition).
+// in ONE launch that reads x ONCE: 8 bytes per element instead of the 12 of the statistics pass + Q/DQ pass chain,
+// and one launch boundary instead of three.  Part of the single translation unit cnnq_kernels.hip.
 //
-// Idea: a workgroup's share of x stays in REGISTERS between the statistics and the Q/DQ.  A workgroup owns one
-// column block (<= 256 float4 columns aligned to channel boundaries, as everywhere else) and R <= K consecutive
-// samples of it: every lane issues its K 16-byte loads back to back (K = 4 .. 32, i.e. up to 128 KB per workgroup
-// in flight), reduces them to per-channel {min, max}, and - this is the only new part - waits until the OTHER
-// workgroups that hold pieces of the same channels (the "group": the S batch splits, times the nb column slices
-// when one channel row is wider than a workgroup) have published theirs:
+// A workgroup owns k WHOLE channels for the WHOLE batch and keeps them in registers between the statistics and
+// the Q/DQ, so no workgroup ever needs another one's result: no exchange, no barrier across workgroups, no
+// workspace, nothing to re-arm.  The T lanes of the workgroup form a 2-D tile over (sample, column):
 //
-//     partial pair -> 8-byte agent-scope store -> release fence -> arrival counter (one per group)
-//     lane 0 polls the counter (relaxed, s_sleep) -> acquire fence -> every member reads the group's pairs
+//     lane = rl * CL + cl      cl < CL = k*H*W/4 float4 columns (the channel block of one sample, contiguous),
+//                              rl < RL = T / CL  row lanes; lane (rl, cl) holds samples rl, rl+RL, rl+2RL, ...
 //
-// then every member derives the same scale / zero point (same inputs, same arithmetic: deterministic), quantizes
-// what it holds in registers and streams y out.  No grid-wide barrier: only the <= ~200 workgroups of one group
-// meet, groups are contiguous in blockIdx so their members are dispatched together, and other groups' loads and
-// stores keep HBM busy meanwhile (the register file of the chip holds ~100 MB, Little's law needs ~20).
-// A group of ONE workgroup (small layers: the whole batch of a channel block fits K rows) needs no exchange.
+// i.e. K = ceil(N / RL) 16-byte loads per lane, all issued back to back (the whole tile is in flight at once),
+// consumed by the min/max reduction in arrival order; per-channel extrema are finished in LDS, every lane picks
+// up the scale / zero point of its column's channel, quantizes its registers sample by sample and streams y out
+// (stores of sample j overlap the arithmetic of sample j+1).
 //
-// Forward progress does not depend on how HIP dispatches workgroups: the wait is bounded (RES_TIMEOUT_TICKS of the
-// 100 MHz wall clock); a workgroup that gives up recomputes the extrema of its channels from x itself (exact, so
-// the result is the same bits) and raises bit 0 of the status word.  The arrival counter doubles as departure
-// counter and the last workgroup to leave a group zeroes it, so the workspace is zeroed ONCE by the caller and
-// the launch is replayable from a HIP graph.
+// It applies when a channel block of the whole batch fits the register tile: RL*K >= N with K <= 32 (T <= 512) or
+// K <= 16 (T = 1024) - at batch 64 every ResNet-50 layer with H*W <= 28*28; larger per-channel populations
+// (56x56 and 112x112 at batch 64, everything at batch 512) stay on the two-pass chain, which already streams
+// them at 6+ TB/s.
+//
+// (A variant in which several workgroups share a channel and exchange {min, max} partials inside the launch -
+// arrival counters, bounded waits - was built and measured first: see DESIGN.md "tried and rejected".)
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"
 
 namespace {
 
-#ifndef RES_POLL_RMW
-#define RES_POLL_RMW 0    // experiment: poll the arrival counter with a returning atomic instead of an sc1 load
-#endif
-#ifndef RES_K32_WAVES
-#define RES_K32_WAVES 3   // waves per SIMD the K = 32 tile is compiled for (168 VGPRs; 2 = no register cap)
-#endif
-constexpr long long RES_TIMEOUT_TICKS = 2000000;   // 20 ms of the 100 MHz constant clock
-constexpr int RES_TIMEOUT_SPINS = 1 << 20;         // second bound on the same wait (>= 64 clocks per iteration)
-constexpr int RES_GS_MAX = 512;                    // members of a group (all co-resident: capacity >= 512 workgroups)
-
 // torch.min / torch.max propagate NaN (a NaN activation poisons its channel's range, iq.py:416,423); v_min/v_max
-// return the other operand.  The hot loop therefore keeps v_min/v_max plus one unordered-compare per two elements
-// and poisons the lane's result afterwards; every merge above the lane uses these propagating forms.
+// return the other operand.  The hot loop keeps v_min/v_max plus one unordered-compare per two elements and
+// poisons the lane's result afterwards; every merge above the lane uses these propagating forms.
 __device__ __forceinline__ float pmin(float a, float b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ float pmax(float a, float b) { return (a > b || a != a) ? a : b; }
-
-__device__ __forceinline__ unsigned long long pack_pair(float mn, float mx) {
-    return (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
-}
-__device__ __forceinline__ void unpack_pair(unsigned long long p, float& mn, float& mx) {
-    mn = __uint_as_float((unsigned)(p & 0xffffffffull));
-    mx = __uint_as_float((unsigned)(p >> 32));
-}
-
-struct RBlk {
-    Blk b;
-    int group, member;
-};
-
-// blockIdx -> (group, member) -> tile.  Members of a group are consecutive workgroups.
-__device__ __forceinline__ RBlk rblk_of(const Geo& g, int Gs) {
-    RBlk r;
-    const int bid = (int)blockIdx.x;
-    r.group = bid / Gs;
-    r.member = bid - r.group * Gs;
-    int s;
-    if (g.mode == 1) {
-        const int cpc = g.HW / 4;
-        s = r.member / g.nb;
-        const int bb = r.member - s * g.nb;
-        const int c = g.cbeg + r.group;
-        r.b.c0 = c;
-        r.b.c1 = c + 1;
-        r.b.col0 = c * cpc + bb * g.w;
-        r.b.col1 = min(r.b.col0 + g.w, (c + 1) * cpc);
-    } else {
-        s = r.member;
-        r.b.c0 = g.cbeg + r.group * g.k;
-        r.b.c1 = min(g.cbeg + g.Cn, r.b.c0 + g.k);
-        r.b.col0 = (int)(((int64_t)r.b.c0 * g.HW) / 4);
-        r.b.col1 = (int)(((int64_t)r.b.c1 * g.HW) / 4);
-    }
-    r.b.n0 = (int)(((int64_t)s * g.N) / g.S);
-    r.b.n1 = (int)(((int64_t)(s + 1) * g.N) / g.S);
-    r.b.grp = s;
-    return r;
-}
-
-// per-lane accumulators -> per-channel extrema of the workgroup's tile in sh_mn / sh_mx [c1 - c0]
-template <int A>
-__device__ __forceinline__ void wg_channel_minmax(const Geo& g, const Blk& b, bool ok, const float (&mn)[A],
-                                                  const float (&mx)[A], float* l_mn, float* l_mx, float* sh_mn,
-                                                  float* sh_mx) {
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    if (g.mode == 1) {
-        float tn = ok ? mn[0] : INFINITY, tx = ok ? mx[0] : -INFINITY;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
-        if (lane == 0) { l_mn[wv] = tn; l_mx[wv] = tx; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < TPB / 64; ++i) { tn = pmin(tn, l_mn[i]); tx = pmax(tx, l_mx[i]); }
-            sh_mn[0] = tn;
-            sh_mx[0] = tx;
-        }
-        __syncthreads();
-        return;
-    }
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        l_mn[tid * A + a] = ok ? mn[a] : INFINITY;
-        l_mx[tid * A + a] = ok ? mx[a] : -INFINITY;
-    }
-    __syncthreads();
-    const int epc = g.HW * A / 4;   // LDS entries per channel
-    if (epc <= 16) {
-        for (int ch = tid; ch < b.c1 - b.c0; ch += TPB) {
-            float tn = INFINITY, tx = -INFINITY;
-            for (int e = ch * epc; e < (ch + 1) * epc; ++e) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
-            sh_mn[ch] = tn;
-            sh_mx[ch] = tx;
-        }
-    } else {
-        for (int ch = wv; ch < b.c1 - b.c0; ch += TPB / 64) {
-            float tn = INFINITY, tx = -INFINITY;
-            for (int e = ch * epc + lane; e < (ch + 1) * epc; e += 64) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
-            if (lane == 0) { sh_mn[ch] = tn; sh_mx[ch] = tx; }
-        }
-    }
-    __syncthreads();
-}
 
 template <int A>
 __device__ __forceinline__ void lane_acc(const float (&v)[4], float (&mn)[A], float (&mx)[A], bool& nan) {
@@ -149,69 +49,35 @@ __device__ __forceinline__ void lane_acc(const float (&v)[4], float (&mn)[A], fl
     }
 }
 
-// cold path (a wait timed out, or the test flag): the extrema of the group's channels straight from x, all samples
-template <int A>
-__device__ __forceinline__ void group_minmax_from_x(const float* __restrict__ x, const Geo& g, const Blk& b, float* l_mn,
-                                                 float* l_mx, float* sh_mn, float* sh_mx) {
-    const int tid = threadIdx.x;
-    float mn[A], mx[A];
-    bool nan = false;
-#pragma unroll
-    for (int a = 0; a < A; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
-    bool ok = true;
-    if (g.mode == 1) {
-        const int cpc = g.HW / 4;
-        for (int n = 0; n < g.N; ++n)
-            for (int col = tid; col < cpc; col += TPB) {
-                float v[4];
-                ldv<4>(x + (size_t)n * (size_t)g.P + ((size_t)b.c0 * cpc + col) * 4, v);
-                lane_acc<A>(v, mn, mx, nan);
-            }
-    } else {
-        const int col = b.col0 + tid;
-        ok = col < b.col1;
-        if (ok)
-            for (int n = 0; n < g.N; ++n) {
-                float v[4];
-                ldv<4>(x + (size_t)n * (size_t)g.P + (size_t)col * 4, v);
-                lane_acc<A>(v, mn, mx, nan);
-            }
-    }
-    if (A == 1 && nan) { mn[0] = NAN; mx[0] = NAN; }
-    __syncthreads();   // l_mn / l_mx may still be read by a previous reduction
-    wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
-}
-
-// ws layout: [0] status word, [64 ..) arrival/departure counter per group, then the 8-byte {min, max} pairs
-struct RWs {
-    unsigned* status;
-    unsigned* cnt;
-    unsigned long long* part;
+struct WGeo {
+    int N, C, HW, P;
+    int k;    // channels per workgroup
+    int CL;   // float4 columns of a full channel block = k*HW/4
+    int RL;   // row lanes (<= N)
 };
 
-template <int A, int K, bool SYNC>
-__global__ void __launch_bounds__(TPB, (K == 32 ? RES_K32_WAVES : 1)) k_mmq_resident(const float* __restrict__ x, float* __restrict__ y, const Geo g,
-                                                      const int Gs, const int num_bits, const int positive,
-                                                      const RWs ws, float* __restrict__ qp, float* __restrict__ mm,
-                                                      const unsigned flags) {
-    __shared__ float l_mn[TPB * A], l_mx[TPB * A];
-    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
-    __shared__ int sh_timed_out;
-    const RBlk rb = rblk_of(g, Gs);
-    const Blk& b = rb.b;
+template <int A, int T, int K>
+__global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, float* __restrict__ y, const WGeo g,
+                                                 const int num_bits, const int positive, float* __restrict__ qp,
+                                                 float* __restrict__ mm) {
+    __shared__ float l_mn[T * A], l_mx[T * A];
+    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH];   // per channel: extrema, then scale / zero point
     const int tid = threadIdx.x;
-    const int col = b.col0 + tid;
-    const bool ok = col < b.col1;
-    const int colc = ok ? col : b.col0;   // idle lanes re-read the block's first column; results discarded
-    const int nrows = b.n1 - b.n0;        // 1 .. K
-    const size_t base = (size_t)b.n0 * (size_t)g.P + (size_t)colc * 4;
+    const int c0 = (int)blockIdx.x * g.k;
+    const int c1 = min(g.C, c0 + g.k);
+    const int nch = c1 - c0;
+    const int ncols = (int)(((int64_t)nch * g.HW) / 4);
+    const int rl = tid / g.CL, cl = tid - rl * g.CL;
+    const bool active = rl < g.RL && cl < ncols;
+    const int rlc = active ? rl : 0, clc = active ? cl : 0;   // idle lanes shadow lane (0, 0); results discarded
+    const size_t colbase = ((size_t)c0 * g.HW / 4 + clc) * 4;
 
-    // ---- the tile: K 16-byte loads per lane, issued back to back (rows past the tile re-read its last row)
+    // ---- the tile: K 16-byte loads per lane, issued back to back (samples past N re-read the lane's first)
     float v[K][4];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const int r = j < nrows ? j : nrows - 1;
-        ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
+        const int n = rlc + j * g.RL;
+        ldv_nt<4>(x + (size_t)(n < g.N ? n : rlc) * (size_t)g.P + colbase, v[j]);
     }
     float mn[A], mx[A];
     bool nan = false;
@@ -220,120 +86,81 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? RES_K32_WAVES : 1)) k_mmq_resi
 #pragma unroll
     for (int j = 0; j < K; ++j) lane_acc<A>(v[j], mn, mx, nan);
     if (A == 1 && nan) { mn[0] = NAN; mx[0] = NAN; }
-    wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
-    const int nch = b.c1 - b.c0;
 
-    // ---- meet the other members of the group
-    if constexpr (SYNC) {
-        // publish: mode 1 part[c][Gs] (a channel's pairs contiguous), mode 2 part[S][C]
-        for (int ch = tid; ch < nch; ch += TPB) {
-            const size_t slot = (g.mode == 1) ? (size_t)b.c0 * Gs + rb.member : (size_t)rb.member * g.C + b.c0 + ch;
-            __hip_atomic_store(ws.part + slot, pack_pair(sh_mn[ch], sh_mx[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned* c = ws.cnt + rb.group;
-            unsigned seen = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            int timed_out = (flags & 1u) ? 1 : 0;
-            if (!timed_out && seen < (unsigned)Gs) {
-                const long long t0 = wall_clock64();
-                for (int spins = 0;; ++spins) {
-                    // every poll is a memory-side access: back off (0.1 us -> 1.7 us) so that a few hundred waiting
-                    // workgroups do not eat the bandwidth the others need to get here
-                    if (spins < 4) __builtin_amdgcn_s_sleep(4);
-                    else if (spins < 12) __builtin_amdgcn_s_sleep(16);
-                    else __builtin_amdgcn_s_sleep(64);
-#if RES_POLL_RMW
-                    seen = __hip_atomic_fetch_add(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-                    seen = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-                    if (seen >= (unsigned)Gs) break;
-                    // two independent bounds: the constant-rate clock, and a plain iteration count
-                    if (wall_clock64() - t0 > RES_TIMEOUT_TICKS || spins > RES_TIMEOUT_SPINS) { timed_out = 1; break; }
-                }
+    // ---- per-channel extrema: lanes -> LDS -> fold the row lanes onto row 0 -> one wave (or lane) per channel
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        l_mn[tid * A + a] = active ? mn[a] : INFINITY;
+        l_mx[tid * A + a] = active ? mx[a] : -INFINITY;
+    }
+    __syncthreads();
+    if (tid < ncols) {
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float tn = l_mn[tid * A + a], tx = l_mx[tid * A + a];
+            for (int r = 1; r < g.RL; ++r) {
+                tn = pmin(tn, l_mn[(r * g.CL + tid) * A + a]);
+                tx = pmax(tx, l_mx[(r * g.CL + tid) * A + a]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            // leave: the last of the 2*Gs increments re-arms the counter for the next launch
-            const unsigned left = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left == 2u * (unsigned)Gs - 1u) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (timed_out) atomicOr(ws.status, 1u);
-            sh_timed_out = timed_out;
-        }
-        __syncthreads();
-        if (sh_timed_out) {
-            group_minmax_from_x<A>(x, g, b, l_mn, l_mx, sh_mn, sh_mx);
-        } else if (g.mode == 1) {
-            float tn = INFINITY, tx = -INFINITY;
-            // after the acquire: plain loads (this CU's L1 was invalidated, the pairs were written through)
-            const unsigned long long* pp = ws.part + (size_t)b.c0 * Gs;
-            for (int m = tid; m < Gs; m += TPB) {
-                float a, c;
-                unpack_pair(pp[m], a, c);
-                tn = pmin(tn, a);
-                tx = pmax(tx, c);
-            }
-            const float one_n[1] = {tn}, one_x[1] = {tx};
-            // reuse the one-channel reduction (A = 1 form)
-            wg_channel_minmax<1>(g, b, true, one_n, one_x, l_mn, l_mx, sh_mn, sh_mx);
-        } else {
-            for (int ch = tid; ch < nch; ch += TPB) {
-                float tn = INFINITY, tx = -INFINITY;
-                const unsigned long long* pp = ws.part + b.c0 + ch;
-#pragma unroll 8
-                for (int s = 0; s < Gs; ++s) {
-                    float a, c;
-                    unpack_pair(pp[(size_t)s * g.C], a, c);
-                    tn = pmin(tn, a);
-                    tx = pmax(tx, c);
-                }
-                sh_mn[ch] = tn;
-                sh_mx[ch] = tx;
-            }
-            __syncthreads();
+            l_mn[tid * A + a] = tn;
+            l_mx[tid * A + a] = tx;
         }
     }
+    __syncthreads();
+    const int epc = g.HW * A / 4;   // LDS entries per channel in row 0
+    const int wv = tid >> 6, lane = tid & 63;
+    if (epc <= 16) {
+        for (int ch = tid; ch < nch; ch += T) {
+            float tn = INFINITY, tx = -INFINITY;
+            for (int e = ch * epc; e < (ch + 1) * epc; ++e) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
+            sh_mn[ch] = tn;
+            sh_mx[ch] = tx;
+        }
+    } else {
+        for (int ch = wv; ch < nch; ch += T / 64) {
+            float tn = INFINITY, tx = -INFINITY;
+            for (int e = ch * epc + lane; e < (ch + 1) * epc; e += 64) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
+            if (lane == 0) { sh_mn[ch] = tn; sh_mx[ch] = tx; }
+        }
+    }
+    __syncthreads();
 
-    // ---- scale / zero point of the owned channels (iq.py:559-572), identical in every member
+    // ---- scale / zero point of the owned channels (iq.py:559-572)
     const float qm = (float)((1u << num_bits) - 1u);
-    for (int ch = tid; ch < nch; ch += TPB) {
-        const float cmn = sh_mn[ch], cmx = sh_mx[ch];
+    float p_sc = 0.f, p_zp = 0.f;
+    if (tid < nch) {
+        const float cmn = sh_mn[tid], cmx = sh_mx[tid];
         const float offset = positive ? 0.f : cmn;
         const float delta = cmx - offset;
-        float sc = delta / qm;
-        sc = (sc < 1e-8f) ? 1e-8f : sc;
-        const float zp = rintf(0.f - offset / sc);
-        sh_sc[ch] = sc;
-        sh_zp[ch] = zp;
-        if (rb.member == 0) {
-            const int c = b.c0 + ch;
-            qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
-            qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
-            qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
-            if (mm) { mm[c] = cmn; mm[g.C + c] = cmx; }
-        }
+        p_sc = delta / qm;
+        p_sc = (p_sc < 1e-8f) ? 1e-8f : p_sc;
+        p_zp = rintf(0.f - offset / p_sc);
+        const int c = c0 + tid;
+        qp[(size_t)CNNQ_QP_SCALE * g.C + c] = p_sc;
+        qp[(size_t)CNNQ_QP_ZP * g.C + c] = p_zp;
+        qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
+        if (mm) { mm[c] = cmn; mm[g.C + c] = cmx; }
     }
+    if (tid < nch) { sh_mn[tid] = p_sc; sh_mx[tid] = p_zp; }   // own entry only: no hazard with the reads above
     __syncthreads();
     float sc[A], zp[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-        const unsigned e = (unsigned)colc * 4u + (unsigned)a;
-        const int ch = (int)(e / (unsigned)g.HW) - b.c0;
-        sc[a] = sh_sc[ch];
-        zp[a] = sh_zp[ch];
+        const int ch = (int)(((unsigned)clc * 4u + (unsigned)a) / (unsigned)g.HW);
+        sc[a] = sh_mn[ch];
+        zp[a] = sh_mx[ch];
     }
 
-    // ---- Q/DQ out of the registers
+    // ---- Q/DQ out of the registers, sample by sample
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        if (j < nrows) {
-            float o[4], cd;
+        const int n = rlc + j * g.RL;
+        float o[4], cd;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
-            if (ok) stv_nt<4>(y + base + (size_t)j * (size_t)g.P, o);
-        }
+        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
+        if (active && n < g.N) stv_nt<4>(y + (size_t)n * (size_t)g.P + colbase, o);
     }
 }
 

@@ -165,50 +165,25 @@ def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None, reverse=False
     return (y, codes) if want_codes else y
 
 
-_RES_WS = {}
-
-
-def _resident_workspace(x, nbytes):
-    """The zeroed-once exchange workspace of cnnq_pc_minmax_qdq_resident, one per (device, stream): launches on
-    one stream are ordered, so they can share it; the kernel re-arms its counters."""
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-    ws = _RES_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(int(nbytes), 4 << 20), dtype=torch.uint8, device=x.device)
-        _RES_WS[key] = ws
-    return ws
-
-
-def resident_status(x):
-    """Status word of this stream's resident workspace (synchronises): bit 0 = some wait timed out and its
-    workgroup recomputed the extrema from x (results are unaffected)."""
-    ws = _RES_WS.get((x.device.index, torch.cuda.current_stream(x.device).cuda_stream))
-    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
-
-
-def minmax_qdq_resident(x, N, C, HW, num_bits, positive=False, out=None, want_parts=False, flags=0):
-    """Config 2 in ONE launch and ONE read of x (cnnq_pc_minmax_qdq_resident): the bits of minmax_qdq_fused at
-    8 instead of 12 bytes per element.  Returns None when the shape has no resident kernel (unaligned, or
-    H*W % 4 != 0 without a straddling layout) - the caller then takes the three-launch chain."""
+def minmax_qdq_resident(x, N, C, HW, num_bits, positive=False, out=None, want_parts=False):
+    """Config 2 in ONE launch and ONE read of x (cnnq_pc_minmax_qdq_resident): the bits of the three-launch chain
+    at 8 instead of 12 bytes per element.  Returns None when the shape has no resident kernel (a channel's batch
+    population does not fit a workgroup's registers, unaligned pointers, H*W % 4 != 0 without a straddling
+    layout) - the caller then takes the chain."""
     lib = L.load()
     x = _dev_f32(x, 'x')
-    nbytes = lib.cnnq_pc_resident_workspace(N, C, HW)
-    if nbytes == 0:
-        return None
     y = _out_like(x, out)
-    ws = _resident_workspace(x, nbytes)
-    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device)
-    mm = torch.empty((2, C), dtype=torch.float32, device=x.device) if want_parts else None
-    rc = lib.cnnq_pc_minmax_qdq_resident(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(ws),
-                                         _ptr(qp), _ptr(mm), int(flags), _stream(x))
+    qp = torch.empty((L.NQP + 2, C), dtype=torch.float32, device=x.device)     # parameters + {min, max} rows
+    rc = lib.cnnq_pc_minmax_qdq_resident(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(qp),
+                                         _ptr(qp[L.NQP:]) if want_parts else None, _stream(x))
     if rc == L.ENOTSUP:
         return None
     L.check(rc, 'cnnq_pc_minmax_qdq_resident')
     if want_parts:
         stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
-        stats[L.STAT_MIN] = mm[0]
-        stats[L.STAT_MAX] = mm[1]
-        return y, dict(stats=stats, qp=qp, diag=None)
+        stats[L.STAT_MIN] = qp[L.NQP]
+        stats[L.STAT_MAX] = qp[L.NQP + 1]
+        return y, dict(stats=stats, qp=qp[:L.NQP], diag=None)
     return y
 
 

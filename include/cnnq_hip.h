@@ -207,26 +207,19 @@ int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int 
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                        float* pmm, float* qp, uint8_t* codes, uint64_t* hist, void* stream);
 
-/* Config 2 in ONE launch that reads x ONCE (8 instead of 12 bytes per element): the same arithmetic as
- * cnnq_pc_minmax_qdq (iq.py:409-451 + 557-603, bit allocation off), the same bits.  Every workgroup keeps its
- * share of x in registers between the statistics and the Q/DQ; workgroups that hold pieces of the same channels
- * exchange their {min, max} pairs through `ws` (agent-scope stores, one arrival counter per channel group, a
- * bounded wait that falls back to recomputing the extrema from x - never a deadlock, never different bits).
- *   ws   cnnq_pc_resident_workspace(N, C, HW) bytes, 8-byte aligned, ZEROED ONCE by the caller before its first
- *        use (the kernel re-arms it); one workspace must not be used by two launches that can run concurrently.
- *        Word 0 is a status word: bit 0 is set when a wait timed out (diagnostic only, results are unaffected).
+/* Config 2 in ONE launch that reads x ONCE (8 instead of 12 bytes per element, one launch boundary instead of
+ * three): the same arithmetic as cnnq_pc_minmax_qdq (iq.py:409-451 + 557-603, bit allocation off), the same bits.
+ * A workgroup owns whole channels for the whole batch and keeps them in registers between the statistics and the
+ * Q/DQ; nothing is exchanged between workgroups and no workspace is needed.
  *   qp   out: qp[CNNQ_NQP][C].   mm: optional out [2][C] = the per-channel min and max.
- *   flags  bit 0: take the recompute path unconditionally (tests).
- * Needs 16-byte aligned x and y and H*W % 4 == 0 (or a straddling layout such as 7x7 with C*H*W % 4 == 0);
- * returns CNNQ_ENOTSUP otherwise (nothing enqueued: call cnnq_pc_minmax_qdq).  cnnq_pc_resident_describe fills
- * out[8] = {A, K, mode, S, column blocks, workgroups per group, groups, workgroups} (tests, tools). */
-size_t cnnq_pc_resident_workspace(int64_t N, int64_t C, int64_t HW);
+ * Applies when one channel's batch population fits a workgroup's registers (N*H*W up to ~50 K elements per
+ * channel: e.g. 64 x 28x28) with 16-byte aligned x and y and H*W % 4 == 0 (or a straddling layout such as 7x7
+ * with C*H*W % 4 == 0); returns CNNQ_ENOTSUP otherwise (nothing enqueued: call cnnq_pc_minmax_qdq).
+ * cnnq_pc_resident_describe fills out[8] = {A, threads per workgroup, K loads per lane, channels per workgroup,
+ * float4 columns, row lanes, workgroups, 0} or returns CNNQ_ENOTSUP (tests, tools). */
 int cnnq_pc_resident_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                                void* ws, float* qp, float* mm, unsigned flags, void* stream);
-
-int cnnq_ws_alloc_uncached(size_t bytes, void** out);
-int cnnq_ws_free(void* p);
+                                float* qp, float* mm, void* stream);
 
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace
