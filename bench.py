@@ -4,27 +4,34 @@
 Workload (BASELINE.json configs[1]): every conv activation of one ResNet-50 forward at batch 512
 (53 tensors, 5.69 G fp32 elements), quantized per channel to int4 with
 dynamic min/max statistics (`-pcq_a --qtype int4`; half-range layers clamp the minimum to 0).
-One "step" = the whole set once: per tensor  statistics pass (4 B/elem) -> parameters ->
-fused Q/DQ (4 B read + 4 B write per element).  Inputs are synthetic per-channel Laplace
-activations generated on the device (seed 12345) and are resident in HBM before the timed
-region; all 53 inputs and 53 outputs are distinct buffers (45.6 GB), so nothing is re-read from
-a cache across layers.
+One "step" = the whole set once.  Inputs are synthetic per-channel Laplace activations generated
+on the device (seed 12345), resident in HBM before the timed region; all inputs and outputs are
+distinct buffers, so nothing is re-read from a cache across layers.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: one process per GPU, each rank holds a batch-512 shard of a global batch of 512*N
-(weak scaling); per-channel statistics are made global with one all_gather of fp64 moment records
-per tensor (RCCL over xGMI), the Q/DQ itself needs no communication.
+Multi-GPU (inference_sim.py:196-200): ONE batch of 512 is sharded over the N ranks,
+512/N samples per GPU (`"scaling": "strong"`; `--scaling weak` gives every rank its own 512);
+per-channel statistics are made global with one small all_gather per tensor (RCCL over xGMI),
+the Q/DQ itself needs no communication.
 
-Prints ONE JSON line (rank 0).  `value` = elements/s of the whole job; `roofline` = the Q/DQ
-kernel's algorithmic bytes / its measured launch time against the 8 TB/s HBM3E peak;
-`cpu_baseline` = the oracle (CPU restatement of the reference's op chain) timed on this host.
+Per tensor the product entry point (ops.act_qdq_per_channel) picks
+  * the register-resident single launch (k_mmq_whole: 4 B read + 4 B write per element) when a
+    channel's batch population fits a workgroup - the small-H*W layers of a batch <= 64 shard;
+  * otherwise the chain k_minmax (4 B read) -> k_minmax_params -> k_qdq (4 B read + 4 B write).
+
+Prints ONE JSON line (rank 0): `value` = elements/s of the whole job; `roofline` = the dominant
+kernel's algorithmic bytes / its measured launch time (HIP events on the launch stream) against
+the 8 TB/s HBM3E peak; `cpu_baseline` = the oracle (CPU restatement of the reference's op chain)
+timed on this host; `other_configs` = BASELINE configs 1, 3, 4, 5 timed the same way; `verified`
+= the outputs of the timed steps were checked after the timed region.
 """
 import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -40,10 +47,11 @@ RESNET50_CONV_OUTPUTS = [
     (256, 28, True, 1), (1024, 14, False, 7), (128, 28, True, 7), (512, 14, True, 1), (2048, 7, False, 4),
     (256, 14, True, 11), (512, 7, True, 5),
 ]
+VGG16_CONV_OUTPUTS = [(64, 224, 2), (128, 112, 2), (256, 56, 3), (512, 28, 3), (512, 14, 3)]   # (C, H=W, layers)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_QDQ = 8                  # fused Q/DQ: 4 B read + 4 B write per element
+BYTES_QDQ = 8                  # fused Q/DQ pass, and the resident single launch: 4 B read + 4 B write per element
 BYTES_STATS = 4                # statistics pass: one read
-BYTES_PATH = 12                # dynamic min/max + Q/DQ, SURVEY.md 8(d3)
+BYTES_PATH = 12                # dynamic min/max + Q/DQ as SURVEY.md 8(d3) accounts it
 
 
 def laplace_activation(shape, gen_seed, device):
@@ -80,20 +88,31 @@ def run_step(ops, layers, group):
 
 def time_kernel_classes(layers):
     """Device time per kernel class, measured live with HIP events recorded on the launch stream
-    between the launches of ONE pass that issues exactly the sequence cnnq_pc_minmax_qdq issues
+    between the launches of ONE pass that issues exactly the sequence the product path issues
     (so cache state is the real one), one event per launch boundary so that each class is the
     duration of that kernel alone, as rocprofv3 --kernel-trace reports it.  Returns
-    {class: (seconds, launches)}."""
+    {class: [seconds, launches, elements]}."""
     import ctypes
     from cnn_quantization_amd import _lib
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    resident_ok = os.environ.get('CNNQ_RESIDENT', '1') != '0'
     recs = []
+    d = (ctypes.c_int32 * 8)()
     for L in layers:
         x, y, N, C, HW = L['x'], L['y'], L['N'], L['C'], L['HW']
         G = lib.cnnq_pc_groups(N, C, HW, 1)
         pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
         qp = torch.empty((3, C), dtype=torch.float32, device=x.device)
+        n = x.numel()
+        if resident_ok and lib.cnnq_pc_resident_describe(N, C, HW, d) == 0:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e[0].record()
+            _lib.check(lib.cnnq_pc_minmax_qdq_resident(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']),
+                                                       qp.data_ptr(), None, st), 'resident')
+            e[1].record()
+            recs.append((n, [('k_mmq_whole', e[0], e[1])]))
+            continue
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         _lib.check(lib.cnnq_pc_minmax(x.data_ptr(), N, C, HW, pmm.data_ptr(), st), 'minmax')
@@ -102,37 +121,212 @@ def time_kernel_classes(layers):
         e[2].record()
         _lib.check(lib.cnnq_pc_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, qp.data_ptr(), None, None, 1, st), 'qdq')
         e[3].record()
-        recs.append(e)
+        recs.append((n, [('k_minmax', e[0], e[1]), ('k_minmax_params', e[1], e[2]), ('k_qdq', e[2], e[3])]))
     torch.cuda.synchronize()
-    t_mm = sum(e[0].elapsed_time(e[1]) for e in recs) * 1e-3
-    t_p = sum(e[1].elapsed_time(e[2]) for e in recs) * 1e-3
-    t_q = sum(e[2].elapsed_time(e[3]) for e in recs) * 1e-3
-    return {'k_minmax': (t_mm, len(recs)), 'k_minmax_params': (t_p, len(recs)), 'k_qdq': (t_q, len(recs))}
+    out = {}
+    for n, evs in recs:
+        for name, a, b in evs:
+            o = out.setdefault(name, [0., 0, 0])
+            o[0] += a.elapsed_time(b) * 1e-3
+            o[1] += 1
+            o[2] += n
+    return out
 
 
-def cpu_baseline(batch_sample=32, reps=3):
-    """The oracle (op-for-op CPU restatement of iq.py:409-451) on the same layer set at a small
-    batch: ~10-30 s of CPU work on all host cores."""
-    from oracle import quant_oracle as O
-    threads = torch.get_num_threads()
-    xs = []
-    g = torch.Generator().manual_seed(12345)
-    elems = 0
-    for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
-        x = torch.randn((batch_sample, C, hw, hw), generator=g)
-        xs.append((x, half, count))
-        elems += x.numel() * count
+KERNEL_BYTES = {'k_qdq': (BYTES_QDQ, 'fused per-channel Q/DQ pass, 8 algorithmic B/elem'),
+                'k_minmax': (BYTES_STATS, 'per-channel exact min/max pass, 4 B/elem'),
+                'k_mmq_whole': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, 8 algorithmic B/elem'),
+                'k_minmax_params': (0, 'per-channel parameter table (latency-bound, a few KB)')}
+
+
+def roofline_objects(layers, batch, world):
+    time_kernel_classes(layers)                       # warm
+    kcs = [time_kernel_classes(layers) for _ in range(3)]
+    objs = {}
+    for name in kcs[0]:
+        t = min(k[name][0] for k in kcs)
+        launches, elems = kcs[0][name][1], kcs[0][name][2]
+        by, what = KERNEL_BYTES[name]
+        gbs = elems * by / t / 1e9
+        objs[name] = {'bound': 'hbm', 'kernel': '%s (%s)' % (name, what), 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                      'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None, 'launches_per_step': launches,
+                      'avg_launch_ms': t * 1e3 / launches, 'bytes_per_launch': elems * by / launches,
+                      'time_per_step_ms': t * 1e3}
+    # HBM bytes from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command and
+    # committed under profiles/ (never measured inside a timed run); attached only to the configuration they
+    # were measured on
+    pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                rec = json.load(f)
+            for name, o in objs.items():
+                k = '%s@b%d' % (name, batch)
+                if world == 1 and k in rec.get('bytes_per_launch', {}):
+                    o['traffic'] = rec['bytes_per_launch'][k]
+                    o['traffic_unit'] = 'bytes per launch'
+                    o['traffic_source'] = rec.get('source', 'profiles/r02_pmc_traffic.json')
+        except (OSError, ValueError):
+            pass
+    dominant = max((n for n in objs if KERNEL_BYTES[n][0]), key=lambda n: objs[n]['time_per_step_ms'])
+    return dominant, objs
+
+
+def verify_outputs(ops, layers):
+    """After the timed region: the buffers the timed steps wrote are checked on the largest tensor and on the
+    largest resident-kernel tensor - extrema against torch's own reductions, codes within [0, 15], y equal to
+    (code - zp) * scale bit for bit, |x - y| <= scale / 2 inside the range, and equal to a second run that also
+    returns its parameters."""
+    from cnn_quantization_amd import _lib as Lb
+    import ctypes
+    lib = Lb.load()
+    d = (ctypes.c_int32 * 8)()
+    big = max(layers, key=lambda L: L['x'].numel())
+    res = [L for L in layers if lib.cnnq_pc_resident_describe(L['N'], L['C'], L['HW'], d) == 0]
+    picks = [big] + ([max(res, key=lambda L: L['x'].numel())] if res else [])
+    ok = True
+    for L in picks:
+        x, y, C = L['x'], L['y'], L['C']
+        y2, parts = ops.act_qdq_per_channel(x, 4, positive=L['half'], want_parts=True)
+        qp, st = parts['qp'], parts['stats']
+        sc, zp = qp[0].view(1, C, 1, 1), qp[1].view(1, C, 1, 1)
+        ok = ok and bool(torch.equal(y2, y))
+        ok = ok and bool(torch.equal(st[1], x.amax(dim=(0, 2, 3)))) and bool(torch.equal(st[0], x.amin(dim=(0, 2, 3))))
+        del y2
+        codes = torch.round(y / sc + zp)
+        ok = ok and float(codes.min()) >= 0 and float(codes.max()) <= 15
+        ok = ok and bool(torch.equal((codes - zp) * sc, y))
+        del codes
+        err = (x - y).abs_().sub_(0.5001 * sc)
+        if L['half']:
+            err = err.masked_fill_(x < 0, 0.)          # below the half range everything clamps to 0
+        ok = ok and float(err.max()) <= 0.
+        del err
+    return bool(ok)
+
+
+def timed_best(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
     best = None
     for _ in range(reps):
         t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def other_configs(ops, device, batch):
+    """BASELINE.json configs 1, 3, 4, 5 on one GPU, inputs resident, best of 3 wall-clock passes bracketed by
+    synchronisation; algorithmic bytes per element as SURVEY.md 8(d3)."""
+    def obj(elems, t, bpe, what):
+        gbs = elems * bpe / t / 1e9
+        return {'workload': what, 'ms': t * 1e3, 'value': elems / t, 'unit': 'elements/s',
+                'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                             'algorithmic_bytes_per_element': bpe, 'traffic': None}}
+    out = {}
+    xs = [laplace_activation((32, 64, 112, 112), 1 + i, device) for i in range(16)]
+    t = timed_best(lambda: [ops.minmax_qdq_per_tensor(x, 8, avg_over_batch=True) for x in xs])
+    out['config1'] = obj(xs[0].numel() * 16, t, 12, 'per-tensor int8 GEMMLOWP Q/DQ with dynamic min/max on 16 distinct '
+                         '[32,64,112,112] tensors (%.1f us per tensor)' % (t / 16 * 1e6))
+    del xs
+    layers, seed = [], 100
+    for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
+        for _ in range(count):
+            layers.append((laplace_activation((batch, C, hw, hw), seed, device), half))
+            seed += 1
+    elems = sum(x.numel() for x, _ in layers)
+    ys = [torch.empty_like(x) for x, _ in layers]
+    t = timed_best(lambda: [ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, out=y)
+                            for (x, half), y in zip(layers, ys)])
+    out['config3'] = obj(elems, t, 16, 'ResNet-50 b%d, per-channel int4 + ACIQ laplace + bit allocation, dynamic statistics '
+                         '(-c laplace -baa)' % batch)
+    del ys
+    t = timed_best(lambda: [ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True,
+                                         need_relu=True) for x, _ in layers])
+    out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics' % batch)
+    del layers
+    torch.cuda.empty_cache()
+    vl, seed = [], 500
+    for (C, hw, count) in VGG16_CONV_OUTPUTS:
+        for _ in range(count):
+            vl.append(laplace_activation((batch, C, hw, hw), seed, device))
+            seed += 1
+    elems = sum(x.numel() for x in vl)
+    t = timed_best(lambda: [ops.mid_tread_qdq(x, 4, clip=True, sym=False, want_entropy=True) for x in vl], reps=2)
+    out['config5'] = obj(elems, t, 16, 'VGG-16 b%d, mid-tread per-channel W4A4 + ACIQ + bin allocation + entropy (-mtq -me)' % batch)
+    del vl
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(batch_sample=8, reps=5):
+    """The oracle (op-for-op CPU restatement of the reference's chain, iq.py:409-451 / 557-603) on the host of
+    this box: the same per-channel Laplace inputs as the GPU leg at a small batch, thread counts 1 / 8 / 32 / 64
+    (capped at the host's CPUs; torch's intra-op pool with all 256 hardware threads of the GPU box runs this chain of
+    small ops 400x SLOWER than one thread - measured 1.3 M elements/s - so "all" is not in the sweep), median of
+    `reps` passes each after a warm-up pass; plus BASELINE config 1 on exactly [32,64,112,112]."""
+    from oracle import quant_oracle as O
+    ncpu = os.cpu_count() or 1
+    xs, seed, elems = [], 12345, 0
+    for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
+        x = laplace_activation((batch_sample, C, hw, hw), seed, torch.device('cpu'))
+        xs.append((x, half, count))
+        elems += x.numel() * count
+        seed += count
+    x1 = laplace_activation((32, 64, 112, 112), 1, torch.device('cpu'))
+
+    def cfg2():
         for x, half, count in xs:
             for _ in range(count):
                 O.act_per_channel_qdq(x, 4, half_range=half)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return dict(value=elems / best, unit='elements/s', cores=threads, kind='port',
-                sample='oracle.act_per_channel_qdq over the 53 ResNet-50 conv outputs at batch %d '
-                       '(%.1f M elements), best of %d, torch threads=%d' % (batch_sample, elems / 1e6, reps, threads))
+
+    def cfg1():
+        O.gemmlowp_minmax_qdq(x1, 8, tag='activation')
+
+    def median_time(fn):
+        t0 = time.perf_counter()
+        fn()
+        if time.perf_counter() - t0 > 4.:          # a pathological thread count: one more pass is enough to say so
+            t0 = time.perf_counter()
+            fn()
+            return time.perf_counter() - t0
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    saved = torch.get_num_threads()
+    sweep, sweep1 = {}, {}
+    for th in sorted({1, min(8, ncpu), min(32, ncpu), min(64, ncpu)}):
+        torch.set_num_threads(th)
+        sweep[th] = elems / median_time(cfg2)
+        sweep1[th] = x1.numel() / median_time(cfg1)
+    torch.set_num_threads(saved)
+    best = max(sweep, key=sweep.get)
+    return dict(value=sweep[best], unit='elements/s', cores=best, kind='port', cpu=cpu_model(), host_cpus=ncpu,
+                one_thread=sweep[1], by_threads={str(k): v for k, v in sweep.items()},
+                config1={'value': max(sweep1.values()), 'cores': max(sweep1, key=sweep1.get), 'one_thread': sweep1[1],
+                         'by_threads': {str(k): v for k, v in sweep1.items()},
+                         'sample': 'oracle.gemmlowp_minmax_qdq (per-tensor int8) on one [32,64,112,112] tensor'},
+                sample='oracle.act_per_channel_qdq over the 53 ResNet-50 conv outputs at batch %d (%.1f M elements per '
+                       'pass), the GPU leg\'s per-channel Laplace inputs, median of %d passes per thread count after '
+                       'a warm-up pass; value = the best thread count' % (batch_sample, elems / 1e6, reps))
 
 
 def main():
@@ -140,8 +334,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (BASELINE config: 512)')
+    ap.add_argument('--batch', type=int, default=512, help='GLOBAL batch of the forward (BASELINE config: 512)')
+    ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong',
+                    help='strong: the one batch is sharded, batch/N per GPU (SURVEY 8 e1); weak: every GPU its own batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a HIP graph (single GPU only)')
+    ap.add_argument('--force-exchange', action='store_true',
+                    help='single GPU: run the multi-GPU launch sequence with a 1-rank RCCL group (a self all_gather per '
+                         'tensor) - measures what the collective costs on this box')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -154,17 +355,26 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     group = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29577')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.force_exchange:
+        os.environ['CNNQ_FORCE_EXCHANGE'] = '1'
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from cnn_quantization_amd import ops, _lib
+    from cnn_quantization_amd import distributed as D
     _lib.load()                                         # fail loudly if the HIP library is missing
-    layers = build_workload(args.batch, device, seed=12345 + 1000 * rank)    # every rank its own batch shard
+    if args.scaling == 'strong':
+        n0, n1 = D.shard_batch(args.batch, rank, world)
+        per_rank = n1 - n0
+    else:
+        per_rank = args.batch
+    layers = build_workload(per_rank, device, seed=12345 + 1000 * rank)    # every rank its own samples
     elems = sum(L['x'].numel() for L in layers)
     torch.cuda.synchronize()
 
@@ -173,64 +383,74 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = lambda: run_step(ops, layers, group)       # noqa: E731
+    if args.graph:
+        assert world == 1 and not args.force_exchange, '--graph is a single-GPU option'
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run_step(ops, layers, group)               # workspaces of this stream exist before the capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                run_step(ops, layers, group)
+        torch.cuda.current_stream().wait_stream(side)
+        step = graph.replay
     for _ in range(args.warmup):
-        run_step(ops, layers, group)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step(ops, layers, group)
+        step()
     barrier()
     dt = time.perf_counter() - t0
+    total_elems = elems
     if world > 1:
-        t = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, float(elems)], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, total_elems = float(tmax[0].item()), int(t[1].item())
     ms_per_step = dt * 1e3 / args.steps
-    from cnn_quantization_amd import distributed as D
-    exchange_name = 'none (1 GPU)' if world == 1 else (
-        'peer-to-peer stores over xGMI (CNNQ_P2P_EXCHANGE=1, verified against the collective)'
-        if D.p2p_exchange(group) is not None else '%s all_gather' % ('RCCL' if backend == 'nccl' else backend))
-    if world > 1 and D.p2p_exchange(group) is not None and not D.p2p_exchange(group).healthy():
-        exchange_name += ' - UNHEALTHY: a wait timed out, results of this run are invalid'
-    value = elems * world * args.steps / dt
+    if world == 1 and not args.force_exchange:
+        exchange_name = 'none (1 GPU)'
+    elif D.p2p_exchange(group) is not None:
+        exchange_name = 'peer-to-peer stores over xGMI (CNNQ_P2P_EXCHANGE=1, verified against the collective)'
+        if not D.p2p_exchange(group).healthy():
+            exchange_name += ' - UNHEALTHY: a wait timed out, results of this run are invalid'
+    else:
+        exchange_name = '%s all_gather of the per-channel {min, max} records, one per tensor%s' % (
+            'RCCL' if backend == 'nccl' else backend, ' (forced on a 1-rank group)' if args.force_exchange else '')
+    value = total_elems * args.steps / dt
 
-    # roofline of the dominant kernel (fused Q/DQ), measured live with HIP events on its stream
-    time_kernel_classes(layers)                       # warm
-    kc = [time_kernel_classes(layers) for _ in range(3)]
-    t_qdq = min(k['k_qdq'][0] for k in kc)
-    t_stats = min(k['k_minmax'][0] for k in kc)
-    n_launch = kc[0]['k_qdq'][1]
-    qdq_gbs = elems * BYTES_QDQ / t_qdq / 1e9
-    stats_gbs = elems * BYTES_STATS / t_stats / 1e9
+    verified = verify_outputs(ops, layers)
+    dominant, objs = roofline_objects(layers, per_rank, world)
     out = {
         'metric': 'activation elements/sec (and % HBM peak) for per-channel int4 Q/DQ, ResNet-50 b512',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'ResNet-50 b%d conv activations (53 tensors, %.2f G elements per GPU), per-channel '
-                               'int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (args.batch, elems / 1e9),
-                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+        'config': {'workload': 'ResNet-50 b%d conv activations (53 tensors, %.2f G elements in the job, %.2f G per GPU), '
+                               'per-channel int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (
+                                   args.batch * (world if args.scaling == 'weak' else 1), total_elems / 1e9, elems / 1e9),
+                   'per_gpu_batch': per_rank, 'global_batch': args.batch * (world if args.scaling == 'weak' else 1),
                    'parallelism': 'batch-sharded dp%d, per-channel stats all_gather' % world,
-                   'exchange': exchange_name},
+                   'exchange': exchange_name, 'launch': 'hip graph replay' if args.graph else 'eager'},
+        'verified': verified,
         'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
-        'roofline': {'bound': 'hbm', 'kernel': 'k_qdq (fused per-channel Q/DQ, 8 algorithmic B/elem)',
-                     'achieved': qdq_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': qdq_gbs / HBM_PEAK_GBS,
-                     'traffic': 864.3e6 if args.batch == 512 else None, 'traffic_unit': 'bytes per launch',
-                     'traffic_source': 'rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same '
-                                       'command; committed in profiles/r01_pmc_summary.md (not re-measured live)',
-                     'launches_per_step': n_launch, 'avg_launch_ms': t_qdq * 1e3 / n_launch,
-                     'bytes_per_launch': elems * BYTES_QDQ / n_launch},
-        'roofline_stats': {'bound': 'hbm', 'kernel': 'k_minmax (per-channel exact min/max, 4 B/elem)',
-                           'achieved': stats_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': stats_gbs / HBM_PEAK_GBS, 'launches_per_step': n_launch,
-                           'avg_launch_ms': t_stats * 1e3 / n_launch},
+        'path_note': '12 B/elem is SURVEY 8(d3)\'s accounting (statistics read + Q/DQ read + write); layers that run '
+                     'the resident single launch move 8 B/elem, so this fraction can exceed what a 12 B path could reach',
+        'roofline': objs[dominant],
+        'roofline_other_kernels': {k: v for k, v in objs.items() if k != dominant},
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.force_exchange:
+            if not args.no_other_configs:
+                out['other_configs'] = other_configs(ops, device, args.batch)
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

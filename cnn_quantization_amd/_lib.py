@@ -50,6 +50,8 @@ SIGNATURES = {
     'cnnq_pc_minmax_qdq': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
     'cnnq_pc_resident_describe': (_I, [_L, _L, _L, ctypes.POINTER(ctypes.c_int32)]),
     'cnnq_pc_minmax_qdq_resident': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P]),
+    'cnnq_pc_minmax_qdq_workspace': (ctypes.c_size_t, [_L, _L, _L]),
+    'cnnq_pc_minmax_qdq_auto': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _I, _P]),
     'cnnq_pc_aciq_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_aciq_qdq': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),

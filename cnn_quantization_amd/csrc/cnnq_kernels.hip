@@ -299,6 +299,28 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
     return launch_whole(x, y, p, num_bits, positive ? 1 : 0, qp, mm, (hipStream_t)stream);
 }
 
+// Config 2 behind ONE call and ONE caller workspace: the resident single launch when the shape has one, the
+// three-launch chain otherwise.  ws layout (floats): qp[CNNQ_NQP][C], mm[2][C] (resident only), pmm[G][2][C].
+size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW) {
+    const int g1 = cnnq_pc_groups(N, C, HW, 1), g0 = cnnq_pc_groups(N, C, HW, 0);
+    const int G = g1 > g0 ? g1 : g0;
+    if (G <= 0) return 0;
+    return ((size_t)CNNQ_NQP + 2 + 2 * (size_t)G) * (size_t)C * sizeof(float);
+}
+
+int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                            float* ws, int allow_resident, void* stream) {
+    if (!x || !y || !ws || num_bits < 1 || num_bits > 8 || C <= 0) return CNNQ_EINVAL;
+    float* qp = ws;
+    float* mm = ws + (size_t)CNNQ_NQP * C;
+    float* pmm = mm + 2 * (size_t)C;
+    if (allow_resident) {
+        const int rc = cnnq_pc_minmax_qdq_resident(x, y, N, C, HW, num_bits, positive, qp, mm, stream);
+        if (rc != CNNQ_ENOTSUP) return rc;
+    }
+    return cnnq_pc_minmax_qdq(x, y, N, C, HW, num_bits, positive, pmm, qp, nullptr, nullptr, stream);
+}
+
 // The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B
 // when b is needed, merge, parameters (ACIQ clipping, bit allocation, scale / zero point), fused Q/DQ - six
 // launches, one host call, one caller workspace.  ws layout (doubles first): part[G][NMOM][C], mom[NMOM][C],

@@ -21,6 +21,13 @@ def world_size(group=None):
     return dist.get_world_size(group)
 
 
+def forced_exchange():
+    """CNNQ_FORCE_EXCHANGE=1 with an initialised (1-rank) process group: take the multi-GPU launch sequence even
+    for world size 1, so that the real collective (RCCL `nccl` backend) runs and can be timed on a 1-GPU box."""
+    import os
+    return os.environ.get('CNNQ_FORCE_EXCHANGE', '0') == '1' and dist.is_available() and dist.is_initialized()
+
+
 def rank(group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return 0
@@ -48,7 +55,7 @@ def collective_all_gather(rec, group=None):
     w = world_size(group)
     rec = rec.contiguous()
     out = torch.empty((w,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
-    if w == 1:
+    if w == 1 and not forced_exchange():
         out[0].copy_(rec)
         return out
     try:

@@ -30,7 +30,25 @@ def _dev_f32(x, what='tensor'):
         # kernels are enqueued in the calling thread's current device context (one process per GPU is the
         # deployment model; in-process multi-GPU callers must enter torch.cuda.device(x.device) first)
         raise L.CnnqError('%s is on %s but the current device is cuda:%d' % (what, x.device, torch.cuda.current_device()))
-    return x.detach().contiguous()
+    if x.requires_grad:
+        x = x.detach()
+    return x if x.is_contiguous() else x.contiguous()
+
+
+_SCRATCH = {}
+_WS_BYTES = {}
+
+
+def _scratch(x, tag, nbytes):
+    """A per-(device, stream, tag) scratch buffer (uint8, at least nbytes), grown on demand and never returned
+    to callers: launches on one stream are ordered, so consecutive calls may share it.  Saves the 2-4
+    torch.empty calls (8-15 us of host time) the small layers would otherwise pay per call."""
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, tag)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=x.device)
+        _SCRATCH[key] = buf
+    return buf
 
 
 def _out_like(x, out):
@@ -198,7 +216,23 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     lib = L.load()
     x = _dev_f32(x, 'x')
     world = D.world_size(group)
-    if (world == 1 and not want_codes and not want_entropy and os.environ.get('CNNQ_RESIDENT', '1') != '0'):
+    exchanging = world > 1 or D.forced_exchange()
+    resident = os.environ.get('CNNQ_RESIDENT', '1') != '0'
+    if not exchanging and not (want_codes or want_entropy or want_parts):
+        # the hot call: one C entry point, one cached workspace, no torch allocation besides the result
+        key = (N, C, HW)
+        nbytes = _WS_BYTES.get(key)
+        if nbytes is None:
+            nbytes = _WS_BYTES[key] = lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+            if nbytes == 0:
+                del _WS_BYTES[key]
+                L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+        y = _out_like(x, out)
+        L.check(lib.cnnq_pc_minmax_qdq_auto(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)),
+                                            _ptr(_scratch(x, 'cfg2', nbytes)), int(resident), _stream(x)),
+                'cnnq_pc_minmax_qdq_auto')
+        return y
+    if not exchanging and resident and not want_codes and not want_entropy:
         res = minmax_qdq_resident(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
         if res is not None:
             return res
@@ -210,7 +244,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device)
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
     hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
-    if world == 1:
+    if not exchanging:
         L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
                                        _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
     elif (os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') == '1' and C >= 8 and not want_codes and not want_entropy
@@ -234,7 +268,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     if want_entropy:
         res.append(entropy_from_hist(hist))
     if want_parts:
-        g_used = world if world > 1 else lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+        g_used = world if exchanging else lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
         stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
         stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
         stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]

@@ -221,6 +221,13 @@ int cnnq_pc_resident_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                                 float* qp, float* mm, void* stream);
 
+/* Config 2 behind one call and one caller workspace `ws` of cnnq_pc_minmax_qdq_workspace(N, C, HW) bytes
+ * (4-byte aligned; floats qp[CNNQ_NQP][C], mm[2][C], pmm[G][2][C]): the resident single launch when
+ * allow_resident != 0 and the shape has one (mm is then valid), the three-launch chain otherwise. */
+size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW);
+int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                            float* ws, int allow_resident, void* stream);
+
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace
  * prior) -> merge -> cnnq_pc_params(cfg) -> fused Q/DQ.  `ws`: caller workspace of cnnq_pc_aciq_workspace(...)
