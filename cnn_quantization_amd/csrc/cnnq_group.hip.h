@@ -1,0 +1,309 @@
+// cnnq_group.hip.h - config 2 in ONE launch and ONE read of x for tensors whose channels do NOT fit one workgroup
+// (cnnq_resident.hip.h covers those that do): 8 instead of 12 bytes per element.
+// Part of the single translation unit cnnq_kernels.hip (see its header for the shared column-block decomposition).
+//
+// A workgroup's share of x stays in REGISTERS between the statistics and the Q/DQ.  It owns one column block
+// (<= 256 float4 columns aligned to channel boundaries) and R <= K consecutive samples of it, issues its K
+// 16-byte loads per lane back to back, reduces them to per-channel {min, max}, and then meets the OTHER workgroups
+// that hold pieces of the same channels - the "group": the S batch splits, times the nb column slices when one
+// channel row is wider than a workgroup.  The exchange follows the write-through publish / counter recipe of
+// cdna_hip_programming.md Guideline 16 (R1), with what the measurements of this kernel added:
+//
+//   * partial {min, max} pairs are 8-byte agent-scope (sc1, write-through) stores, every storing wave drains its
+//     vmcnt, then ONE lane bumps the group's arrival counter.  NO release fence: buffer_wbl2 would have to write
+//     back the megabytes of y that this very kernel keeps dirtying in the XCD's L2 - with it the kernel ran 3x
+//     slower than the two-pass chain;
+//   * every group's pairs live in their own 128-byte-aligned block: a line is written only by its group and read
+//     only after that group's counter is complete.  With the pairs of neighbouring groups sharing lines, a
+//     workgroup that read its own (complete) group pulled the line into its XCD's L2 with the neighbour's slots
+//     still unwritten, and the neighbour's members on that XCD later hit that stale copy (buffer_inv sc1 drops
+//     L1, not L2) - wrong scales in groups dispatched late, found by the rotating-buffer tests;
+//   * lane 0 polls the counter (relaxed sc1 load, s_sleep back-off up to 3.4 us: hundreds of pollers on one word
+//     otherwise saturate it), one agent acquire, plain loads of the group's block;
+//   * the counter also counts departures and the last workgroup to leave zeroes it: the workspace is zeroed ONCE
+//     by the caller, the launch is replayable from a HIP graph;
+//   * forward progress does not depend on dispatch order: the wait is bounded twice (20 ms of the 100 MHz clock,
+//     2^20 polls); a workgroup that gives up recomputes its channels' extrema from x itself (exact, hence the
+//     same bits) and raises bit 0 of the status word.
+#pragma once
+#include "cnnq_common.hip.h"
+#include "cnnq_qdq.hip.h"
+#include "cnnq_resident.hip.h"   // pmin / pmax / lane_acc
+
+namespace {
+
+constexpr long long GRP_TIMEOUT_TICKS = 2000000;   // 20 ms of the 100 MHz constant clock
+constexpr int GRP_TIMEOUT_SPINS = 1 << 20;         // second bound on the same wait
+constexpr int GRP_CNT_STRIDE = 64;                 // words between two groups' counters: one 256-byte line each - with
+                                                   // 16 counters per line every arrival, departure and poll of 16
+                                                   // groups serialised on one line (~130 ns per workgroup, measured)
+constexpr int GRP_GS_MAX = 512;                    // members of a group (all co-resident: capacity >= 512 workgroups)
+#ifndef GRP_K32_WAVES
+#define GRP_K32_WAVES 3   // waves per SIMD the K = 32 tile is compiled for (168 VGPRs)
+#endif
+
+__device__ __forceinline__ unsigned long long pack_pair(float mn, float mx) {
+    return (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
+}
+__device__ __forceinline__ void unpack_pair(unsigned long long p, float& mn, float& mx) {
+    mn = __uint_as_float((unsigned)(p & 0xffffffffull));
+    mx = __uint_as_float((unsigned)(p >> 32));
+}
+
+struct RBlk {
+    Blk b;
+    int group, member;
+};
+
+// blockIdx -> (group, member) -> tile.  Members of a group are consecutive workgroups.
+__device__ __forceinline__ RBlk rblk_of(const Geo& g, int Gs) {
+    RBlk r;
+    const int bid = (int)blockIdx.x;
+    r.group = bid / Gs;
+    r.member = bid - r.group * Gs;
+    int s;
+    if (g.mode == 1) {
+        const int cpc = g.HW / 4;
+        s = r.member / g.nb;
+        const int bb = r.member - s * g.nb;
+        const int c = g.cbeg + r.group;
+        r.b.c0 = c;
+        r.b.c1 = c + 1;
+        r.b.col0 = c * cpc + bb * g.w;
+        r.b.col1 = min(r.b.col0 + g.w, (c + 1) * cpc);
+    } else {
+        s = r.member;
+        r.b.c0 = g.cbeg + r.group * g.k;
+        r.b.c1 = min(g.cbeg + g.Cn, r.b.c0 + g.k);
+        r.b.col0 = (int)(((int64_t)r.b.c0 * g.HW) / 4);
+        r.b.col1 = (int)(((int64_t)r.b.c1 * g.HW) / 4);
+    }
+    r.b.n0 = (int)(((int64_t)s * g.N) / g.S);
+    r.b.n1 = (int)(((int64_t)(s + 1) * g.N) / g.S);
+    r.b.grp = s;
+    return r;
+}
+
+// per-lane accumulators -> per-channel extrema of the workgroup's tile in sh_mn / sh_mx [c1 - c0]
+template <int A>
+__device__ __forceinline__ void wg_channel_minmax(const Geo& g, const Blk& b, bool ok, const float (&mn)[A],
+                                                  const float (&mx)[A], float* l_mn, float* l_mx, float* sh_mn,
+                                                  float* sh_mx) {
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if (g.mode == 1) {
+        float tn = ok ? mn[0] : INFINITY, tx = ok ? mx[0] : -INFINITY;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
+        if (lane == 0) { l_mn[wv] = tn; l_mx[wv] = tx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < TPB / 64; ++i) { tn = pmin(tn, l_mn[i]); tx = pmax(tx, l_mx[i]); }
+            sh_mn[0] = tn;
+            sh_mx[0] = tx;
+        }
+        __syncthreads();
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        l_mn[tid * A + a] = ok ? mn[a] : INFINITY;
+        l_mx[tid * A + a] = ok ? mx[a] : -INFINITY;
+    }
+    __syncthreads();
+    const int epc = g.HW * A / 4;   // LDS entries per channel
+    if (epc <= 16) {
+        for (int ch = tid; ch < b.c1 - b.c0; ch += TPB) {
+            float tn = INFINITY, tx = -INFINITY;
+            for (int e = ch * epc; e < (ch + 1) * epc; ++e) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
+            sh_mn[ch] = tn;
+            sh_mx[ch] = tx;
+        }
+    } else {
+        for (int ch = wv; ch < b.c1 - b.c0; ch += TPB / 64) {
+            float tn = INFINITY, tx = -INFINITY;
+            for (int e = ch * epc + lane; e < (ch + 1) * epc; e += 64) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
+            if (lane == 0) { sh_mn[ch] = tn; sh_mx[ch] = tx; }
+        }
+    }
+    __syncthreads();
+}
+
+// cold path (a wait timed out, or the test flag): the extrema of the group's channels straight from x, all samples
+template <int A>
+__device__ __forceinline__ void group_minmax_from_x(const float* __restrict__ x, const Geo& g, const Blk& b, float* l_mn,
+                                                 float* l_mx, float* sh_mn, float* sh_mx) {
+    const int tid = threadIdx.x;
+    float mn[A], mx[A];
+    bool nan = false;
+#pragma unroll
+    for (int a = 0; a < A; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+    bool ok = true;
+    if (g.mode == 1) {
+        const int cpc = g.HW / 4;
+        for (int n = 0; n < g.N; ++n)
+            for (int col = tid; col < cpc; col += TPB) {
+                float v[4];
+                ldv<4>(x + (size_t)n * (size_t)g.P + ((size_t)b.c0 * cpc + col) * 4, v);
+                lane_acc<A>(v, mn, mx, nan);
+            }
+    } else {
+        const int col = b.col0 + tid;
+        ok = col < b.col1;
+        if (ok)
+            for (int n = 0; n < g.N; ++n) {
+                float v[4];
+                ldv<4>(x + (size_t)n * (size_t)g.P + (size_t)col * 4, v);
+                lane_acc<A>(v, mn, mx, nan);
+            }
+    }
+    if (A == 1 && nan) { mn[0] = NAN; mx[0] = NAN; }
+    __syncthreads();   // l_mn / l_mx may still be read by a previous reduction
+    wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
+}
+
+// ws: [0] status word, [256 ..) 16384 arrival/departure counters, one per group and per 256-byte line (a fixed
+// region, so that no geometry's pairs ever land on another geometry's counters), then one 128-byte-aligned block of 8-byte
+// {min, max} pairs per group: [member] (mode 1) or [member][k] (mode 2)
+struct GWs {
+    unsigned* status;
+    unsigned* cnt;
+    unsigned long long* part;
+    int gstride;   // pairs per group block
+};
+
+template <int A, int K>
+__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_group(
+    const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
+    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags) {
+    __shared__ float l_mn[TPB * A], l_mx[TPB * A];
+    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
+    __shared__ int sh_timed_out;
+    const RBlk rb = rblk_of(g, Gs);
+    const Blk& b = rb.b;
+    const int tid = threadIdx.x;
+    const int col = b.col0 + tid;
+    const bool ok = col < b.col1;
+    const int colc = ok ? col : b.col0;   // idle lanes re-read the block's first column; results discarded
+    const int nrows = b.n1 - b.n0;        // 1 .. K
+    const size_t base = (size_t)b.n0 * (size_t)g.P + (size_t)colc * 4;
+
+    // ---- the tile: K 16-byte loads per lane, issued back to back (rows past the tile re-read its last row)
+    float v[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int r = j < nrows ? j : nrows - 1;
+        ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
+    }
+    float mn[A], mx[A];
+    bool nan = false;
+#pragma unroll
+    for (int a = 0; a < A; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+#pragma unroll
+    for (int j = 0; j < K; ++j) lane_acc<A>(v[j], mn, mx, nan);
+    if (A == 1 && nan) { mn[0] = NAN; mx[0] = NAN; }
+    wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
+    const int nch = b.c1 - b.c0;
+
+    // ---- publish this workgroup's pairs (write-through), arrive, wait for the group
+    unsigned long long* blk = ws.part + (size_t)rb.group * ws.gstride;
+    const int kk = (g.mode == 1) ? 1 : g.k;
+    for (int ch = tid; ch < nch; ch += TPB)
+        __hip_atomic_store(blk + (size_t)rb.member * kk + ch, pack_pair(sh_mn[ch], sh_mx[ch]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* c = ws.cnt + (size_t)rb.group * GRP_CNT_STRIDE;
+        unsigned seen = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        int timed_out = (flags & 1u) ? 1 : 0;
+        if (!timed_out && seen < (unsigned)Gs) {
+            const long long t0 = wall_clock64();
+            for (int spins = 0;; ++spins) {
+                if (spins < 2) __builtin_amdgcn_s_sleep(8);
+                else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+                else __builtin_amdgcn_s_sleep(127);
+                seen = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen >= (unsigned)Gs) break;
+                if (wall_clock64() - t0 > GRP_TIMEOUT_TICKS || spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // leave: the last of the 2*Gs increments re-arms the counter for the next launch
+        const unsigned left = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == 2u * (unsigned)Gs - 1u) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timed_out) atomicOr(ws.status, 1u);
+        sh_timed_out = timed_out;
+    }
+    __syncthreads();
+    if (sh_timed_out) {
+        group_minmax_from_x<A>(x, g, b, l_mn, l_mx, sh_mn, sh_mx);
+    } else if (g.mode == 1) {
+        float tn = INFINITY, tx = -INFINITY;
+        for (int m = tid; m < Gs; m += TPB) {
+            float a, c;
+            unpack_pair(blk[m], a, c);
+            tn = pmin(tn, a);
+            tx = pmax(tx, c);
+        }
+        const float one_n[1] = {tn}, one_x[1] = {tx};
+        wg_channel_minmax<1>(g, b, true, one_n, one_x, l_mn, l_mx, sh_mn, sh_mx);   // the one-channel reduction
+    } else {
+        for (int ch = tid; ch < nch; ch += TPB) {
+            float tn = INFINITY, tx = -INFINITY;
+#pragma unroll 8
+            for (int s = 0; s < Gs; ++s) {
+                float a, c;
+                unpack_pair(blk[(size_t)s * kk + ch], a, c);
+                tn = pmin(tn, a);
+                tx = pmax(tx, c);
+            }
+            sh_mn[ch] = tn;
+            sh_mx[ch] = tx;
+        }
+        __syncthreads();
+    }
+
+    // ---- scale / zero point of the owned channels (iq.py:559-572), identical in every member
+    const float qm = (float)((1u << num_bits) - 1u);
+    for (int ch = tid; ch < nch; ch += TPB) {
+        const float cmn = sh_mn[ch], cmx = sh_mx[ch];
+        const float offset = positive ? 0.f : cmn;
+        const float delta = cmx - offset;
+        float sc = delta / qm;
+        sc = (sc < 1e-8f) ? 1e-8f : sc;
+        const float zp = rintf(0.f - offset / sc);
+        sh_sc[ch] = sc;
+        sh_zp[ch] = zp;
+        if (rb.member == 0) {
+            const int c = b.c0 + ch;
+            qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
+            qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
+            qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
+            if (mm) { mm[c] = cmn; mm[g.C + c] = cmx; }
+        }
+    }
+    __syncthreads();
+    float sc[A], zp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const unsigned e = (unsigned)colc * 4u + (unsigned)a;
+        const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+        sc[a] = sh_sc[ch];
+        zp[a] = sh_zp[ch];
+    }
+
+    // ---- Q/DQ out of the registers
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < nrows) {
+            float o[4], cd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
+            if (ok) stv_nt<4>(y + base + (size_t)j * (size_t)g.P, o);
+        }
+    }
+}
+
+}  // namespace

@@ -40,6 +40,7 @@
 #include "cnnq_corrections.hip.h"
 #include "cnnq_pertensor.hip.h"
 #include "cnnq_resident.hip.h"
+#include "cnnq_group.hip.h"
 #include "cnnq_plan.hip.h"
 #include "cnnq_kld.hip.h"
 #include "cnnq_p2p.hip.h"
@@ -297,6 +298,31 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
     const int rc = plan_whole(N, C, HW, al16(x) && al16(y), &p);
     if (rc) return rc;
     return launch_whole(x, y, p, num_bits, positive ? 1 : 0, qp, mm, (hipStream_t)stream);
+}
+
+// Config 2 in one launch and one read of x for tensors whose channels span several workgroups (cnnq_group.hip.h)
+size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW) {
+    GPlan p;
+    return plan_group(N, C, HW, true, &p) ? 0 : p.ws_bytes;
+}
+
+int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
+    if (!out) return CNNQ_EINVAL;
+    GPlan p;
+    const int rc = plan_group(N, C, HW, true, &p);
+    if (rc) return rc;
+    const int32_t vals[8] = {p.v.A, p.K, p.g.mode, p.g.S, p.g.ncb, p.Gs, p.ngroups, p.g.S * p.g.ncb};
+    for (int i = 0; i < 8; ++i) out[i] = vals[i];
+    return 0;
+}
+
+int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                             void* ws, float* qp, float* mm, unsigned flags, void* stream) {
+    if (!x || !y || !ws || !qp || num_bits < 1 || num_bits > 8 || ((uintptr_t)ws & 127)) return CNNQ_EINVAL;
+    GPlan p;
+    const int rc = plan_group(N, C, HW, al16(x) && al16(y), &p);
+    if (rc) return rc;
+    return launch_group(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
 }
 
 // Config 2 behind ONE call and ONE caller workspace: the resident single launch when the shape has one, the

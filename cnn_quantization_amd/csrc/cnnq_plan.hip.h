@@ -3,6 +3,7 @@
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_resident.hip.h"
+#include "cnnq_group.hip.h"
 
 namespace {
 
@@ -212,6 +213,84 @@ int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int pos
         else { if (p.K == 8) LAUNCH_W(4, 1024, 8); else LAUNCH_W(4, 1024, 16); }
     }
 #undef LAUNCH_W
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// the group-exchange single-launch form of config 2 (cnnq_group.hip.h)
+// ------------------------------------------------------------------------------------------
+struct GPlan {
+    Variant v;     // {4, A, 1}
+    Geo g;         // column blocks of <= 256 float4 columns, S = batch splits of <= K samples
+    int K;         // samples (16-byte loads) a lane holds
+    int Gs;        // workgroups per group (the ones that exchange extrema)
+    int ngroups;   // groups = arrival counters
+    int gstride;   // 8-byte pairs per group block (a multiple of 16 = 128 bytes)
+    size_t ws_bytes;
+};
+
+// ws layout, the SAME for every geometry (the counters must never alias another launch's pairs: they are only
+// ever zero or mid-count): status word, GRP_MAX_GROUPS counters, then the pair blocks
+constexpr size_t GRP_WS_HDR = 256;
+constexpr int GRP_MAX_GROUPS = 16384;
+constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_GROUPS * GRP_CNT_STRIDE * 4;
+
+int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p) {
+    if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
+    if (!aligned16) return CNNQ_ENOTSUP;
+    if (HW % 4 == 0) {
+        p->v = {4, 1, 1};
+    } else if ((C * HW) % 4 == 0) {
+        const int m = 4 / gcd_i((int)(HW % 4), 4);
+        if ((int64_t)m * HW > TPB * 4) return CNNQ_ENOTSUP;
+        p->v = {4, 4, 1};
+    } else {
+        return CNNQ_ENOTSUP;
+    }
+    const int rc = make_geo(N, C, HW, p->v, 0, C, 0, 0, 0, &p->g);
+    if (rc) return rc;
+    Geo& g = p->g;
+    static const int forceK = env_int("CNNQ_GRP_K", 0);      // development knobs (kernel sweeps)
+    static const int target = env_int("CNNQ_GRP_WGS", 1024);
+    const int members_per_split = (g.mode == 1) ? g.nb : 1;
+    int K = 4;
+    if (forceK == 4 || forceK == 8 || forceK == 16 || forceK == 32) {
+        K = forceK;
+    } else {
+        for (K = 32; K > 4; K >>= 1)   // the largest tile that still yields `target` workgroups
+            if ((int64_t)g.ncb * ((N + K - 1) / K) >= target) break;
+    }
+    while (K < 32 && ((N + K - 1) / K) * members_per_split > GRP_GS_MAX) K <<= 1;   // groups stay co-resident
+    const int64_t S = (N + K - 1) / K;
+    if (S * members_per_split > GRP_GS_MAX) return CNNQ_ENOTSUP;
+    if (S * g.ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    g.S = (int)S;
+    p->K = K;
+    p->Gs = (int)(S * members_per_split);
+    p->ngroups = (g.mode == 1) ? g.Cn : g.ncb;
+    if (p->ngroups > GRP_MAX_GROUPS) return CNNQ_ENOTSUP;
+    const int64_t pairs = (int64_t)p->Gs * ((g.mode == 1) ? 1 : g.k);
+    p->gstride = (int)(((pairs + 15) / 16) * 16);
+    p->ws_bytes = GRP_WS_PAIRS + (size_t)p->ngroups * p->gstride * 8;
+    return 0;
+}
+
+int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
+                 unsigned flags, hipStream_t st) {
+    GWs w;
+    w.status = reinterpret_cast<unsigned*>(ws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
+    w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.gstride = p.gstride;
+    const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
+#define LAUNCH_G(A, K) \
+    hipLaunchKernelGGL((k_mmq_group<A, K>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags)
+    if (p.v.A == 4) {
+        if (p.K == 32) LAUNCH_G(4, 32); else if (p.K == 16) LAUNCH_G(4, 16); else if (p.K == 8) LAUNCH_G(4, 8); else LAUNCH_G(4, 4);
+    } else {
+        if (p.K == 32) LAUNCH_G(1, 32); else if (p.K == 16) LAUNCH_G(1, 16); else if (p.K == 8) LAUNCH_G(1, 8); else LAUNCH_G(1, 4);
+    }
+#undef LAUNCH_G
     return launch_status();
 }
 
