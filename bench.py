@@ -16,10 +16,12 @@ Multi-GPU (inference_sim.py:196-200): ONE batch of 512 is sharde
 per-channel statistics are made global with one small all_gather per tensor (RCCL over xGMI),
 the Q/DQ itself needs no communication.
 
-Per tensor the product entry point (ops.act_qdq_per_channel) picks
-  * the register-resident single launch (k_mmq_whole: 4 B read + 4 B write per element) when a
-    channel's batch population fits a workgroup - the small-H*W layers of a batch <= 64 shard;
-  * otherwise the chain k_minmax (4 B read) -> k_minmax_params -> k_qdq (4 B read + 4 B write).
+Per tensor the product entry point (ops.act_qdq_per_channel) picks a SINGLE launch that reads x once
+(4 B read + 4 B write per element, the tile stays in registers between statistics and Q/DQ):
+  * k_mmq_whole when a channel's batch population fits one workgroup (small H*W at batch <= 64),
+  * k_mmq_group otherwise: the workgroups that share a channel exchange {min, max} inside the launch;
+and only for shapes neither supports (unaligned, odd H*W) the three-launch chain
+k_minmax (4 B read) -> k_minmax_params -> k_qdq (4 B read + 4 B write).
 
 Prints ONE JSON line (rank 0): `value` = elements/s of the whole job; `roofline` = the dominant
 kernel's algorithmic bytes / its measured launch time (HIP events on the launch stream) against
@@ -93,10 +95,11 @@ def time_kernel_classes(layers):
     duration of that kernel alone, as rocprofv3 --kernel-trace reports it.  Returns
     {class: [seconds, launches, elements]}."""
     import ctypes
-    from cnn_quantization_amd import _lib
+    from cnn_quantization_amd import _lib, ops
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     resident_ok = os.environ.get('CNNQ_RESIDENT', '1') != '0'
+    gws = ops._group_workspace(layers[0]['x']) if resident_ok else None
     recs = []
     d = (ctypes.c_int32 * 8)()
     for L in layers:
@@ -112,6 +115,14 @@ def time_kernel_classes(layers):
                                                        qp.data_ptr(), None, st), 'resident')
             e[1].record()
             recs.append((n, [('k_mmq_whole', e[0], e[1])]))
+            continue
+        if resident_ok and 0 < lib.cnnq_pc_group_workspace(N, C, HW) <= ops.GROUP_WS_BYTES:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e[0].record()
+            _lib.check(lib.cnnq_pc_minmax_qdq_group(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']), gws,
+                                                    qp.data_ptr(), None, 0, st), 'group')
+            e[1].record()
+            recs.append((n, [('k_mmq_group', e[0], e[1])]))
             continue
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
@@ -135,7 +146,10 @@ def time_kernel_classes(layers):
 
 KERNEL_BYTES = {'k_qdq': (BYTES_QDQ, 'fused per-channel Q/DQ pass, 8 algorithmic B/elem'),
                 'k_minmax': (BYTES_STATS, 'per-channel exact min/max pass, 4 B/elem'),
-                'k_mmq_whole': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, 8 algorithmic B/elem'),
+                'k_mmq_whole': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, whole channels per workgroup, '
+                                           '8 algorithmic B/elem'),
+                'k_mmq_group': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, extrema exchanged between the '
+                                           'workgroups of a channel group, 8 algorithmic B/elem'),
                 'k_minmax_params': (0, 'per-channel parameter table (latency-bound, a few KB)')}
 
 

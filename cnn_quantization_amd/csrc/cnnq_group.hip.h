@@ -20,7 +20,7 @@
 //     L1, not L2) - wrong scales in groups dispatched late, found by the rotating-buffer tests;
 //   * lane 0 polls the counter (relaxed sc1 load, s_sleep back-off up to 3.4 us: hundreds of pollers on one word
 //     otherwise saturate it), one agent acquire, plain loads of the group's block;
-//   * the counter also counts departures and the last workgroup to leave zeroes it: the workspace is zeroed ONCE
+//   * departures are counted too and the last one to leave a counter line zeroes it: the workspace is zeroed ONCE
 //     by the caller, the launch is replayable from a HIP graph;
 //   * forward progress does not depend on dispatch order: the wait is bounded twice (20 ms of the 100 MHz clock,
 //     2^20 polls); a workgroup that gives up recomputes its channels' extrema from x itself (exact, hence the
@@ -38,6 +38,10 @@ constexpr int GRP_CNT_STRIDE = 64;                 // words between two groups' 
                                                    // 16 counters per line every arrival, departure and poll of 16
                                                    // groups serialised on one line (~130 ns per workgroup, measured)
 constexpr int GRP_GS_MAX = 512;                    // members of a group (all co-resident: capacity >= 512 workgroups)
+#ifndef GRP_ACQUIRE
+#define GRP_ACQUIRE 1     // agent-scope acquire (buffer_inv sc1) between the wait and the reads of the group's pairs
+#endif
+constexpr int GRP_SUB = 16;                        // members per arrival counter
 #ifndef GRP_K32_WAVES
 #define GRP_K32_WAVES 3   // waves per SIMD the K = 32 tile is compiled for (168 VGPRs)
 #endif
@@ -215,24 +219,57 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
     __syncthreads();
     if (tid == 0) {
-        unsigned* c = ws.cnt + (size_t)rb.group * GRP_CNT_STRIDE;
-        unsigned seen = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        // Counter lines (256 bytes each; words: [0] arrivals A, [1] departures D, [2] ready flag F).  Up to GRP_SUB
+        // members share one line; larger groups arrive in sub-groups of GRP_SUB whose last arrivers meet on the
+        // group's top line, and the very last one raises every sub-group's flag: no word ever sees more than
+        // GRP_SUB + 1 increments or GRP_SUB pollers (208 members on ONE word cost the 112x112 layer 60 % of its
+        // time).  Arrivals and departures are counted apart, so a workgroup that gives up waiting (or the test
+        // flag) and leaves early cannot be mistaken for an arrival; whoever performs the LAST departure of a line
+        // - members and, with two levels, the flag raiser - zeroes it: every launch leaves the workspace zero
+        // under any interleaving.
+        const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+        const int si = rb.member / GRP_SUB;
+        const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
+        unsigned* top = ws.cnt + (size_t)rb.group * (nsub > 1 ? nsub + 1 : 1) * GRP_CNT_STRIDE;
+        unsigned* line = (nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top;
+        auto leave = [](unsigned* ln, unsigned actors) {
+            if (__hip_atomic_fetch_add(ln + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == actors - 1u) {
+                __hip_atomic_store(ln + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ln + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ln + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        const unsigned seen = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        bool ready = (nsub == 1) && seen >= m_i;
+        if (nsub > 1 && seen == m_i) {
+            // last arrival of this sub-group -> the group's top counter (exactly nsub arrivals per launch)
+            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsub - 1u) {
+                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < nsub; ++j)
+                    __hip_atomic_store(top + (size_t)(1 + j) * GRP_CNT_STRIDE + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flags are out before this actor departs
+                for (int j = 0; j < nsub; ++j)
+                    leave(top + (size_t)(1 + j) * GRP_CNT_STRIDE, (unsigned)min(GRP_SUB, Gs - j * GRP_SUB) + 1u);
+                ready = true;
+            }
+        }
         int timed_out = (flags & 1u) ? 1 : 0;
-        if (!timed_out && seen < (unsigned)Gs) {
+        if (!timed_out && !ready) {
+            const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals
+            const unsigned want = (nsub > 1) ? 1u : m_i;
             const long long t0 = wall_clock64();
             for (int spins = 0;; ++spins) {
-                if (spins < 2) __builtin_amdgcn_s_sleep(8);
-                else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+                if (spins < 2) __builtin_amdgcn_s_sleep(16);
+                else if (spins < 6) __builtin_amdgcn_s_sleep(48);
                 else __builtin_amdgcn_s_sleep(127);
-                seen = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen >= (unsigned)Gs) break;
+                if (__hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
                 if (wall_clock64() - t0 > GRP_TIMEOUT_TICKS || spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
             }
         }
+#if GRP_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // leave: the last of the 2*Gs increments re-arms the counter for the next launch
-        const unsigned left = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == 2u * (unsigned)Gs - 1u) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        leave(line, (nsub > 1) ? m_i + 1u : m_i);
         if (timed_out) atomicOr(ws.status, 1u);
         sh_timed_out = timed_out;
     }

@@ -306,6 +306,27 @@ size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW) {
     return plan_group(N, C, HW, true, &p) ? 0 : p.ws_bytes;
 }
 
+// The exchange workspace lives in fine-grained (uncached) device memory: the pairs one XCD writes must be what
+// another XCD reads in the same launch AND in the next one.  In ordinary (cached) device memory a reader's L2 can
+// still hold a pair line of an EARLIER launch - the same slot, other data - when little else ran in between
+// (small tensors, found by the tests; agent-scope acquires drop L1, not L2).  These are the only entry points of
+// the path that allocate; they synchronise the device.
+int cnnq_group_ws_alloc(size_t bytes, void** ws) {
+    if (!ws || bytes < GRP_WS_PAIRS) return CNNQ_EINVAL;
+    hipError_t e = hipExtMallocWithFlags(ws, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(*ws, 0, bytes);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipDeviceSynchronize();
+}
+
+int cnnq_group_ws_free(void* ws) { return ws ? (int)hipFree(ws) : CNNQ_EINVAL; }
+
+int cnnq_group_ws_status(const void* ws, uint32_t* status_host) {
+    if (!ws || !status_host) return CNNQ_EINVAL;
+    return (int)hipMemcpy(status_host, ws, sizeof(uint32_t), hipMemcpyDeviceToHost);
+}
+
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
     if (!out) return CNNQ_EINVAL;
     GPlan p;
@@ -325,8 +346,8 @@ int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int
     return launch_group(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
 }
 
-// Config 2 behind ONE call and ONE caller workspace: the resident single launch when the shape has one, the
-// three-launch chain otherwise.  ws layout (floats): qp[CNNQ_NQP][C], mm[2][C] (resident only), pmm[G][2][C].
+// Config 2 behind ONE call: the resident single launch when the shape has one, else the group-exchange single
+// launch (needs gws), else the three-launch chain.  ws layout (floats): qp[CNNQ_NQP][C], mm[2][C], pmm[G][2][C].
 size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW) {
     const int g1 = cnnq_pc_groups(N, C, HW, 1), g0 = cnnq_pc_groups(N, C, HW, 0);
     const int G = g1 > g0 ? g1 : g0;
@@ -335,14 +356,18 @@ size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW) {
 }
 
 int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                            float* ws, int allow_resident, void* stream) {
+                            float* ws, void* gws, size_t gws_bytes, int allow_single_launch, void* stream) {
     if (!x || !y || !ws || num_bits < 1 || num_bits > 8 || C <= 0) return CNNQ_EINVAL;
     float* qp = ws;
     float* mm = ws + (size_t)CNNQ_NQP * C;
     float* pmm = mm + 2 * (size_t)C;
-    if (allow_resident) {
-        const int rc = cnnq_pc_minmax_qdq_resident(x, y, N, C, HW, num_bits, positive, qp, mm, stream);
+    if (allow_single_launch) {
+        int rc = cnnq_pc_minmax_qdq_resident(x, y, N, C, HW, num_bits, positive, qp, mm, stream);
         if (rc != CNNQ_ENOTSUP) return rc;
+        if (gws && cnnq_pc_group_workspace(N, C, HW) <= gws_bytes && cnnq_pc_group_workspace(N, C, HW) > 0) {
+            rc = cnnq_pc_minmax_qdq_group(x, y, N, C, HW, num_bits, positive, gws, qp, mm, 0u, stream);
+            if (rc != CNNQ_ENOTSUP) return rc;
+        }
     }
     return cnnq_pc_minmax_qdq(x, y, N, C, HW, num_bits, positive, pmm, qp, nullptr, nullptr, stream);
 }

@@ -230,10 +230,11 @@ struct GPlan {
 };
 
 // ws layout, the SAME for every geometry (the counters must never alias another launch's pairs: they are only
-// ever zero or mid-count): status word, GRP_MAX_GROUPS counters, then the pair blocks
+// ever zero or mid-count; counters of different geometries may alias each other, every launch leaves them zero):
+// status word, GRP_MAX_LINES counter lines, then the pair blocks
 constexpr size_t GRP_WS_HDR = 256;
-constexpr int GRP_MAX_GROUPS = 16384;
-constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_GROUPS * GRP_CNT_STRIDE * 4;
+constexpr int GRP_MAX_LINES = 16384;   // counter lines (4 MB)
+constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_LINES * GRP_CNT_STRIDE * 4;
 
 int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p) {
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
@@ -268,7 +269,10 @@ int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p) {
     p->K = K;
     p->Gs = (int)(S * members_per_split);
     p->ngroups = (g.mode == 1) ? g.Cn : g.ncb;
-    if (p->ngroups > GRP_MAX_GROUPS) return CNNQ_ENOTSUP;
+    {   // counter lines: one per group, plus one per sub-group of GRP_SUB members when a group has several
+        const int64_t nsub = (p->Gs + GRP_SUB - 1) / GRP_SUB;
+        if ((int64_t)p->ngroups * (nsub > 1 ? nsub + 1 : 1) > GRP_MAX_LINES) return CNNQ_ENOTSUP;
+    }
     const int64_t pairs = (int64_t)p->Gs * ((g.mode == 1) ? 1 : g.k);
     p->gstride = (int)(((pairs + 15) / 16) * 16);
     p->ws_bytes = GRP_WS_PAIRS + (size_t)p->ngroups * p->gstride * 8;

@@ -183,6 +183,58 @@ def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None, reverse=False
     return (y, codes) if want_codes else y
 
 
+_GROUP_WS = {}
+GROUP_WS_BYTES = 16 << 20
+
+
+def _group_workspace(x):
+    """The exchange workspace of the group single launch (cnnq_pc_minmax_qdq_group): fine-grained device memory
+    from cnnq_group_ws_alloc, zeroed ONCE, one per (device, stream) - launches on one stream are ordered, so they
+    share it; the kernel re-arms its counters.  Returns the raw device pointer (a ctypes.c_void_p)."""
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _GROUP_WS.get(key)
+    if ws is None:
+        ws = ctypes.c_void_p()
+        L.check(L.load().cnnq_group_ws_alloc(GROUP_WS_BYTES, ctypes.byref(ws)), 'cnnq_group_ws_alloc')
+        _GROUP_WS[key] = ws
+    return ws
+
+
+def group_status(x):
+    """Status word of this stream's group workspace (synchronises): bit 0 = some wait timed out and its workgroup
+    recomputed the extrema from x (results are unaffected)."""
+    ws = _GROUP_WS.get((x.device.index, torch.cuda.current_stream(x.device).cuda_stream))
+    if ws is None:
+        return 0
+    v = ctypes.c_uint32()
+    L.check(L.load().cnnq_group_ws_status(ws, ctypes.byref(v)), 'cnnq_group_ws_status')
+    return int(v.value)
+
+
+def minmax_qdq_group(x, N, C, HW, num_bits, positive=False, out=None, want_parts=False, flags=0):
+    """Config 2 in ONE launch and ONE read of x for tensors whose channels span several workgroups
+    (cnnq_pc_minmax_qdq_group).  Returns None when the shape is not supported (the caller takes the chain)."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    nbytes = lib.cnnq_pc_group_workspace(N, C, HW)
+    if nbytes == 0 or nbytes > GROUP_WS_BYTES:
+        return None
+    y = _out_like(x, out)
+    qp = torch.empty((L.NQP + 2, C), dtype=torch.float32, device=x.device)
+    rc = lib.cnnq_pc_minmax_qdq_group(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)),
+                                      _group_workspace(x), _ptr(qp), _ptr(qp[L.NQP:]) if want_parts else None,
+                                      int(flags), _stream(x))
+    if rc == L.ENOTSUP:
+        return None
+    L.check(rc, 'cnnq_pc_minmax_qdq_group')
+    if want_parts:
+        stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
+        stats[L.STAT_MIN] = qp[L.NQP]
+        stats[L.STAT_MAX] = qp[L.NQP + 1]
+        return y, dict(stats=stats, qp=qp[:L.NQP], diag=None)
+    return y
+
+
 def minmax_qdq_resident(x, N, C, HW, num_bits, positive=False, out=None, want_parts=False):
     """Config 2 in ONE launch and ONE read of x (cnnq_pc_minmax_qdq_resident): the bits of the three-launch chain
     at 8 instead of 12 bytes per element.  Returns None when the shape has no resident kernel (a channel's batch
@@ -228,12 +280,16 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
                 del _WS_BYTES[key]
                 L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
         y = _out_like(x, out)
+        gws = _group_workspace(x) if resident else None
         L.check(lib.cnnq_pc_minmax_qdq_auto(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)),
-                                            _ptr(_scratch(x, 'cfg2', nbytes)), int(resident), _stream(x)),
+                                            _ptr(_scratch(x, 'cfg2', nbytes)), gws, GROUP_WS_BYTES if resident else 0,
+                                            int(resident), _stream(x)),
                 'cnnq_pc_minmax_qdq_auto')
         return y
     if not exchanging and resident and not want_codes and not want_entropy:
         res = minmax_qdq_resident(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
+        if res is None:
+            res = minmax_qdq_group(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
         if res is not None:
             return res
     y = _out_like(x, out)

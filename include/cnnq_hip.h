@@ -225,24 +225,31 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
  * every workgroup keeps its tile of x in registers; the workgroups that hold pieces of the same channels exchange
  * their {min, max} pairs through `ws` (write-through stores, one arrival counter per channel group, a bounded wait
  * that falls back to recomputing the extrema from x - never a deadlock, never different bits).
- *   ws   cnnq_pc_group_workspace(N, C, HW) bytes, 128-byte aligned, ZEROED ONCE by the caller before its first use
- *        (the kernel re-arms it); one workspace must not be used by two launches that can run concurrently.
- *        Word 0 is a status word: bit 0 is set when a wait timed out (diagnostic only, results are unaffected).
+ *   ws   from cnnq_group_ws_alloc(bytes >= cnnq_pc_group_workspace(N, C, HW)): fine-grained (uncached) device
+ *        memory, zeroed once (the kernel re-arms it) - in cached device memory a reader's L2 may still hold a pair
+ *        line of an earlier launch; one workspace must not be used by two launches that can run concurrently.
+ *        Word 0 is a status word (cnnq_group_ws_status copies it to the host, synchronising): bit 0 is set when
+ *        a wait timed out (diagnostic only, results are unaffected).
  *   qp   out: qp[CNNQ_NQP][C].   mm: optional out [2][C] = the per-channel min and max.
  *   flags  bit 0: take the recompute path unconditionally (tests).
  * Same shape / alignment conditions and CNNQ_ENOTSUP convention as cnnq_pc_minmax_qdq_resident.
  * cnnq_pc_group_describe: out[8] = {A, K, mode, S, column blocks, workgroups per group, groups, workgroups}. */
 size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW);
+int cnnq_group_ws_alloc(size_t bytes, void** ws);   /* allocates + zeroes, synchronises the device */
+int cnnq_group_ws_free(void* ws);
+int cnnq_group_ws_status(const void* ws, uint32_t* status_host);
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              void* ws, float* qp, float* mm, unsigned flags, void* stream);
 
-/* Config 2 behind one call and one caller workspace `ws` of cnnq_pc_minmax_qdq_workspace(N, C, HW) bytes
- * (4-byte aligned; floats qp[CNNQ_NQP][C], mm[2][C], pmm[G][2][C]): the resident single launch when
- * allow_resident != 0 and the shape has one (mm is then valid), the three-launch chain otherwise. */
+/* Config 2 behind one call.  `ws`: caller workspace of cnnq_pc_minmax_qdq_workspace(N, C, HW) bytes (4-byte aligned;
+ * floats qp[CNNQ_NQP][C], mm[2][C], pmm[G][2][C]).  allow_single_launch != 0: the resident single launch when the
+ * shape has one, else - when `gws` (a zeroed-once group workspace of gws_bytes >= cnnq_pc_group_workspace(...), see
+ * cnnq_pc_minmax_qdq_group) is given - the group-exchange single launch; mm is valid after either.  Otherwise,
+ * and for shapes neither supports, the three-launch chain. */
 size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW);
 int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                            float* ws, int allow_resident, void* stream);
+                            float* ws, void* gws, size_t gws_bytes, int allow_single_launch, void* stream);
 
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace

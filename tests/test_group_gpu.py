@@ -1,0 +1,184 @@
+"""The group-exchange single-launch form of config 2 (cnnq_pc_minmax_qdq_group, csrc/cnnq_group.hip.h): same bits
+as the reference-pinned golden vectors, the oracle and the three-launch chain on every tile shape, with the workgroup
+exchange exercised - groups of 2 .. 208 workgroups, one- and two-level arrival counters, a workspace zeroed ONCE and
+shared by launches of different geometry, rotating inputs (no launch may see the previous launch's extrema), HIP-graph
+replay, the bounded-wait fallback forced, NaN / inf semantics, and the BASELINE-sized 1.64 GB layers.
+Needs an MI355X: `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal
+from oracle import quant_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from cnn_quantization_amd import ops as _ops
+    return _ops
+
+
+def describe(N, C, HW):
+    from cnn_quantization_amd import _lib
+    out = (ctypes.c_int32 * 8)()
+    rc = _lib.load().cnnq_pc_group_describe(N, C, HW, out)
+    return rc, dict(zip(('A', 'K', 'mode', 'S', 'ncb', 'Gs', 'groups', 'wgs'), list(out)))
+
+
+def classic(ops, x, bits, half):
+    """The three-launch chain: want_codes keeps it off the single-launch paths."""
+    N, C = x.shape[:2]
+    y, codes, parts = ops.minmax_qdq_fused(x, N, C, x[0, 0].numel(), bits, half, want_codes=True, want_parts=True)
+    return y, parts
+
+
+def test_group_golden_bit_exact(ops, golden):
+    """The config-2 cases recorded from the reference (12 with a float4 layout): dequantized floats, min / max,
+    scale / zero point bit for bit - with the exchange, and with the recompute path forced."""
+    from cnn_quantization_amd import _lib as L
+    g = golden('act_pc')
+    n = 0
+    for key in g.np('names'):
+        key = str(key)
+        name, si = key.rsplit('_s', 1)
+        if not name.startswith('cfg2') or 'baa' in name:
+            continue
+        x = g.t('x' + si).cuda()
+        N, C = x.shape[:2]
+        bits, half = int(g.np(key + '_bits')), bool(g.np(key + '_half'))
+        if describe(N, C, x[0, 0].numel())[0] != 0:      # [3,16,5,9]: H*W = 45
+            assert ops.minmax_qdq_group(x, N, C, x[0, 0].numel(), bits, half) is None
+            continue
+        for flags in (0, 1):
+            y, parts = ops.minmax_qdq_group(x, N, C, x[0, 0].numel(), bits, half, want_parts=True, flags=flags)
+            assert bits_equal(y.cpu(), g.np(key + '_y')), (key, flags)
+            assert bits_equal(parts['stats'][L.STAT_MAX].cpu(), g.np('s%s_stat_max' % si)), key
+            assert bits_equal(parts['stats'][L.STAT_MIN].cpu(), g.np('s%s_stat_min' % si)), key
+        n += 1
+    assert n == 12
+
+
+SHAPES = [
+    (3, 8, 7, 7), (70, 40, 7, 7), (300, 24, 7, 7),          # straddling float4s; several column blocks and batch splits
+    (2, 8, 14, 14), (37, 24, 14, 14), (64, 256, 14, 14), (200, 12, 14, 14),
+    (5, 3, 28, 28), (33, 16, 28, 28), (130, 20, 28, 28),
+    (9, 4, 56, 56), (70, 6, 56, 56),                         # a channel row wider than a workgroup: slices x splits
+    (66, 3, 112, 112), (260, 2, 112, 112),                   # two-level arrival (more than 16 members per group)
+    (130, 2, 40, 36), (1, 1100, 2, 2), (4, 260, 1, 4), (2, 3, 64, 80), (600, 2, 8, 8),
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('half', [False, True])
+def test_group_equals_chain_and_oracle(ops, shape, half):
+    gen = torch.Generator().manual_seed(sum(shape) + int(half))
+    N, C, H, W = shape
+    rc, d = describe(N, C, H * W)
+    assert rc == 0
+    yc = None
+    for rnd in range(3):          # a different tensor every launch, the same (never re-zeroed) workspace
+        x = torch.randn(shape, generator=gen) * (torch.rand(1, C, 1, 1, generator=gen) * 4 + 0.05) + \
+            torch.randn(1, C, 1, 1, generator=gen)
+        xd = x.cuda()
+        y, parts = ops.minmax_qdq_group(xd, N, C, H * W, 4, half, want_parts=True, flags=1 if rnd == 1 else 0)
+        assert torch.equal(parts['stats'][0], xd.amin(dim=(0, 2, 3))) and torch.equal(parts['stats'][1], xd.amax(dim=(0, 2, 3)))
+        yc, pc = classic(ops, xd, 4, half)
+        assert torch.equal(yc, y) and torch.equal(pc['qp'], parts['qp']), (shape, d, rnd)
+    assert bits_equal(y.cpu(), O.act_per_channel_qdq(x, 4, half_range=half)), (shape, d)
+    assert ops.group_status(xd) in (0, 1)        # 1: the forced recompute of round 1 reported itself
+
+
+def test_group_plans_cover_one_and_two_level_arrival():
+    levels = set()
+    for shape in SHAPES + [(512, 64, 112, 112), (512, 256, 56, 56), (512, 2048, 7, 7)]:
+        rc, d = describe(shape[0], shape[1], shape[2] * shape[3])
+        assert rc == 0
+        levels.add(1 if d['Gs'] <= 16 else 2)
+        assert d['S'] * d['K'] >= shape[0] and d['Gs'] <= 512
+    assert levels == {1, 2}
+    assert describe(512, 64, 112 * 112)[1]['Gs'] == 208
+
+
+def test_group_nan_inf_follow_torch(ops):
+    """torch.min / torch.max propagate NaN (iq.py:416,423): a NaN poisons exactly its channel, also through the
+    exchange; +-inf give an infinite range.  NaN positions and all other bits as the oracle."""
+    def same(a, b):
+        a, b = a.numpy(), b.numpy()
+        na, nb = np.isnan(a), np.isnan(b)
+        return np.array_equal(na, nb) and np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32))
+
+    gen = torch.Generator().manual_seed(3)
+    for shape in ((70, 8, 14, 14), (40, 12, 7, 7), (40, 3, 56, 56), (130, 5, 28, 28)):
+        x = torch.randn(shape, generator=gen)
+        x[1, 2, 3, 4] = float('nan')
+        x[0, 0, 0, 0] = float('inf')
+        x[2, 1, 1, 1] = float('-inf')
+        for half in (False, True):
+            ref = O.act_per_channel_qdq(x, 4, half_range=half)
+            y = ops.minmax_qdq_group(x.cuda(), shape[0], shape[1], shape[2] * shape[3], 4, half)
+            assert same(y.cpu(), ref), (shape, half)
+            assert bool(torch.isnan(y[:, 2]).all()) and not bool(torch.isnan(y[:, 3:]).any())
+
+
+def test_group_rearms_and_replays_from_a_graph(ops):
+    """The exchange workspace is zeroed once; 50 launches in a row and 20 graph replays give the chain's bits."""
+    torch.manual_seed(7)
+    x = torch.randn(64, 128, 56, 56, device='cuda') * 2
+    rc, d = describe(64, 128, 3136)
+    assert rc == 0 and d['Gs'] > 1
+    y = torch.empty_like(x)
+    for _ in range(50):
+        x.mul_(1.001)
+        ops.minmax_qdq_group(x, 64, 128, 3136, 4, False, out=y)
+    ref, _ = classic(ops, x, 4, False)
+    assert torch.equal(y, ref)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.minmax_qdq_group(x, 64, 128, 3136, 4, False, out=y)      # allocates this stream's workspace
+        graph = torch.cuda.CUDAGraph()
+        y.zero_()
+        with torch.cuda.graph(graph, stream=side):
+            ops.minmax_qdq_group(x, 64, 128, 3136, 4, False, out=y)
+        for i in range(20):
+            x.mul_(1.01)
+            graph.replay()
+        st = ops.group_status(x)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref, _ = classic(ops, x, 4, False)
+    assert torch.equal(y, ref)
+    assert st == 0 and ops.group_status(x) in (0, 1)
+
+
+@pytest.mark.parametrize('shape,half', [((512, 64, 112, 112), True), ((512, 256, 56, 56), False),
+                                        ((512, 2048, 7, 7), False), ((64, 64, 112, 112), True),
+                                        ((512, 512, 28, 28), False), ((64, 64, 56, 56), True),
+                                        ((64, 1024, 14, 14), False)])
+def test_group_full_size_properties(ops, shape, half):
+    """BASELINE-sized layers (1.64 GB: groups of 208 / 64 workgroups, 13-16 K workgroups per launch): properties
+    that need no oracle, plus equality with the three-launch chain - twice, on different data."""
+    from cnn_quantization_amd import _lib as L
+    N, C, H, W = shape
+    torch.manual_seed(12345)
+    x = torch.empty(shape, device='cuda').normal_()
+    for rnd in range(2):
+        x.mul_(torch.rand(1, C, 1, 1, device='cuda') * 3 + 0.1)
+        y, parts = ops.minmax_qdq_group(x, N, C, H * W, 4, half, want_parts=True)
+        st, qp = parts['stats'], parts['qp']
+        assert torch.equal(st[L.STAT_MAX], x.amax(dim=(0, 2, 3)))
+        assert torch.equal(st[L.STAT_MIN], x.amin(dim=(0, 2, 3)))
+        sc, zp = qp[0].view(1, C, 1, 1), qp[1].view(1, C, 1, 1)
+        codes = torch.round(y / sc + zp)
+        assert float(codes.min()) >= 0 and float(codes.max()) <= 15
+        assert torch.equal((codes - zp) * sc, y)
+        del codes
+        yc, pc = classic(ops, x, 4, half)
+        assert torch.equal(pc['qp'], qp)
+        assert torch.equal(yc, y)
+        del yc, y
+    assert ops.group_status(x) in (0, 1)

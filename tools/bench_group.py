@@ -28,7 +28,8 @@ def main():
     lib = _lib.load()
     dev = torch.device('cuda')
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)          # zeroed ONCE
+    ws = ctypes.c_void_p()
+    _lib.check(lib.cnnq_group_ws_alloc(32 << 20, ctypes.byref(ws)), 'alloc')      # fine-grained, zeroed ONCE
     want = set(args.shapes.split(',')) if args.shapes else None
     tot = {'chain': 0., 'group': 0.}
     elems_total = 0
@@ -48,7 +49,7 @@ def main():
         qp2 = torch.empty((3, C), dtype=torch.float32, device=dev)
         d = (ctypes.c_int32 * 8)()
         rc = lib.cnnq_pc_group_describe(N, C, HW, d)
-        assert rc == 0 and lib.cnnq_pc_group_workspace(N, C, HW) <= ws.numel()
+        assert rc == 0 and lib.cnnq_pc_group_workspace(N, C, HW) <= (32 << 20)
 
         def chain(i):
             _lib.check(lib.cnnq_pc_minmax_qdq(xs[i].data_ptr(), ys[i].data_ptr(), N, C, HW, 4, int(half), pmm.data_ptr(),
@@ -56,7 +57,7 @@ def main():
 
         def group(i):
             _lib.check(lib.cnnq_pc_minmax_qdq_group(xs[i].data_ptr(), yr[i].data_ptr(), N, C, HW, 4, int(half),
-                                                    ws.data_ptr(), qp2.data_ptr(), None, 0, st), 'group')
+                                                    ws, qp2.data_ptr(), None, 0, st), 'group')
         for i in range(nbuf):
             chain(i)
         bad = 0
@@ -78,7 +79,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[name] = e0.elapsed_time(e1) * 1e-3 / args.reps
-        status = int(ws[:4].view(torch.int32).item())
+        stw = ctypes.c_uint32()
+        lib.cnnq_group_ws_status(ws, ctypes.byref(stw))
+        status = int(stw.value)
         print('C=%4d HW=%5d half=%d x%2d | A=%d K=%2d S=%3d Gs=%3d wgs=%5d | chain %7.1f us %5.0f GB/s(12B) | group %7.1f us '
               '%5.0f GB/s(8B) %5.0f GB/s(12B-equiv) | x%.2f | mismatches=%d status=%d' % (
                   C, HW, half, count, d[0], d[1], d[3], d[5], d[7], times['chain'] * 1e6, n * 12 / times['chain'] / 1e9,
