@@ -39,7 +39,10 @@ constexpr int GRP_CNT_STRIDE = 64;                 // words between two groups' 
                                                    // groups serialised on one line (~130 ns per workgroup, measured)
 constexpr int GRP_GS_MAX = 512;                    // members of a group (all co-resident: capacity >= 512 workgroups)
 #ifndef GRP_ACQUIRE
-#define GRP_ACQUIRE 1     // agent-scope acquire (buffer_inv sc1) between the wait and the reads of the group's pairs
+#define GRP_ACQUIRE 0     // 1: agent-scope acquire (buffer_inv sc1) between the wait and the reads of the group's pairs.
+                          // Not needed by construction - the pairs live in fine-grained (uncached) memory, a block is
+                          // written only by its group and read only after the group is complete - and it costs 6 %
+                          // (each buffer_inv drops the CU's whole L1 under three streaming workgroups); kept as a switch.
 #endif
 constexpr int GRP_SUB = 16;                        // members per arrival counter
 #ifndef GRP_K32_WAVES
@@ -167,6 +170,15 @@ __device__ __forceinline__ void group_minmax_from_x(const float* __restrict__ x,
     wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
 }
 
+// one departure from a counter line (words: [0] arrivals, [1] departures, [2] ready flag); the last of `actors` zeroes it
+__device__ __forceinline__ void grp_leave(unsigned* ln, unsigned actors) {
+    if (__hip_atomic_fetch_add(ln + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == actors - 1u) {
+        __hip_atomic_store(ln + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ln + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ln + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ws: [0] status word, [256 ..) 16384 arrival/departure counters, one per group and per 256-byte line (a fixed
 // region, so that no geometry's pairs ever land on another geometry's counters), then one 128-byte-aligned block of 8-byte
 // {min, max} pairs per group: [member] (mode 1) or [member][k] (mode 2)
@@ -232,13 +244,6 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
         unsigned* top = ws.cnt + (size_t)rb.group * (nsub > 1 ? nsub + 1 : 1) * GRP_CNT_STRIDE;
         unsigned* line = (nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top;
-        auto leave = [](unsigned* ln, unsigned actors) {
-            if (__hip_atomic_fetch_add(ln + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == actors - 1u) {
-                __hip_atomic_store(ln + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ln + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ln + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
         const unsigned seen = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         bool ready = (nsub == 1) && seen >= m_i;
         if (nsub > 1 && seen == m_i) {
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
                     __hip_atomic_store(top + (size_t)(1 + j) * GRP_CNT_STRIDE + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flags are out before this actor departs
                 for (int j = 0; j < nsub; ++j)
-                    leave(top + (size_t)(1 + j) * GRP_CNT_STRIDE, (unsigned)min(GRP_SUB, Gs - j * GRP_SUB) + 1u);
+                    grp_leave(top + (size_t)(1 + j) * GRP_CNT_STRIDE, (unsigned)min(GRP_SUB, Gs - j * GRP_SUB) + 1u);
                 ready = true;
             }
         }
@@ -269,7 +274,6 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
 #if GRP_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
-        leave(line, (nsub > 1) ? m_i + 1u : m_i);
         if (timed_out) atomicOr(ws.status, 1u);
         sh_timed_out = timed_out;
     }
@@ -340,6 +344,15 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
             for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
             if (ok) stv_nt<4>(y + base + (size_t)j * (size_t)g.P, o);
         }
+    }
+    // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
+    //      counter line re-arms it for the next launch
+    if (tid == 0) {
+        const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+        const int si = rb.member / GRP_SUB;
+        const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
+        unsigned* top = ws.cnt + (size_t)rb.group * (nsub > 1 ? nsub + 1 : 1) * GRP_CNT_STRIDE;
+        grp_leave((nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top, (nsub > 1) ? m_i + 1u : m_i);
     }
 }
 
