@@ -92,7 +92,17 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 // Cache, so the statistics passes use them only for tensors too large for the next pass to find
 // anything still cached (NT_BYTES).  The Q/DQ pass always uses them: x is read for the last time and
 // y is never re-read by this path.
-constexpr int64_t NT_BYTES = (int64_t)384 << 20;   // swept 0..1000 MB on the ResNet-50 set: flat optimum 250-400
+constexpr int64_t NT_BYTES_DEFAULT = (int64_t)384 << 20;   // swept 0..1000 MB on the ResNet-50 set: flat optimum 250-400
+// CNNQ_NT_BYTES overrides it (read once): 0 forces the non-temporal template instances on every tensor, which is how
+// the parity tests reach the instances that otherwise only the > 384 MB layers of the benchmark select
+inline int64_t nt_bytes() {
+    static const int64_t v = [] {
+        const char* e = getenv("CNNQ_NT_BYTES");
+        return (e && *e) ? (int64_t)atoll(e) : NT_BYTES_DEFAULT;
+    }();
+    return v;
+}
+#define NT_BYTES nt_bytes()
 
 template <int VEC>
 __device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&v)[VEC]) {
@@ -117,6 +127,14 @@ template <int VEC, bool NTL>
 __device__ __forceinline__ void ldv_sel(const float* __restrict__ p, float (&v)[VEC]) {
     if constexpr (NTL) ldv_nt<VEC>(p, v); else ldv<VEC>(p, v);
 }
+
+// torch.min / torch.max propagate NaN (a NaN activation poisons its channel's range, iq.py:416,423); v_min/v_max
+// return the other operand.  The hot loop keeps v_min/v_max plus one unordered-compare per two elements and
+// poisons the lane's result afterwards; every merge above the lane uses these propagating forms.
+__device__ __forceinline__ float pmin(float a, float b) { return (a < b || a != a) ? a : b; }
+__device__ __forceinline__ float pmax(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double pmind(double a, double b) { return (a < b || a != a) ? a : b; }
+__device__ __forceinline__ double pmaxd(double a, double b) { return (a > b || a != a) ? a : b; }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }

@@ -40,10 +40,13 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
         col[j] = ok[j] ? c : b.col0;
     }
     float mn[J][A], mx[J][A];
+    bool nan[J];   // A == 1: a NaN seen by this lane's column j (v_min / v_max drop it; torch.min / max propagate it)
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+    for (int j = 0; j < J; ++j) {
+        nan[j] = false;
 #pragma unroll
         for (int a = 0; a < A; ++a) { mn[j][a] = INFINITY; mx[j][a] = -INFINITY; }
+    }
     const float* row = x + (size_t)b.n0 * (size_t)g.P;
     constexpr int NU = (J == 1) ? 4 : 2;  // samples in flight per lane
 #pragma unroll NU
@@ -56,14 +59,20 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
             if constexpr (A == 1 && VEC == 4) {
                 mn[j][0] = fminf(fminf(mn[j][0], fminf(v[j][0], v[j][1])), fminf(v[j][2], v[j][3]));
                 mx[j][0] = fmaxf(fmaxf(mx[j][0], fmaxf(v[j][0], v[j][1])), fmaxf(v[j][2], v[j][3]));
+                nan[j] |= __builtin_isunordered(v[j][0], v[j][1]) | __builtin_isunordered(v[j][2], v[j][3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    mn[j][A == 1 ? 0 : e] = fminf(mn[j][A == 1 ? 0 : e], v[j][e]);
-                    mx[j][A == 1 ? 0 : e] = fmaxf(mx[j][A == 1 ? 0 : e], v[j][e]);
+                    mn[j][A == 1 ? 0 : e] = pmin(mn[j][A == 1 ? 0 : e], v[j][e]);
+                    mx[j][A == 1 ? 0 : e] = pmax(mx[j][A == 1 ? 0 : e], v[j][e]);
                 }
             }
         }
+    }
+    if constexpr (A == 1 && VEC == 4) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (nan[j]) { mn[j][0] = NAN; mx[j][0] = NAN; }
     }
     float* pn = pmm + (size_t)(2 * b.grp) * g.C;
     float* px = pn + g.C;
@@ -72,13 +81,13 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
         float tn = INFINITY, tx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            if (ok[j]) { tn = fminf(tn, mn[j][0]); tx = fmaxf(tx, mx[j][0]); }
+            if (ok[j]) { tn = pmin(tn, mn[j][0]); tx = pmax(tx, mx[j][0]); }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { tn = fminf(tn, shfl_xor_f(tn, m)); tx = fmaxf(tx, shfl_xor_f(tx, m)); }
+        for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
         if (lane == 0) { l_mn[wv] = tn; l_mx[wv] = tx; }
         __syncthreads();
         if (tid == 0) {
-            for (int i = 1; i < TPB / 64; ++i) { tn = fminf(tn, l_mn[i]); tx = fmaxf(tx, l_mx[i]); }
+            for (int i = 1; i < TPB / 64; ++i) { tn = pmin(tn, l_mn[i]); tx = pmax(tx, l_mx[i]); }
             pn[b.c0] = tn;
             px[b.c0] = tx;
         }
@@ -100,7 +109,7 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
         for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
             const int lo = (ch - b.c0) * epc;
             float tn = INFINITY, tx = -INFINITY;
-            for (int e = lo; e < lo + epc; ++e) { tn = fminf(tn, l_mn[e]); tx = fmaxf(tx, l_mx[e]); }
+            for (int e = lo; e < lo + epc; ++e) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
             pn[ch] = tn;
             px[ch] = tx;
         }
@@ -109,9 +118,9 @@ __global__ void __launch_bounds__(TPB) k_minmax(const float* __restrict__ x, con
     for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
         const int lo = (ch - b.c0) * epc;
         float tn = INFINITY, tx = -INFINITY;
-        for (int e = lo + lane; e < lo + epc; e += 64) { tn = fminf(tn, l_mn[e]); tx = fmaxf(tx, l_mx[e]); }
+        for (int e = lo + lane; e < lo + epc; e += 64) { tn = pmin(tn, l_mn[e]); tx = pmax(tx, l_mx[e]); }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { tn = fminf(tn, shfl_xor_f(tn, m)); tx = fmaxf(tx, shfl_xor_f(tx, m)); }
+        for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
         if (lane == 0) { pn[ch] = tn; px[ch] = tx; }
     }
 }
@@ -124,11 +133,11 @@ __device__ __forceinline__ void reduce_pairs(const float* __restrict__ pmm, int 
     mn = INFINITY;
     mx = -INFINITY;
     for (int gi = lane; gi < G; gi += 64) {
-        mn = fminf(mn, pmm[(size_t)(2 * gi) * C + c]);
-        mx = fmaxf(mx, pmm[(size_t)(2 * gi + 1) * C + c]);
+        mn = pmin(mn, pmm[(size_t)(2 * gi) * C + c]);
+        mx = pmax(mx, pmm[(size_t)(2 * gi + 1) * C + c]);
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, shfl_xor_f(mn, m)); mx = fmaxf(mx, shfl_xor_f(mx, m)); }
+    for (int m = 32; m >= 1; m >>= 1) { mn = pmin(mn, shfl_xor_f(mn, m)); mx = pmax(mx, shfl_xor_f(mx, m)); }
 }
 
 // pmm[G][2][C] -> out[2][C]: the rank-local extrema that ranks exchange (all_gather)

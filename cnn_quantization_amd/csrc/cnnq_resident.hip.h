@@ -27,12 +27,6 @@
 
 namespace {
 
-// torch.min / torch.max propagate NaN (a NaN activation poisons its channel's range, iq.py:416,423); v_min/v_max
-// return the other operand.  The hot loop keeps v_min/v_max plus one unordered-compare per two elements and
-// poisons the lane's result afterwards; every merge above the lane uses these propagating forms.
-__device__ __forceinline__ float pmin(float a, float b) { return (a < b || a != a) ? a : b; }
-__device__ __forceinline__ float pmax(float a, float b) { return (a > b || a != a) ? a : b; }
-
 template <int A>
 __device__ __forceinline__ void lane_acc(const float (&v)[4], float (&mn)[A], float (&mx)[A], bool& nan) {
     if constexpr (A == 1) {

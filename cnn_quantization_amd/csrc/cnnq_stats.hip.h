@@ -14,10 +14,13 @@ struct Mom {
     __device__ __forceinline__ void init() {
         mn = INFINITY; mx = -INFINITY; s = 0.; ss = 0.; rs = 0.; rss = 0.;
     }
+    // NaN: torch's min / max propagate it; the sums do so by themselves.  add4 (the hot form) keeps v_min / v_max
+    // (they return the other operand) and k_moments poisons mn / mx afterwards when the sum of squares came out
+    // NaN - that happens iff an element was NaN (inf * inf = inf, no cancellation); the merges propagate.
     template <bool RELU>
     __device__ __forceinline__ void add(float v) {
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+        mn = pmin(mn, v);
+        mx = pmax(mx, v);
         const double d = (double)v;
         s += d;
         ss = fma(d, d, ss);
@@ -44,8 +47,8 @@ struct Mom {
     }
     template <bool RELU>
     __device__ __forceinline__ void merge(const Mom& o) {
-        mn = fminf(mn, o.mn);
-        mx = fmaxf(mx, o.mx);
+        mn = pmin(mn, o.mn);
+        mx = pmax(mx, o.mx);
         s += o.s;
         ss += o.ss;
         if constexpr (RELU) { rs += o.rs; rss += o.rss; }
@@ -119,6 +122,11 @@ __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, co
         }
     }
 
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+            if (acc[j][a].ss != acc[j][a].ss) { acc[j][a].mn = NAN; acc[j][a].mx = NAN; }
     const double rows = (double)(b.n1 - b.n0);
     if (g.mode == 1) {
         // one channel per workgroup: registers -> wave shuffle -> 4 LDS entries
@@ -203,8 +211,8 @@ __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part
     double mn = INFINITY, mx = -INFINITY, s = 0., ss = 0., cnt = 0., rs = 0., rss = 0.;
     for (int gi = lane; gi < G; gi += 64) {
         const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
-        mn = fmin(mn, p[(size_t)CNNQ_MOM_MIN * C]);
-        mx = fmax(mx, p[(size_t)CNNQ_MOM_MAX * C]);
+        mn = pmind(mn, p[(size_t)CNNQ_MOM_MIN * C]);
+        mx = pmaxd(mx, p[(size_t)CNNQ_MOM_MAX * C]);
         s += p[(size_t)CNNQ_MOM_SUM * C];
         ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
         cnt += p[(size_t)CNNQ_MOM_COUNT * C];
@@ -215,8 +223,8 @@ __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        mn = fmin(mn, shfl_xor_d(mn, m));
-        mx = fmax(mx, shfl_xor_d(mx, m));
+        mn = pmind(mn, shfl_xor_d(mn, m));
+        mx = pmaxd(mx, shfl_xor_d(mx, m));
         s += shfl_xor_d(s, m);
         ss += shfl_xor_d(ss, m);
         cnt += shfl_xor_d(cnt, m);

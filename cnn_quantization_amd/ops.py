@@ -187,16 +187,32 @@ _GROUP_WS = {}
 GROUP_WS_BYTES = 16 << 20
 
 
+_GROUP_POOL = {}
+GROUP_POOL_SIZE = 4
+
+
 def _group_workspace(x):
     """The exchange workspace of the group single launch (cnnq_pc_minmax_qdq_group): fine-grained device memory
     from cnnq_group_ws_alloc, zeroed ONCE, one per (device, stream) - launches on one stream are ordered, so they
-    share it; the kernel re-arms its counters.  Returns the raw device pointer (a ctypes.c_void_p)."""
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    share it; the kernel re-arms its counters.  Allocation synchronises the device, which a stream capture does
+    not survive: the first call on a device allocates a small pool, later streams (a capture stream included)
+    take from it; with the pool empty under capture there is no workspace (None: the caller takes the chain).
+    Returns the raw device pointer (a ctypes.c_void_p)."""
+    dev = x.device.index
+    key = (dev, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _GROUP_WS.get(key)
-    if ws is None:
-        ws = ctypes.c_void_p()
-        L.check(L.load().cnnq_group_ws_alloc(GROUP_WS_BYTES, ctypes.byref(ws)), 'cnnq_group_ws_alloc')
-        _GROUP_WS[key] = ws
+    if ws is not None:
+        return ws
+    pool = _GROUP_POOL.setdefault(dev, [])
+    if not pool:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        lib = L.load()
+        for _ in range(GROUP_POOL_SIZE):
+            w = ctypes.c_void_p()
+            L.check(lib.cnnq_group_ws_alloc(GROUP_WS_BYTES, ctypes.byref(w)), 'cnnq_group_ws_alloc')
+            pool.append(w)
+    ws = _GROUP_WS[key] = pool.pop()
     return ws
 
 
@@ -219,10 +235,13 @@ def minmax_qdq_group(x, N, C, HW, num_bits, positive=False, out=None, want_parts
     nbytes = lib.cnnq_pc_group_workspace(N, C, HW)
     if nbytes == 0 or nbytes > GROUP_WS_BYTES:
         return None
+    gws = _group_workspace(x)
+    if gws is None:
+        return None
     y = _out_like(x, out)
     qp = torch.empty((L.NQP + 2, C), dtype=torch.float32, device=x.device)
     rc = lib.cnnq_pc_minmax_qdq_group(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)),
-                                      _group_workspace(x), _ptr(qp), _ptr(qp[L.NQP:]) if want_parts else None,
+                                      gws, _ptr(qp), _ptr(qp[L.NQP:]) if want_parts else None,
                                       int(flags), _stream(x))
     if rc == L.ENOTSUP:
         return None
@@ -273,16 +292,20 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     if not exchanging and not (want_codes or want_entropy or want_parts):
         # the hot call: one C entry point, one cached workspace, no torch allocation besides the result
         key = (N, C, HW)
-        nbytes = _WS_BYTES.get(key)
-        if nbytes is None:
-            nbytes = _WS_BYTES[key] = lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+        plan = _WS_BYTES.get(key)
+        if plan is None:
+            nbytes = lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
             if nbytes == 0:
-                del _WS_BYTES[key]
                 L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+            d = (ctypes.c_int32 * 8)()
+            wants_group = (lib.cnnq_pc_resident_describe(N, C, HW, d) != 0
+                           and 0 < lib.cnnq_pc_group_workspace(N, C, HW) <= GROUP_WS_BYTES)
+            plan = _WS_BYTES[key] = (nbytes, wants_group)
+        nbytes, wants_group = plan
         y = _out_like(x, out)
-        gws = _group_workspace(x) if resident else None
+        gws = _group_workspace(x) if (resident and wants_group) else None
         L.check(lib.cnnq_pc_minmax_qdq_auto(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)),
-                                            _ptr(_scratch(x, 'cfg2', nbytes)), gws, GROUP_WS_BYTES if resident else 0,
+                                            _ptr(_scratch(x, 'cfg2', nbytes)), gws, GROUP_WS_BYTES if gws is not None else 0,
                                             int(resident), _stream(x)),
                 'cnnq_pc_minmax_qdq_auto')
         return y

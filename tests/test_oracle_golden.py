@@ -158,3 +158,15 @@ def test_act_bias_correction(golden, name):
     g = golden('bca')
     got = O.act_bias_correction(g.t(name + '/out'), g.t(name + '/out_q').clone(), bool(g.np(name + '/relu_first')))
     assert bits_equal(got.numpy(), g.np(name + '/corrected'))
+
+
+def test_nan_golden(golden):
+    """nan.npz: NaN / inf activations through the reference's config-2 chain; NaN positions and every other bit
+    (the sign / payload bits of a NaN are not semantics: CPU torch itself varies them inside one tensor)."""
+    g = golden('nan')
+    for i in range(int(g.np('n_cases'))):
+        y = O.act_per_channel_qdq(g.t('c%d_x' % i), 4, half_range=bool(g.np('c%d_half' % i))).numpy()
+        ref = g.np('c%d_y' % i)
+        na, nb = np.isnan(y), np.isnan(ref)
+        assert np.array_equal(na, nb) and np.array_equal(y[~na].view(np.uint32), ref[~nb].view(np.uint32)), i
+        assert nb[:, 2].all() and not nb[:, 3:].any()
