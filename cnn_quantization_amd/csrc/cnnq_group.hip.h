@@ -341,7 +341,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         if (j < nrows) {
             float o[4], cd;
 #pragma unroll
+#ifdef GRP_EXPERIMENT_CHEAP_ALU
+            for (int e = 0; e < 4; ++e) { cd = 0.f; o[e] = (v[j][e] + zp[A == 1 ? 0 : e]) * sc[A == 1 ? 0 : e]; }
+#else
             for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
+#endif
             if (ok) stv_nt<4>(y + base + (size_t)j * (size_t)g.P, o);
         }
     }
