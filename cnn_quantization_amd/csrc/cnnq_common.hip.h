@@ -136,6 +136,10 @@ __device__ __forceinline__ float pmax(float a, float b) { return (a > b || a != 
 __device__ __forceinline__ double pmind(double a, double b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ double pmaxd(double a, double b) { return (a > b || a != a) ? a : b; }
 
+// qmax = 2.**num_bits - 1. (iq.py:559: a Python float, i.e. fp64, rounded to fp32 when it meets the tensor): exact up
+// to 24 bits, 2^32 for 'int32' - any width the reference's __gemmlowpQuantize1__ accepts
+__device__ __host__ __forceinline__ float qmax_of(int num_bits) { return (float)(exp2((double)num_bits) - 1.0); }
+
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     }
 
     // ---- scale / zero point of the owned channels (iq.py:559-572), identical in every member
-    const float qm = (float)((1u << num_bits) - 1u);
+    const float qm = qmax_of(num_bits);
     for (int ch = tid; ch < nch; ch += TPB) {
         const float cmn = sh_mn[ch], cmx = sh_mx[ch];
         const float offset = positive ? 0.f : cmn;

@@ -131,7 +131,7 @@ int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom
 int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg, float* qp, float* diag,
                    void* stream) {
     if (!stats || !cfg || !qp || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
-    if (cfg->num_bits < 1 || cfg->num_bits > 8 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
+    if (cfg->num_bits < 1 || cfg->num_bits > 32 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
     if (cfg->bit_alloc && cfg->num_bits <= 4 && !diag) return CNNQ_EINVAL;  // bit table lives in diag
     float* bits_ws = diag ? diag + (size_t)CNNQ_DIAG_BITS * C : nullptr;
     const int threads = (int)(C >= PTPB ? PTPB : ((C + 63) / 64) * 64);
@@ -227,6 +227,41 @@ int cnnq_pc_dequantize_u8(const uint8_t* codes, float* y, int64_t N, int64_t C, 
     return dequantize_codes(codes, y, N, C, HW, qp, 8, stream);
 }
 
+// variable-width packed codes (bit allocation as the stored format)
+static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, int64_t N, int64_t C, int64_t HW,
+                         const float* qp, const float* bits, const uint32_t* rowoff, void* stream) {
+    if (!packed || !qp || !bits || !rowoff || N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
+    if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31 || C > 65535) return CNNQ_ERANGE;
+    int64_t S = (4096 + C - 1) / C;           // ~4096 workgroups
+    if (S > N) S = N;
+    const dim3 grid((unsigned)(C * S)), block(TPB);
+    if (quant)
+        hipLaunchKernelGGL((k_packed<true>), grid, block, 0, (hipStream_t)stream, x, y, packed, (int)N, (int)C, (int)HW,
+                           (int)S, qp, bits, rowoff);
+    else
+        hipLaunchKernelGGL((k_packed<false>), grid, block, 0, (hipStream_t)stream, x, y, packed, (int)N, (int)C, (int)HW,
+                           (int)S, qp, bits, rowoff);
+    return launch_status();
+}
+
+int cnnq_pc_packed_layout(const float* bits, int64_t C, int64_t HW, uint32_t* rowoff, void* stream) {
+    if (!bits || !rowoff || C <= 0 || HW <= 0 || C * HW >= (int64_t)1 << 31) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_packed_layout, dim3(1), dim3(PTPB), 0, (hipStream_t)stream, bits, (int)C, (int)HW, rowoff);
+    return launch_status();
+}
+
+int cnnq_pc_quantize_packed(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
+                            const float* bits, const uint32_t* rowoff, void* stream) {
+    if (!x) return CNNQ_EINVAL;
+    return packed_launch(true, x, nullptr, packed, N, C, HW, qp, bits, rowoff, stream);
+}
+
+int cnnq_pc_dequantize_packed(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                              const float* bits, const uint32_t* rowoff, void* stream) {
+    if (!y) return CNNQ_EINVAL;
+    return packed_launch(false, nullptr, y, const_cast<uint8_t*>(packed), N, C, HW, qp, bits, rowoff, stream);
+}
+
 int cnnq_pc_minmax_strided(const float* x, int64_t N, int64_t C, int64_t HW, int64_t sample_stride, float* pmm,
                            void* stream) {
     if (!x || !pmm || !strided_ok(C, HW, sample_stride)) return CNNQ_EINVAL;
@@ -260,7 +295,7 @@ int cnnq_pc_minmax_reduce(const float* pmm, int G, int64_t C, float* out, void* 
 }
 
 int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int positive, float* qp, void* stream) {
-    if (!pmm || !qp || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || num_bits < 1 || num_bits > 8)
+    if (!pmm || !qp || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || num_bits < 1 || num_bits > 32)
         return CNNQ_EINVAL;
     hipLaunchKernelGGL(k_minmax_params, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0,
                        (hipStream_t)stream, pmm, G, (int)C, num_bits, positive ? 1 : 0, qp);
@@ -269,7 +304,8 @@ int cnnq_pc_minmax_params(const float* pmm, int G, int64_t C, int num_bits, int 
 
 int cnnq_pc_minmax_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                        float* pmm, float* qp, uint8_t* codes, uint64_t* hist, void* stream) {
-    if (!x || !y || !pmm || !qp || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
+    if (!x || !y || !pmm || !qp || num_bits < 1 || num_bits > 32) return CNNQ_EINVAL;
+    if ((codes || hist) && num_bits > 8) return CNNQ_EINVAL;   // one byte per code, 256 histogram bins
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
     int rc = cnnq_pc_minmax(x, N, C, HW, pmm, stream);
@@ -293,7 +329,7 @@ int cnnq_pc_resident_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) 
 
 int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                                 float* qp, float* mm, void* stream) {
-    if (!x || !y || !qp || num_bits < 1 || num_bits > 8) return CNNQ_EINVAL;
+    if (!x || !y || !qp || num_bits < 1 || num_bits > 32) return CNNQ_EINVAL;
     WPlan p;
     const int rc = plan_whole(N, C, HW, al16(x) && al16(y), &p);
     if (rc) return rc;
@@ -339,7 +375,7 @@ int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
 
 int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              void* ws, float* qp, float* mm, unsigned flags, void* stream) {
-    if (!x || !y || !ws || !qp || num_bits < 1 || num_bits > 8 || ((uintptr_t)ws & 127)) return CNNQ_EINVAL;
+    if (!x || !y || !ws || !qp || num_bits < 1 || num_bits > 32 || ((uintptr_t)ws & 127)) return CNNQ_EINVAL;
     GPlan p;
     const int rc = plan_group(N, C, HW, al16(x) && al16(y), &p);
     if (rc) return rc;
@@ -357,7 +393,7 @@ size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW) {
 
 int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                             float* ws, void* gws, size_t gws_bytes, int allow_single_launch, void* stream) {
-    if (!x || !y || !ws || num_bits < 1 || num_bits > 8 || C <= 0) return CNNQ_EINVAL;
+    if (!x || !y || !ws || num_bits < 1 || num_bits > 32 || C <= 0) return CNNQ_EINVAL;
     float* qp = ws;
     float* mm = ws + (size_t)CNNQ_NQP * C;
     float* pmm = mm + 2 * (size_t)C;

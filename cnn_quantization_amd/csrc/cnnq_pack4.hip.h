@@ -3,6 +3,7 @@
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"
+#include "cnnq_params.hip.h"   // PTPB
 
 namespace {
 
@@ -93,6 +94,101 @@ __global__ void __launch_bounds__(TPB) k_unpack4_dq(const uint8_t* __restrict__ 
             for (int e = 0; e < 4; ++e)
                 o[e] = ((float)((pk >> (BITS * e)) & ((1u << BITS) - 1u)) - zp[j]) * sc[j];   // iq.py:591-592
             if (ok[j]) stv_nt<4>(y + off + (size_t)col[j] * 4, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// variable-width packed storage (SURVEY.md 8 f3 with bit allocation, iq.py:563-564,582-584): channel c stores
+// bits[c] in 0..8 bits per code, so an activation costs sum(bits)/8 bytes per spatial position instead of 4*C -
+// the deployment format the paper's bit-rate tables assume; the reference only simulates it (codes stay fp32).
+//
+// Layout: row (n, c) = H*W codes of bits[c] bits each, little-endian bit stream (element i occupies bits
+// [i*b, (i+1)*b)), padded to 4 bytes; row (n, c) starts at n * rowoff[C] + rowoff[c] (k_packed_layout: rowoff[c] =
+// running sum of ceil(H*W*bits/32)*4, rowoff[C] = bytes per sample).  A 0-bit channel stores nothing and decodes
+// to the constant (0 - zp) * scale, exactly what the fused Q/DQ returns for it.
+// A lane handles 8 consecutive elements of a row = bits[c] whole bytes; a workgroup walks a flat (row, group)
+// index space of one channel, so small H*W still fills the lanes.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PTPB) k_packed_layout(const float* __restrict__ bits, int C, int HW,
+                                                        uint32_t* __restrict__ rowoff) {
+    // one workgroup; channel counts are small (<= a few thousand): a serial scan by one thread per PTPB-chunk
+    __shared__ uint32_t chunk[PTPB];
+    const int tid = threadIdx.x;
+    const int per = (C + PTPB - 1) / PTPB;
+    uint32_t sum = 0;
+    for (int c = tid * per; c < min(C, (tid + 1) * per); ++c) {
+        const uint32_t b = (uint32_t)bits[c];
+        sum += (((uint32_t)HW * b + 31u) / 32u) * 4u;
+    }
+    chunk[tid] = sum;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int t = 0; t < tid; ++t) base += chunk[t];
+    for (int c = tid * per; c < min(C, (tid + 1) * per); ++c) {
+        rowoff[c] = base;
+        const uint32_t b = (uint32_t)bits[c];
+        base += (((uint32_t)HW * b + 31u) / 32u) * 4u;
+    }
+    if (tid == PTPB - 1) rowoff[C] = base;
+}
+
+template <bool QUANT>
+__global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, float* __restrict__ y,
+                                                uint8_t* __restrict__ packed, int N, int C, int HW, int S,
+                                                const float* __restrict__ qp, const float* __restrict__ bits,
+                                                const uint32_t* __restrict__ rowoff) {
+    const int c = (int)blockIdx.x / S, s = (int)blockIdx.x - c * S;
+    const int n0 = (int)(((int64_t)s * N) / S), n1 = (int)(((int64_t)(s + 1) * N) / S);
+    const int b = (int)bits[c];
+    const float sc = qp[(size_t)CNNQ_QP_SCALE * C + c], zp = qp[(size_t)CNNQ_QP_ZP * C + c];
+    const float qm = qp[(size_t)CNNQ_QP_QMAX * C + c];
+    const uint32_t plane = rowoff[C], roff = rowoff[c];
+    const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
+    const int ngroups = (HW + 7) / 8;
+    const int64_t total = (int64_t)(n1 - n0) * ngroups;
+    const bool vec4 = (HW % 4 == 0) && (((uintptr_t)(QUANT ? (const void*)x : (const void*)y) & 15) == 0);
+    for (int64_t idx = threadIdx.x; idx < total; idx += TPB) {
+        const int r = (int)(idx / ngroups), gi = (int)(idx - (int64_t)r * ngroups);
+        const int n = n0 + r;
+        const int e0 = gi * 8, cnt = min(8, HW - e0);
+        const size_t xoff = ((size_t)n * C + c) * (size_t)HW + e0;
+        uint8_t* rowp = packed + (size_t)n * plane + roff;
+        // bytes of this group: b whole bytes, or - last group of the row - everything up to the padded row end
+        const uint32_t boff = (uint32_t)gi * (uint32_t)b;
+        const uint32_t nb = (gi == ngroups - 1) ? rowbytes - boff : (uint32_t)b;
+        if constexpr (QUANT) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (vec4 && cnt == 8) {
+                ldv_nt<4>(x + xoff, *reinterpret_cast<float(*)[4]>(&v[0]));
+                ldv_nt<4>(x + xoff + 4, *reinterpret_cast<float(*)[4]>(&v[4]));
+            } else {
+                for (int e = 0; e < cnt; ++e) v[e] = x[xoff + e];
+            }
+            unsigned long long w = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float cd;
+                (void)qdq1(v[e], sc, zp, qm, cd);
+                if (e < cnt) w |= (unsigned long long)(unsigned)cd << (e * b);
+            }
+            for (uint32_t k = 0; k < nb; ++k) rowp[boff + k] = (uint8_t)(k < 8 ? (w >> (8 * k)) : 0ull);
+        } else {
+            unsigned long long w = 0;
+            const uint32_t nr = nb < 8 ? nb : 8;
+            for (uint32_t k = 0; k < nr; ++k) w |= (unsigned long long)rowp[boff + k] << (8 * k);
+            const unsigned long long mask = (b >= 8) ? 0xffull : ((1ull << b) - 1ull);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = ((float)((w >> (e * b)) & mask) - zp) * sc;   // iq.py:591-592
+            if (vec4 && cnt == 8) {
+                stv_nt<4>(y + xoff, *reinterpret_cast<float(*)[4]>(&o[0]));
+                stv_nt<4>(y + xoff + 4, *reinterpret_cast<float(*)[4]>(&o[4]));
+            } else {
+                for (int e = 0; e < cnt; ++e) y[xoff + e] = o[e];
+            }
         }
     }
 }

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats
             qmax = exp2f(bits) - 1.f;
             scale = (qmax > 0.f) ? delta / qmax : 0.f;
         } else {
-            qmax = (float)((1u << cfg.num_bits) - 1u);
+            qmax = qmax_of(cfg.num_bits);
             scale = delta / qmax;
         }
         scale = (scale < 1e-8f) ? 1e-8f : scale;  // NaN stays NaN, as torch.max does

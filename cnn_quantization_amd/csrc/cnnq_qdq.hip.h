@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_params(const float* __restrict__
     if ((threadIdx.x & 63) != 0) return;
     const float offset = positive ? 0.f : mn;
     const float delta = mx - offset;
-    const float qm = (float)((1u << num_bits) - 1u);
+    const float qm = qmax_of(num_bits);
     float sc = delta / qm;
     sc = (sc < 1e-8f) ? 1e-8f : sc;
     qp[(size_t)CNNQ_QP_SCALE * C + c] = sc;

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     __syncthreads();
 
     // ---- scale / zero point of the owned channels (iq.py:559-572)
-    const float qm = (float)((1u << num_bits) - 1u);
+    const float qm = qmax_of(num_bits);
     float p_sc = 0.f, p_zp = 0.f;
     if (tid < nch) {
         const float cmn = sh_mn[tid], cmx = sh_mx[tid];

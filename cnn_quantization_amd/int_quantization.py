@@ -2,8 +2,9 @@
 (kernels/int_quantization.cpp:10-12, built from kernels/gemmlowp.cu): same entry point, same
 seven arguments, same early return - backed by cnnq_pt_setup + cnnq_pt_qdq (HIP, gfx950).
 
-`import int_quantization` resolves to this module when `cnn_quantization_amd/dropin` is on
-sys.path."""
+`import int_quantization` resolves to this module once it is registered under that name:
+`sys.modules['int_quantization'] = cnn_quantization_amd.int_quantization` (INTEGRATION.md section 2,
+exercised by tests/test_reference_shim_cpu.py)."""
 import torch
 
 from . import ops

@@ -147,6 +147,12 @@ def _params_cfg(num_bits, positive, clip, bit_alloc, prior_is_b, target, round_m
         cfg.clip, cfg.pstd = CLIP_CODES[clip], 0.
     elif 'std' in clip:
         cfg.clip, cfg.pstd = 3, float(clip.replace('std', ''))
+    elif clip == 'mix':
+        # iq.py:310-323: picks laplace / gaus / min-max per channel from the mse_laplace / mse_gaus / mse_lowp
+        # columns of a statistics file written with collect_err=True - a diagnostic mode outside SURVEY 8(a7)
+        # that the statistics managers here do not collect
+        raise L.CnnqError("clipping 'mix' needs the mse_* error statistics (collect_err), which are out of scope: "
+                          "use 'laplace', 'gaus' or '<p>std'")
     else:
         raise L.CnnqError('unsupported clipping %r' % (clip,))
     cfg.bit_alloc = int(bool(bit_alloc))
@@ -461,6 +467,33 @@ def dequantize_u8(codes, qp):
     y = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
     N, C, HW = geometry(y)
     L.check(lib.cnnq_pc_dequantize_u8(_ptr(codes), _ptr(y), N, C, HW, _ptr(qp), _stream(y)), 'cnnq_pc_dequantize_u8')
+    return y
+
+
+def quantize_packed(x, qp, bits):
+    """x [N, C, H, W] + parameter table + per-channel bit widths (diag[DIAG_BITS] of pc_params with bit
+    allocation) -> (packed uint8 [N * bytes_per_sample], rowoff int32 [C + 1]): bits[c] bits per code, i.e.
+    sum(bits)/8 bytes per spatial position (cnnq_pc_quantize_packed).  One host read (the buffer size)."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    N, C, HW = geometry(x)
+    bits = bits.contiguous()
+    rowoff = torch.empty(C + 1, dtype=torch.int32, device=x.device)
+    L.check(lib.cnnq_pc_packed_layout(_ptr(bits), C, HW, _ptr(rowoff), _stream(x)), 'cnnq_pc_packed_layout')
+    plane = int(rowoff[C].item())
+    packed = torch.empty(max(N * plane, 4), dtype=torch.uint8, device=x.device)
+    L.check(lib.cnnq_pc_quantize_packed(_ptr(x), _ptr(packed), N, C, HW, _ptr(qp), _ptr(bits), _ptr(rowoff), _stream(x)),
+            'cnnq_pc_quantize_packed')
+    return packed[:N * plane], rowoff
+
+
+def dequantize_packed(packed, shape, qp, bits, rowoff):
+    """Inverse of quantize_packed: the dequantized fp32 tensor (bit-identical to pc_qdq's output)."""
+    lib = L.load()
+    y = torch.empty(shape, dtype=torch.float32, device=packed.device)
+    N, C, HW = geometry(y)
+    L.check(lib.cnnq_pc_dequantize_packed(_ptr(packed), _ptr(y), N, C, HW, _ptr(qp), _ptr(bits.contiguous()), _ptr(rowoff),
+                                          _stream(y)), 'cnnq_pc_dequantize_packed')
     return y
 
 

@@ -180,6 +180,18 @@ int cnnq_pc_quantize_u8(const float* x, uint8_t* codes, int64_t N, int64_t C, in
 int cnnq_pc_dequantize_u8(const uint8_t* codes, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
                           void* stream);
 
+/* Bit allocation as the STORED format (the per-channel qmax = 2**bit_alloc - 1 of iq.py:563-564,
+ * 582-584 made real): channel c stores bits[c] in 0..8 bits per code (bits = row CNNQ_DIAG_BITS of cnnq_pc_params'
+ * diag), i.e. sum(bits)/8 bytes per spatial position.  Row (n, c) = H*W codes as a little-endian bit stream,
+ * padded to 4 bytes, at byte n * rowoff[C] + rowoff[c]; cnnq_pc_packed_layout fills rowoff[C + 1] (uint32, device)
+ * from bits; the packed buffer needs N * rowoff[C] bytes.  A 0-bit channel stores nothing.  The round trip
+ * reproduces the fused Q/DQ (cnnq_pc_qdq with the same qp) bit for bit. */
+int cnnq_pc_packed_layout(const float* bits, int64_t C, int64_t HW, uint32_t* rowoff, void* stream);
+int cnnq_pc_quantize_packed(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
+                            const float* bits, const uint32_t* rowoff, void* stream);
+int cnnq_pc_dequantize_packed(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                              const float* bits, const uint32_t* rowoff, void* stream);
+
 /* Config 2 (dynamic per-channel min/max, no clipping, uniform bit width: iq.py:409-451 with
  * bit allocation off) as three launches, two of them streaming:
  *   cnnq_pc_minmax         exact per-channel {min, max} partials pmm[G][2][C] (G = cnnq_pc_groups;

@@ -1,8 +1,8 @@
 /* oracle/qdq_core.c - plain-C restatement of the two elementwise cores of the hot path.
  *
  * TEST INFRASTRUCTURE ONLY (see oracle/quant_oracle.py): used by tests/ to cross-check the
- * torch-based oracle's IEEE semantics (true division, separate roundings, rint vs roundf) and
- * by bench.py's cpu_baseline leg as the scalar 1-core port.  Never linked into the product.
+ * torch-based oracle's IEEE semantics (true division, separate roundings, rint vs roundf).
+ * (bench.py's cpu_baseline times the torch-based oracle, not this file.)  Never linked into the product.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/build_oracle.py).
  *

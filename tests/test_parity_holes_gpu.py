@@ -255,3 +255,90 @@ def test_nan_golden_case(ops, golden):
             na, nb = np.isnan(y), np.isnan(ref)
             assert np.array_equal(na, nb), (i, name)
             assert np.array_equal(y[~na].view(np.uint32), ref[~nb].view(np.uint32)), (i, name)
+
+
+# ------------------------------------------------------------------ f3: bit allocation as the stored format
+def _unpack_rows(packed, rowoff, bits, N, C, HW):
+    """CPU decode of the variable-width layout of include/cnnq_hip.h (little-endian bit stream per (n, c) row)."""
+    packed = packed.cpu().numpy()
+    rowoff = rowoff.cpu().numpy().astype(np.int64)
+    plane = int(rowoff[C])
+    codes = np.zeros((N, C, HW), dtype=np.int32)
+    for n in range(N):
+        for c in range(C):
+            b = int(bits[c])
+            if b == 0:
+                continue
+            nbytes = (HW * b + 31) // 32 * 4
+            row = packed[n * plane + rowoff[c]: n * plane + rowoff[c] + nbytes]
+            bitsarr = np.unpackbits(row, bitorder='little')[:HW * b].reshape(HW, b)
+            codes[n, c] = (bitsarr.astype(np.int32) << np.arange(b, dtype=np.int32)).sum(axis=1)
+    return codes
+
+
+def test_packed_bit_alloc_storage_golden(ops, golden):
+    """The per-channel bit widths of -baa as the STORED format: the packed bit streams decode to the reference's
+    integer codes (act_pc.npz cfg2_int4_baa*), the device round trip reproduces the reference's floats, and the
+    buffer is sum(bits)/8 bytes per position (+ row padding)."""
+    from cnn_quantization_amd import _lib as L
+    from test_oracle_golden import ACT_KW
+    g = golden('act_pc')
+    n = 0
+    for key in g.np('names'):
+        key = str(key)
+        name, si = key.rsplit('_s', 1)
+        if 'baa' not in name or not name.startswith('cfg2'):
+            continue
+        kw = ACT_KW[name]
+        x = g.t('x' + si).cuda()
+        N, C, H, W = x.shape
+        y, codes, parts = ops.act_qdq_per_channel(x, int(g.np(key + '_bits')), positive=bool(g.np(key + '_half')),
+                                                  bit_alloc=True, target=kw.get('bit_alloc_target'),
+                                                  round_mode=kw.get('bit_alloc_round', True), want_codes=True, want_parts=True)
+        bits = parts['diag'][L.DIAG_BITS]
+        assert np.array_equal(bits.cpu().numpy(), g.np(key + '_bit_alloc')), key
+        packed, rowoff = ops.quantize_packed(x, parts['qp'], bits)
+        b = bits.cpu().numpy().astype(np.int64)
+        assert packed.numel() == N * int(((H * W * b + 31) // 32 * 4).sum()), key
+        dec = _unpack_rows(packed, rowoff, b, N, C, H * W).reshape(N, C, H, W)
+        assert np.array_equal(dec, g.np(key + '_codes')), key
+        assert np.array_equal(dec, codes.cpu().numpy().astype(np.int32)), key
+        back = ops.dequantize_packed(packed, tuple(x.shape), parts['qp'], bits, rowoff)
+        assert torch.equal(back, y) and bits_equal(back.cpu(), g.np(key + '_y')), key
+        n += 1
+    assert n >= 4
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 56, 56), (5, 20, 14, 14), (3, 8, 7, 7), (2, 5, 5, 9), (4, 300, 4, 4)])
+def test_packed_round_trip_equals_fused_qdq(ops, shape):
+    """Any geometry (rows that are not a multiple of 8 elements, unaligned rows, 0-bit channels): the round trip
+    through the packed format equals the fused Q/DQ with the same parameters bit for bit."""
+    from cnn_quantization_amd import _lib as L
+    gen = torch.Generator().manual_seed(shape[1])
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=gen) * torch.exp(torch.randn(1, C, 1, 1, generator=gen) * 1.5) + 0.1).cuda()
+    y, parts = ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True, want_parts=True)
+    bits = parts['diag'][L.DIAG_BITS]
+    packed, rowoff = ops.quantize_packed(x, parts['qp'], bits)
+    back = ops.dequantize_packed(packed, shape, parts['qp'], bits, rowoff)
+    assert torch.equal(back, y)
+    bpe = packed.numel() / x.numel()
+    assert bpe <= float(bits.mean()) / 8 + 4. / (H * W) + 1e-6      # sum(bits)/8 per position + <= 4 bytes row padding
+
+
+@pytest.mark.parametrize('bits', [16, 32])
+def test_wide_per_channel_bits(ops, bits):
+    """'int16' / bare 'int' (32-bit) quantizer types with -pcq_a: qmax = 2**bits - 1 as the reference's Python float
+    (iq.py:559); every config-2 path, bit-exact against the oracle."""
+    gen = torch.Generator().manual_seed(bits)
+    for shape in ((5, 6, 14, 14), (40, 3, 56, 56), (3, 8, 7, 7), (3, 5, 5, 9)):
+        x = torch.randn(shape, generator=gen) * 3 + 0.5
+        for half in (False, True):
+            ref = O.act_per_channel_qdq(x, bits, half_range=half)
+            assert bits_equal(ops.act_qdq_per_channel(x.cuda(), bits, positive=half).cpu(), ref), (shape, half)
+            N, C = shape[:2]
+            os.environ['CNNQ_RESIDENT'] = '0'
+            try:
+                assert bits_equal(ops.act_qdq_per_channel(x.cuda(), bits, positive=half).cpu(), ref), (shape, half)
+            finally:
+                os.environ['CNNQ_RESIDENT'] = '1'
