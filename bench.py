@@ -258,6 +258,25 @@ def other_configs(ops, device, batch):
     out['config3'] = obj(elems, t, 16, 'ResNet-50 b%d, per-channel int4 + ACIQ laplace + bit allocation, dynamic statistics '
                          '(-c laplace -baa)' % batch)
     del ys
+    # the same configuration with the bit-allocated integer codes as the STORED result
+    # (sum(bits)/8 bytes per position instead of 4 B/elem of dequantized floats); the packing pass alone is timed,
+    # its parameters come from one untimed statistics + parameter run per tensor
+    from cnn_quantization_amd import _lib as Lb
+    pk = []
+    for (x, half) in layers:
+        _, parts = ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, want_parts=True)
+        pk.append((x, parts['qp'], parts['diag'][Lb.DIAG_BITS].contiguous()))
+    del _
+    stored = [ops.quantize_packed(x, qp, bits) for x, qp, bits in pk]
+    nbytes = sum(p.numel() for p, _ in stored)
+    del stored
+    torch.cuda.empty_cache()
+    t = timed_best(lambda: [ops.quantize_packed(x, qp, bits) for x, qp, bits in pk])
+    bpe = 4 + nbytes / elems
+    out['config3_packed_storage'] = obj(elems, t, bpe, 'ResNet-50 b%d, the quantize+pack pass of config 3 with the bit-allocated '
+                                        'codes as the stored format: %.3f bytes per element written (fp32 dequantized: 4), one '
+                                        'host read of the buffer size per tensor included' % (batch, nbytes / elems))
+    del pk
     t = timed_best(lambda: [ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True,
                                          need_relu=True) for x, _ in layers])
     out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics' % batch)

@@ -19,6 +19,7 @@ import pandas as pd
 import torch
 
 from .. import _lib as L
+from .. import distributed as D
 from .. import ops
 from ..utils.misc import Singleton
 
@@ -62,11 +63,18 @@ class StatisticManagerPerChannel(metaclass=Singleton):
                                 need_kurt='kurtosis' in self.stats_names,
                                 need_relu='std_pos' in self.stats_names, group=self.group)
         if self.batch_avg and not force_global_min_max:
-            # mean over the batch of the per-sample extrema (smpc.py:72,78): rows = (n, c) pairs
+            # mean over the batch of the per-sample extrema (smpc.py:72,78): rows = (n, c) pairs; with several ranks
+            # the sums and the sample counts travel, so every rank holds the mean over the GLOBAL batch
             rows, _ = ops.pc_stats(x, 1, N * C, HW, local_only=True)
             table = table.clone()
-            table[L.STAT_MAX] = rows[L.STAT_MAX].view(N, C).mean(dim=0)
-            table[L.STAT_MIN] = rows[L.STAT_MIN].view(N, C).mean(dim=0)
+            smax = rows[L.STAT_MAX].view(N, C).double().sum(dim=0)
+            smin = rows[L.STAT_MIN].view(N, C).double().sum(dim=0)
+            cnt = torch.full_like(smax, float(N))
+            if D.world_size(self.group) > 1:
+                rec = D.all_gather_records(torch.stack([smax, smin, cnt]), self.group).sum(dim=0)
+                smax, smin, cnt = rec[0], rec[1], rec[2]
+            table[L.STAT_MAX] = (smax / cnt).float()
+            table[L.STAT_MIN] = (smin / cnt).float()
         host = table.cpu().numpy()          # the only synchronisation of this call
         layer = self.stats.setdefault(id, {})
         for sn in self.stats_names:
@@ -81,6 +89,17 @@ class StatisticManagerPerChannel(metaclass=Singleton):
     def __exit__(self, *args):
         if not self.save_stats:
             return
+        if D.world_size(self.group) > 1:
+            # every rank holds the same (global) statistics: rank 0 writes, the others wait for the files
+            if D.rank(self.group) != 0:
+                torch.distributed.barrier(group=self.group)
+                return
+            self._write()
+            torch.distributed.barrier(group=self.group)
+            return
+        self._write()
+
+    def _write(self):
         if os.path.exists(self.folder):
             shutil.rmtree(self.folder)
         os.makedirs(self.folder)
