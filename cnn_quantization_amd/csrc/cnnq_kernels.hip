@@ -118,6 +118,59 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
     return launch_status();
 }
 
+// pass B straight from the UNMERGED pass-A records (each workgroup merges its own channels' records in its prologue)
+static int absdev_raw(const float* x, int64_t N, int64_t C, int64_t HW, const double* part, int want_kurt, double* part2,
+                      void* stream) {
+    Variant v;
+    Geo g;
+    const int rc = plan(N, C, HW, al16(x), /*rev=*/1, &v, &g);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ntl = N * C * HW * 4 > NT_BYTES;
+    const int G = g.S * g.nb;
+    const float* nostats = nullptr;
+#define LAUNCH_DEVR(VEC, A, J)                                                                                              \
+    do {                                                                                                                    \
+        if (want_kurt && ntl) hipLaunchKernelGGL((k_absdev<VEC, A, J, true, true, true>), grid, block, 0, st, x, g, nostats, part2, part, G);   \
+        else if (want_kurt) hipLaunchKernelGGL((k_absdev<VEC, A, J, true, false, true>), grid, block, 0, st, x, g, nostats, part2, part, G);    \
+        else if (ntl) hipLaunchKernelGGL((k_absdev<VEC, A, J, false, true, true>), grid, block, 0, st, x, g, nostats, part2, part, G);          \
+        else hipLaunchKernelGGL((k_absdev<VEC, A, J, false, false, true>), grid, block, 0, st, x, g, nostats, part2, part, G);                  \
+    } while (0)
+    CNNQ_DISPATCH(v, LAUNCH_DEVR);
+#undef LAUNCH_DEVR
+    return launch_status();
+}
+
+// All per-channel statistics of one tensor behind ONE call and one caller workspace: pass A -> (pass B with the
+// pass-A merge fused into its prologue -> one final merge of both passes) - three launches for the full set of
+// smpc.py:45-79 instead of four, two for {min, max, mean, std}.  ws: doubles part[G][NMOM][C], part2[G][NDEV][C].
+size_t cnnq_pc_stats_workspace(int64_t N, int64_t C, int64_t HW, int aligned16) {
+    const int G = cnnq_pc_groups(N, C, HW, aligned16);
+    if (G <= 0) return 0;
+    return ((size_t)G * (CNNQ_NMOM + CNNQ_NDEV)) * (size_t)C * sizeof(double);
+}
+
+int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws,
+                  double* mom, float* stats, void* stream) {
+    if (!x || !ws || !stats || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    double* part2 = part + (size_t)G * CNNQ_NMOM * C;
+    hipStream_t st = (hipStream_t)stream;
+    // rows nobody writes (KURT / STD_POS / B when not requested) must not hold NaN garbage for later readers
+    if (hipMemsetAsync(stats, 0, (size_t)CNNQ_NSTAT * C * sizeof(float), st) != hipSuccess) return launch_status();
+    int rc = cnnq_pc_moments(x, N, C, HW, need_relu, part, stream);
+    if (rc) return rc;
+    if (!(need_b || need_kurt)) return cnnq_pc_combine(part, G, C, need_relu, mom, stats, stream);
+    rc = absdev_raw(x, N, C, HW, part, need_kurt, part2, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_combine_all, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, st, part, part2, G,
+                       (int)C, need_relu, need_kurt, mom, stats);
+    return launch_status();
+}
+
 int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom, int want_kurt, double* dev_out,
                         float* stats, void* stream) {
     if (!part2 || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!dev_out && !stats) || (stats && !mom))
@@ -410,7 +463,7 @@ int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int6
 
 // The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B
 // when b is needed, merge, parameters (ACIQ clipping, bit allocation, scale / zero point), fused Q/DQ - six
-// launches, one host call, one caller workspace.  ws layout (doubles first): part[G][NMOM][C], mom[NMOM][C],
+// launches (five since round 2: the first merge runs inside pass B), one host call, one caller workspace.  ws layout (doubles first): part[G][NMOM][C], mom[NMOM][C],
 // part2[G][NDEV][C], then floats stats[NSTAT][C].
 size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16) {
     const int G = cnnq_pc_groups(N, C, HW, aligned16);
@@ -435,14 +488,17 @@ int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW,
     if (hipMemsetAsync(stats, 0, (size_t)CNNQ_NSTAT * C * sizeof(float), st) != hipSuccess) return launch_status();
     int rc = cnnq_pc_moments(x, N, C, HW, 0, part, stream);
     if (rc) return rc;
-    rc = cnnq_pc_combine(part, G, C, 0, mom, stats, stream);
-    if (rc) return rc;
     if (need_b) {
-        rc = cnnq_pc_absdev(x, N, C, HW, stats, 0, part2, stream);
+        // pass B merges the pass-A records of its own channels in its prologue; one final merge writes all rows
+        rc = absdev_raw(x, N, C, HW, part, 0, part2, stream);
         if (rc) return rc;
-        rc = cnnq_pc_combine_dev(part2, G, C, mom, 0, nullptr, stats, stream);
-        if (rc) return rc;
+        hipLaunchKernelGGL(k_combine_all, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, st, part, part2, G,
+                           (int)C, 0, 0, mom, stats);
+        rc = launch_status();
+    } else {
+        rc = cnnq_pc_combine(part, G, C, 0, mom, stats, stream);
     }
+    if (rc) return rc;
     rc = cnnq_pc_params(stats, C, cfg, qp, diag, stream);
     if (rc) return rc;
     // pass B walks the tensor descending, so the Q/DQ after it ascends; straight after pass A it descends

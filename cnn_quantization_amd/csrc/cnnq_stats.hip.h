@@ -202,55 +202,71 @@ __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, co
     }
 }
 
+// One wave64 merges the G pass-A records of channel c (lanes stride over the groups, then a shuffle tree): the
+// single definition of the merge order, shared by k_combine, k_combine_all and the prologue of k_absdev<RAW>, so
+// the mean a fused pass B subtracts is bit for bit the mean the statistics table reports.
+struct MomSum {
+    double mn, mx, s, ss, cnt, rs, rss;
+};
+__device__ __forceinline__ MomSum merge_moments(const double* __restrict__ part, int G, int C, int c, bool has_relu) {
+    const int lane = threadIdx.x & 63;
+    MomSum r{INFINITY, -INFINITY, 0., 0., 0., 0., 0.};
+    for (int gi = lane; gi < G; gi += 64) {
+        const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
+        r.mn = pmind(r.mn, p[(size_t)CNNQ_MOM_MIN * C]);
+        r.mx = pmaxd(r.mx, p[(size_t)CNNQ_MOM_MAX * C]);
+        r.s += p[(size_t)CNNQ_MOM_SUM * C];
+        r.ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
+        r.cnt += p[(size_t)CNNQ_MOM_COUNT * C];
+        if (has_relu) {
+            r.rs += p[(size_t)CNNQ_MOM_SUM_RELU * C];
+            r.rss += p[(size_t)CNNQ_MOM_SUMSQ_RELU * C];
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        r.mn = pmind(r.mn, shfl_xor_d(r.mn, m));
+        r.mx = pmaxd(r.mx, shfl_xor_d(r.mx, m));
+        r.s += shfl_xor_d(r.s, m);
+        r.ss += shfl_xor_d(r.ss, m);
+        r.cnt += shfl_xor_d(r.cnt, m);
+        r.rs += shfl_xor_d(r.rs, m);
+        r.rss += shfl_xor_d(r.rss, m);
+    }
+    return r;
+}
+__device__ __forceinline__ float mean_of(const MomSum& r) { return (float)(r.s / r.cnt); }
+__device__ __forceinline__ float std_of(const MomSum& r) {
+    const double mean = r.s / r.cnt;
+    double var = (r.ss - r.s * mean) / (r.cnt - 1.);
+    if (var < 0.) var = 0.;
+    return (float)sqrt(var);
+}
+
 // merge G records per channel; one wave64 per channel, lanes stride over the groups
 __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part, int G, int C, int has_relu,
                                                  double* __restrict__ mom, float* __restrict__ stats) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = blockIdx.x * (TPB / 64) + wv;
     if (c >= C) return;
-    double mn = INFINITY, mx = -INFINITY, s = 0., ss = 0., cnt = 0., rs = 0., rss = 0.;
-    for (int gi = lane; gi < G; gi += 64) {
-        const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
-        mn = pmind(mn, p[(size_t)CNNQ_MOM_MIN * C]);
-        mx = pmaxd(mx, p[(size_t)CNNQ_MOM_MAX * C]);
-        s += p[(size_t)CNNQ_MOM_SUM * C];
-        ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
-        cnt += p[(size_t)CNNQ_MOM_COUNT * C];
-        if (has_relu) {
-            rs += p[(size_t)CNNQ_MOM_SUM_RELU * C];
-            rss += p[(size_t)CNNQ_MOM_SUMSQ_RELU * C];
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        mn = pmind(mn, shfl_xor_d(mn, m));
-        mx = pmaxd(mx, shfl_xor_d(mx, m));
-        s += shfl_xor_d(s, m);
-        ss += shfl_xor_d(ss, m);
-        cnt += shfl_xor_d(cnt, m);
-        rs += shfl_xor_d(rs, m);
-        rss += shfl_xor_d(rss, m);
-    }
+    const MomSum r = merge_moments(part, G, C, c, has_relu != 0);
     if (lane != 0) return;
     if (mom) {
-        mom[(size_t)CNNQ_MOM_MIN * C + c] = mn;
-        mom[(size_t)CNNQ_MOM_MAX * C + c] = mx;
-        mom[(size_t)CNNQ_MOM_SUM * C + c] = s;
-        mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = ss;
-        mom[(size_t)CNNQ_MOM_COUNT * C + c] = cnt;
-        mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = rs;
-        mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = rss;
+        mom[(size_t)CNNQ_MOM_MIN * C + c] = r.mn;
+        mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
+        mom[(size_t)CNNQ_MOM_SUM * C + c] = r.s;
+        mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = r.ss;
+        mom[(size_t)CNNQ_MOM_COUNT * C + c] = r.cnt;
+        mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = r.rs;
+        mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = r.rss;
     }
     if (stats) {
-        const double mean = s / cnt;
-        double var = (ss - s * mean) / (cnt - 1.);
-        if (var < 0.) var = 0.;
-        stats[(size_t)CNNQ_STAT_MIN * C + c] = (float)mn;
-        stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)mx;
-        stats[(size_t)CNNQ_STAT_MEAN * C + c] = (float)mean;
-        stats[(size_t)CNNQ_STAT_STD * C + c] = (float)sqrt(var);
+        stats[(size_t)CNNQ_STAT_MIN * C + c] = (float)r.mn;
+        stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)r.mx;
+        stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean_of(r);
+        stats[(size_t)CNNQ_STAT_STD * C + c] = std_of(r);
         if (has_relu) {
-            double rv = (rss - rs * (rs / cnt)) / (cnt - 1.);
+            double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
             if (rv < 0.) rv = 0.;
             stats[(size_t)CNNQ_STAT_STD_POS * C + c] = (float)sqrt(rv);
         }
@@ -260,9 +276,12 @@ __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part
 // ------------------------------------------------------------------------------------------
 // Pass B: sum |x - mean| and sum ((x - mean)/std)^4 per channel
 // ------------------------------------------------------------------------------------------
-template <int VEC, int A, int J, bool KURT, bool NTL>
+// RAW: `stats` is NULL and `part` holds the G UNMERGED pass-A records: every workgroup merges the records of its own
+// channels in its prologue (one wave per channel, the k_combine arithmetic) - one launch less per tensor.
+template <int VEC, int A, int J, bool KURT, bool NTL, bool RAW = false>
 __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, const Geo g,
-                                                const float* __restrict__ stats, double* __restrict__ part2) {
+                                                const float* __restrict__ stats, double* __restrict__ part2,
+                                                const double* __restrict__ part = nullptr, int G = 0) {
     constexpr int NE = TPB * J * A;
     __shared__ double l_a[NE];
     __shared__ double l_k[KURT ? NE : 1];
@@ -270,9 +289,16 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
 
     const Blk b = blk_of<VEC>(g);
     const int tid = threadIdx.x;
-    for (int i = tid; i < b.c1 - b.c0; i += TPB) {
-        sh_mean[i] = stats[(size_t)CNNQ_STAT_MEAN * g.C + b.c0 + i];
-        sh_std[i] = stats[(size_t)CNNQ_STAT_STD * g.C + b.c0 + i];
+    if constexpr (RAW) {
+        for (int i = tid >> 6; i < b.c1 - b.c0; i += TPB / 64) {
+            const MomSum r = merge_moments(part, G, g.C, b.c0 + i, false);
+            if ((tid & 63) == 0) { sh_mean[i] = mean_of(r); sh_std[i] = std_of(r); }
+        }
+    } else {
+        for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+            sh_mean[i] = stats[(size_t)CNNQ_STAT_MEAN * g.C + b.c0 + i];
+            sh_std[i] = stats[(size_t)CNNQ_STAT_STD * g.C + b.c0 + i];
+        }
     }
     __syncthreads();
     int col[J];
@@ -371,6 +397,46 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
         for (int m = 32; m >= 1; m >>= 1) { ra += shfl_xor_d(ra, m); rk += shfl_xor_d(rk, m); }
         if (lane == 0) emit(ch, ra, rk);
     }
+}
+
+// final merge of BOTH passes (the fused form: k_moments -> k_absdev<RAW> -> this): rows MIN, MAX, MEAN, STD (STD_POS)
+// from the pass-A records, B (KURT) from the pass-B records, and the merged moment record
+__global__ void __launch_bounds__(TPB) k_combine_all(const double* __restrict__ part, const double* __restrict__ part2,
+                                                     int G, int C, int has_relu, int want_kurt, double* __restrict__ mom,
+                                                     float* __restrict__ stats) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (TPB / 64) + wv;
+    if (c >= C) return;
+    const MomSum r = merge_moments(part, G, C, c, has_relu != 0);
+    double sa = 0., sk = 0.;
+    for (int gi = lane; gi < G; gi += 64) {
+        const double* p = part2 + (size_t)gi * CNNQ_NDEV * C + c;
+        sa += p[(size_t)CNNQ_DEV_ABS * C];
+        sk += p[(size_t)CNNQ_DEV_Z4 * C];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { sa += shfl_xor_d(sa, m); sk += shfl_xor_d(sk, m); }
+    if (lane != 0) return;
+    if (mom) {
+        mom[(size_t)CNNQ_MOM_MIN * C + c] = r.mn;
+        mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
+        mom[(size_t)CNNQ_MOM_SUM * C + c] = r.s;
+        mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = r.ss;
+        mom[(size_t)CNNQ_MOM_COUNT * C + c] = r.cnt;
+        mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = r.rs;
+        mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = r.rss;
+    }
+    stats[(size_t)CNNQ_STAT_MIN * C + c] = (float)r.mn;
+    stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)r.mx;
+    stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean_of(r);
+    stats[(size_t)CNNQ_STAT_STD * C + c] = std_of(r);
+    if (has_relu) {
+        double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
+        if (rv < 0.) rv = 0.;
+        stats[(size_t)CNNQ_STAT_STD_POS * C + c] = (float)sqrt(rv);
+    }
+    stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sa / r.cnt);
+    if (want_kurt) stats[(size_t)CNNQ_STAT_KURT * C + c] = (float)(sk / r.cnt - 3.);
 }
 
 __global__ void __launch_bounds__(TPB) k_combine_dev(const double* __restrict__ part2, int G, int C,

@@ -120,8 +120,19 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
     moment records are all-gathered (<= 7*C*8 bytes per rank, latency-bound on xGMI) and merged
     in rank order on every rank, so all ranks hold the statistics of the GLOBAL batch."""
     x = _dev_f32(x, 'x')
-    part = pc_moments(x, N, C, HW, need_relu)
     world = 1 if local_only else D.world_size(group)
+    if world == 1:
+        # one C call, one cached workspace, three launches (cnnq_pc_stats)
+        lib = L.load()
+        nbytes = lib.cnnq_pc_stats_workspace(N, C, HW, int(x.data_ptr() % 16 == 0))
+        if nbytes == 0:
+            L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+        stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
+        mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
+        L.check(lib.cnnq_pc_stats(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)),
+                                  _ptr(_scratch(x, 'stats', nbytes)), _ptr(mom), _ptr(stats), _stream(x)), 'cnnq_pc_stats')
+        return stats, mom
+    part = pc_moments(x, N, C, HW, need_relu)
     if world > 1:
         mom_local, _ = pc_combine(part, need_relu)
         part = D.all_gather_records(mom_local, group)

@@ -120,6 +120,16 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
 int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom, int want_kurt,
                         double* dev_out, float* stats, void* stream);
 
+/* All per-channel statistics of one tensor behind one call and one caller workspace `ws` of
+ * cnnq_pc_stats_workspace(...) bytes (8-byte aligned): pass A -> pass B with the merge of the pass-A records fused
+ * into its prologue -> one final merge of both passes (three launches for the seven statistics of smpc.py:45-79,
+ * two when neither b nor kurtosis is wanted).  stats[CNNQ_NSTAT][C] is written completely (rows not requested are
+ * zero); mom[CNNQ_NMOM][C] (merged moment record) may be NULL.  Single process: the cross-rank exchange needs the
+ * separate calls above. */
+size_t cnnq_pc_stats_workspace(int64_t N, int64_t C, int64_t HW, int aligned16);
+int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws,
+                  double* mom, float* stats, void* stream);
+
 /* Per-channel statistics -> quantisation parameters, entirely on the device (the reference
  * takes >= 6 host round trips here: iq.py:248,285-288,355,405).  One workgroup.
  *   clip: 0 = min/max range (iq.py:409-424), 1 = ACIQ laplace (iq.py:227-253),
