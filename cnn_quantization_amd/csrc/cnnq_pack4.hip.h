@@ -174,7 +174,13 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
                 (void)qdq1(v[e], sc, zp, qm, cd);
                 if (e < cnt) w |= (unsigned long long)(unsigned)cd << (e * b);
             }
-            for (uint32_t k = 0; k < nb; ++k) rowp[boff + k] = (uint8_t)(k < 8 ? (w >> (8 * k)) : 0ull);
+            // widest naturally aligned stores (boff = gi * b): 8 / 4 / 2-byte pieces where b allows, bytes otherwise
+            if (nb == 8u && b == 8) *reinterpret_cast<unsigned long long*>(rowp + boff) = w;
+            else if (nb == 4u && b == 4) *reinterpret_cast<uint32_t*>(rowp + boff) = (uint32_t)w;
+            else if ((b & 1) == 0 && (nb & 1u) == 0u)
+                for (uint32_t k = 0; k < nb; k += 2) *reinterpret_cast<uint16_t*>(rowp + boff + k) = (uint16_t)(k < 8 ? (w >> (8 * k)) : 0ull);
+            else
+                for (uint32_t k = 0; k < nb; ++k) rowp[boff + k] = (uint8_t)(k < 8 ? (w >> (8 * k)) : 0ull);
         } else {
             unsigned long long w = 0;
             const uint32_t nr = nb < 8 ? nb : 8;

@@ -481,21 +481,37 @@ def dequantize_u8(codes, qp):
     return y
 
 
-def quantize_packed(x, qp, bits):
+def packed_capacity(shape):
+    """Worst-case bytes of the packed format for an activation of this shape (every channel at 8 bits)."""
+    N, C = shape[0], shape[1]
+    HW = 1
+    for d in shape[2:]:
+        HW *= d
+    return N * C * ((HW * 8 + 31) // 32 * 4)
+
+
+def quantize_packed(x, qp, bits, out=None):
     """x [N, C, H, W] + parameter table + per-channel bit widths (diag[DIAG_BITS] of pc_params with bit
     allocation) -> (packed uint8 [N * bytes_per_sample], rowoff int32 [C + 1]): bits[c] bits per code, i.e.
-    sum(bits)/8 bytes per spatial position (cnnq_pc_quantize_packed).  One host read (the buffer size)."""
+    sum(bits)/8 bytes per spatial position (cnnq_pc_quantize_packed).  Sizing the buffer exactly takes one host
+    read of rowoff[C]; with `out` (a uint8 buffer of at least packed_capacity(x.shape) bytes) nothing synchronises
+    and the whole buffer is returned (the used prefix is N * rowoff[C] bytes)."""
     lib = L.load()
     x = _dev_f32(x, 'x')
     N, C, HW = geometry(x)
     bits = bits.contiguous()
     rowoff = torch.empty(C + 1, dtype=torch.int32, device=x.device)
     L.check(lib.cnnq_pc_packed_layout(_ptr(bits), C, HW, _ptr(rowoff), _stream(x)), 'cnnq_pc_packed_layout')
-    plane = int(rowoff[C].item())
-    packed = torch.empty(max(N * plane, 4), dtype=torch.uint8, device=x.device)
+    if out is not None:
+        if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= packed_capacity(x.shape)):
+            raise L.CnnqError('out must be a contiguous uint8 device buffer of at least packed_capacity(x.shape) bytes')
+        packed, plane = out, None
+    else:
+        plane = int(rowoff[C].item())
+        packed = torch.empty(max(N * plane, 4), dtype=torch.uint8, device=x.device)
     L.check(lib.cnnq_pc_quantize_packed(_ptr(x), _ptr(packed), N, C, HW, _ptr(qp), _ptr(bits), _ptr(rowoff), _stream(x)),
             'cnnq_pc_quantize_packed')
-    return packed[:N * plane], rowoff
+    return (packed if plane is None else packed[:N * plane]), rowoff
 
 
 def dequantize_packed(packed, shape, qp, bits, rowoff):
