@@ -88,17 +88,18 @@ def run_step(ops, layers, group):
         ops.act_qdq_per_channel(L['x'], 4, positive=L['half'], group=group, out=L['y'])
 
 
-def time_kernel_classes(layers):
+def time_kernel_classes(layers, single_launch=True):
     """Device time per kernel class, measured live with HIP events recorded on the launch stream
     between the launches of ONE pass that issues exactly the sequence the product path issues
     (so cache state is the real one), one event per launch boundary so that each class is the
     duration of that kernel alone, as rocprofv3 --kernel-trace reports it.  Returns
-    {class: [seconds, launches, elements]}."""
+    {class: [seconds, launches, elements]}.  single_launch=False: the three-launch chain (what runs with several
+    ranks, where the cross-rank exchange sits between the statistics and the Q/DQ pass)."""
     import ctypes
     from cnn_quantization_amd import _lib, ops
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    resident_ok = os.environ.get('CNNQ_RESIDENT', '1') != '0'
+    resident_ok = single_launch and os.environ.get('CNNQ_RESIDENT', '1') != '0'
     gws = ops._group_workspace(layers[0]['x']) if resident_ok else None
     recs = []
     d = (ctypes.c_int32 * 8)()
@@ -153,9 +154,9 @@ KERNEL_BYTES = {'k_qdq': (BYTES_QDQ, 'fused per-channel Q/DQ pass, 8 algorithmic
                 'k_minmax_params': (0, 'per-channel parameter table (latency-bound, a few KB)')}
 
 
-def roofline_objects(layers, batch, world):
-    time_kernel_classes(layers)                       # warm
-    kcs = [time_kernel_classes(layers) for _ in range(3)]
+def roofline_objects(layers, batch, world, single_launch=True):
+    time_kernel_classes(layers, single_launch)        # warm
+    kcs = [time_kernel_classes(layers, single_launch) for _ in range(3)]
     objs = {}
     for name in kcs[0]:
         t = min(k[name][0] for k in kcs)
@@ -186,11 +187,12 @@ def roofline_objects(layers, batch, world):
     return dominant, objs
 
 
-def verify_outputs(ops, layers):
+def verify_outputs(ops, layers, group=None, world=1):
     """After the timed region: the buffers the timed steps wrote are checked on the largest tensor and on the
-    largest resident-kernel tensor - extrema against torch's own reductions, codes within [0, 15], y equal to
-    (code - zp) * scale bit for bit, |x - y| <= scale / 2 inside the range, and equal to a second run that also
-    returns its parameters."""
+    largest resident-kernel tensor - extrema against torch's own reductions (with several ranks: all-reduced over
+    the ranks, i.e. the extrema of the GLOBAL batch, through typed MIN / MAX all-reduces that the product path
+    never uses), codes within [0, 15], y equal to (code - zp) * scale bit for bit, |x - y| <= scale / 2 inside
+    the range, and equal to a second run that also returns its parameters.  Every rank must call it."""
     from cnn_quantization_amd import _lib as Lb
     import ctypes
     lib = Lb.load()
@@ -201,11 +203,18 @@ def verify_outputs(ops, layers):
     ok = True
     for L in picks:
         x, y, C = L['x'], L['y'], L['C']
-        y2, parts = ops.act_qdq_per_channel(x, 4, positive=L['half'], want_parts=True)
+        y2, parts = ops.act_qdq_per_channel(x, 4, positive=L['half'], want_parts=True, group=group)
         qp, st = parts['qp'], parts['stats']
         sc, zp = qp[0].view(1, C, 1, 1), qp[1].view(1, C, 1, 1)
         ok = ok and bool(torch.equal(y2, y))
-        ok = ok and bool(torch.equal(st[1], x.amax(dim=(0, 2, 3)))) and bool(torch.equal(st[0], x.amin(dim=(0, 2, 3))))
+        mx, mn = x.amax(dim=(0, 2, 3)), x.amin(dim=(0, 2, 3))
+        if world > 1:
+            on_dev = dist.get_backend(group) == 'nccl'
+            mxr, mnr = (mx, mn) if on_dev else (mx.cpu(), mn.cpu())
+            dist.all_reduce(mxr, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(mnr, op=dist.ReduceOp.MIN, group=group)
+            mx, mn = mxr.to(x.device), mnr.to(x.device)
+        ok = ok and bool(torch.equal(st[1], mx)) and bool(torch.equal(st[0], mn))
         del y2
         codes = torch.round(y / sc + zp)
         ok = ok and float(codes.min()) >= 0 and float(codes.max()) <= 15
@@ -457,8 +466,12 @@ def main():
             'RCCL' if backend == 'nccl' else backend, ' (forced on a 1-rank group)' if args.force_exchange else '')
     value = total_elems * args.steps / dt
 
-    verified = verify_outputs(ops, layers)
-    dominant, objs = roofline_objects(layers, per_rank, world)
+    verified = verify_outputs(ops, layers, group, world)
+    if world > 1:
+        v = torch.tensor([1 if verified else 0], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(int(v.item()))
+    dominant, objs = roofline_objects(layers, per_rank, world, single_launch=(world == 1 and not args.force_exchange))
     out = {
         'metric': 'activation elements/sec (and % HBM peak) for per-channel int4 Q/DQ, ResNet-50 b512',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
