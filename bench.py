@@ -109,7 +109,8 @@ def time_kernel_classes(layers, single_launch=True):
         pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
         qp = torch.empty((3, C), dtype=torch.float32, device=x.device)
         n = x.numel()
-        if resident_ok and lib.cnnq_pc_resident_describe(N, C, HW, d) == 0:
+        group_ok = resident_ok and 0 < lib.cnnq_pc_group_workspace(N, C, HW) <= ops.GROUP_WS_BYTES
+        if resident_ok and lib.cnnq_pc_resident_describe(N, C, HW, d) == 0 and not (group_ok and d[6] < 192):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             e[0].record()
             _lib.check(lib.cnnq_pc_minmax_qdq_resident(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']),
@@ -117,7 +118,7 @@ def time_kernel_classes(layers, single_launch=True):
             e[1].record()
             recs.append((n, [('k_mmq_whole', e[0], e[1])]))
             continue
-        if resident_ok and 0 < lib.cnnq_pc_group_workspace(N, C, HW) <= ops.GROUP_WS_BYTES:
+        if group_ok:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             e[0].record()
             _lib.check(lib.cnnq_pc_minmax_qdq_group(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']), gws,

@@ -451,12 +451,21 @@ int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int6
     float* mm = ws + (size_t)CNNQ_NQP * C;
     float* pmm = mm + 2 * (size_t)C;
     if (allow_single_launch) {
-        int rc = cnnq_pc_minmax_qdq_resident(x, y, N, C, HW, num_bits, positive, qp, mm, stream);
+        const size_t gneed = gws ? cnnq_pc_group_workspace(N, C, HW) : 0;
+        const bool group_ok = gneed > 0 && gneed <= gws_bytes;
+        // whole channels per workgroup needs no exchange, but with fewer channel blocks than ~3/4 of the CUs it leaves
+        // the chip idle: [64,128,28,28] = 128 workgroups takes 17.8 us, the group form (1024 tiles) 13.4
+        WPlan wp;
+        const bool whole_ok = plan_whole(N, C, HW, al16(x) && al16(y), &wp) == 0;
+        int rc = CNNQ_ENOTSUP;
+        if (whole_ok && !(group_ok && wp.wgs < RES_MIN_WGS))
+            rc = cnnq_pc_minmax_qdq_resident(x, y, N, C, HW, num_bits, positive, qp, mm, stream);
         if (rc != CNNQ_ENOTSUP) return rc;
-        if (gws && cnnq_pc_group_workspace(N, C, HW) <= gws_bytes && cnnq_pc_group_workspace(N, C, HW) > 0) {
+        if (group_ok) {
             rc = cnnq_pc_minmax_qdq_group(x, y, N, C, HW, num_bits, positive, gws, qp, mm, 0u, stream);
             if (rc != CNNQ_ENOTSUP) return rc;
         }
+        if (whole_ok) return cnnq_pc_minmax_qdq_resident(x, y, N, C, HW, num_bits, positive, qp, mm, stream);
     }
     return cnnq_pc_minmax_qdq(x, y, N, C, HW, num_bits, positive, pmm, qp, nullptr, nullptr, stream);
 }

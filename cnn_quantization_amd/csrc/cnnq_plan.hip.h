@@ -139,6 +139,8 @@ int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const f
 // ------------------------------------------------------------------------------------------
 // the register-resident single-launch form of config 2 (cnnq_resident.hip.h)
 // ------------------------------------------------------------------------------------------
+constexpr int RES_MIN_WGS = 192;   // below this many workgroups the whole-channel form leaves CUs idle: prefer the group form
+
 struct WPlan {
     int A, T, K;   // parameter sets per float4, threads per workgroup, samples (16-byte loads) per lane
     WGeo g;

@@ -66,12 +66,19 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     const int rlc = active ? rl : 0, clc = active ? cl : 0;   // idle lanes shadow lane (0, 0); results discarded
     const size_t colbase = ((size_t)c0 * g.HW / 4 + clc) * 4;
 
-    // ---- the tile: K 16-byte loads per lane, issued back to back (samples past N re-read the lane's first)
+    // ---- the tile: K 16-byte loads per lane, issued back to back; slots past the batch (N is rarely RL * K) issue no
+    //      load and shadow the lane's first sample, which is neutral for min / max
     float v[K][4];
+    ldv_nt<4>(x + (size_t)rlc * (size_t)g.P + colbase, v[0]);
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
+    for (int j = 1; j < K; ++j) {
         const int n = rlc + j * g.RL;
-        ldv_nt<4>(x + (size_t)(n < g.N ? n : rlc) * (size_t)g.P + colbase, v[j]);
+        if (n < g.N) {
+            ldv_nt<4>(x + (size_t)n * (size_t)g.P + colbase, v[j]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = v[0][e];
+        }
     }
     float mn[A], mx[A];
     bool nan = false;

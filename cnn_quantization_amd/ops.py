@@ -315,7 +315,10 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
             if nbytes == 0:
                 L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
             d = (ctypes.c_int32 * 8)()
-            wants_group = (lib.cnnq_pc_resident_describe(N, C, HW, d) != 0
+            # the group workspace is needed when there is no whole-channel kernel, or one with too few workgroups
+            # to fill the chip (RES_MIN_WGS in csrc/cnnq_plan.hip.h: the C side routes, this only decides whether
+            # to hand it the workspace)
+            wants_group = ((lib.cnnq_pc_resident_describe(N, C, HW, d) != 0 or d[6] < 192)
                            and 0 < lib.cnnq_pc_group_workspace(N, C, HW) <= GROUP_WS_BYTES)
             plan = _WS_BYTES[key] = (nbytes, wants_group)
         nbytes, wants_group = plan
