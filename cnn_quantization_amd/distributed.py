@@ -87,6 +87,7 @@ class P2PExchange:
     of `group` on one node.  `verify()` cross-checks it against the group's own all_gather and must be
     called once before use; on any failure the caller keeps RCCL."""
     SLOT_FLOATS = 32768                                 # 128 KB: fp64 moment records [7][C] up to C = 2340
+    CHECK_EVERY = 4096                                  # exchanges between two host checks of the status word
 
     def __init__(self, group=None):
         """Collective: every rank of `group` must call it.  Local failures (allocation, IPC export / import)
@@ -127,6 +128,8 @@ class P2PExchange:
             self.windows = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
+        self.calls = 0
+        self.stream = None
 
     def _all_agree(self, flag):
         """Group-wide AND of a local boolean (a collective)."""
@@ -149,9 +152,22 @@ class P2PExchange:
         if not self.fits(rec):
             raise self.L.CnnqError('P2PExchange carries device records of at most %d bytes' % (4 * self.SLOT_FLOATS))
         n = rec.numel() * rec.element_size() // 4
+        cur = torch.cuda.current_stream(rec.device)
+        # the two-parity slot reuse is only safe for exchanges that are stream-ordered on every rank, and the
+        # sequence number is a host counter (a graph replay would freeze it): one stream, never under capture
+        if torch.cuda.is_current_stream_capturing():
+            raise self.L.CnnqError('P2PExchange cannot be captured into a HIP graph (host-side sequence number)')
+        if self.stream is None:
+            self.stream = cur.cuda_stream
+        elif self.stream != cur.cuda_stream:
+            raise self.L.CnnqError('P2PExchange is bound to the stream of its first exchange; use one stream per group')
         out = torch.empty((self.world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
         self.seq += 1
-        st = ctypes.c_void_p(torch.cuda.current_stream(rec.device).cuda_stream)
+        self.calls += 1
+        if self.calls % self.CHECK_EVERY == 0 and not self.healthy():      # periodic host check (synchronises)
+            raise self.L.CnnqError('P2PExchange: a wait timed out (a peer did not post); results since the last check '
+                                   'are invalid')
+        st = ctypes.c_void_p(cur.cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         self.L.check(self.lib.cnnq_p2p_all_gather(p(rec), n, p(self.windows), self.rank, self.world, self.SLOT_FLOATS,
                                                   self.seq, p(out), p(self.status), st), 'cnnq_p2p_all_gather')
@@ -194,7 +210,8 @@ def p2p_exchange(group=None):
     import os
     if os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' or world_size(group) == 1:
         return None
-    key = id(group)
+    # keyed by the group's membership, not by id(group): a new group object may reuse a collected one's id
+    key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
     if key not in _P2P:
         ex = P2PExchange(group)                          # collective; never raises for a local failure
         good = ex.ok and ex.verify()
