@@ -390,6 +390,12 @@ def main():
                          'tensor) - measures what the collective costs on this box')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: libraries that print to fd 1 (RCCL's version banner at communicator
+    # creation, gloo's connection notes) are sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -498,7 +504,7 @@ def main():
                 out['other_configs'] = other_configs(ops, device, args.batch)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 

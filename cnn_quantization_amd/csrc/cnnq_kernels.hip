@@ -435,6 +435,26 @@ int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int
     return launch_group(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
 }
 
+// The two halves of config 2 around the cross-rank exchange, one call each: local extrema [2][C] of this rank's
+// shard (k_minmax + k_minmax_reduce), and - after the all_gather - parameters from the W gathered records plus the
+// fused Q/DQ.  pmm: workspace [G][2][C] floats; qp: workspace / output [CNNQ_NQP][C].
+int cnnq_pc_minmax_local(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, float* local, void* stream) {
+    if (!x || !pmm || !local) return CNNQ_EINVAL;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    const int rc = cnnq_pc_minmax(x, N, C, HW, pmm, stream);
+    if (rc) return rc;
+    return cnnq_pc_minmax_reduce(pmm, G, C, local, stream);
+}
+
+int cnnq_pc_gathered_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* gathered, int W,
+                         int num_bits, int positive, float* qp, void* stream) {
+    if (!x || !y || !gathered || !qp || W <= 0) return CNNQ_EINVAL;
+    const int rc = cnnq_pc_minmax_params(gathered, W, C, num_bits, positive, qp, stream);
+    if (rc) return rc;
+    return cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, /*reverse=*/1, stream);
+}
+
 // Config 2 behind ONE call: the resident single launch when the shape has one, else the group-exchange single
 // launch (needs gws), else the three-launch chain.  ws layout (floats): qp[CNNQ_NQP][C], mm[2][C], pmm[G][2][C].
 size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW) {

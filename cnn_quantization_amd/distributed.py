@@ -41,20 +41,22 @@ def shard_batch(n, rank_, world):
     return n0, n0 + base + (1 if rank_ < rem else 0)
 
 
-def all_gather_records(rec, group=None):
+def all_gather_records(rec, group=None, out=None):
     """rec [K, C] on every rank -> [W, K, C] in rank order (the G axis cnnq_pc_combine merges): the verified
-    peer-to-peer exchange when CNNQ_P2P_EXCHANGE=1, otherwise the backend's all_gather."""
+    peer-to-peer exchange when CNNQ_P2P_EXCHANGE=1, otherwise the backend's all_gather.  `out`: optional
+    preallocated [W, K, C] result (collective path only)."""
     ex = p2p_exchange(group)
     if ex is not None and ex.fits(rec):
         return ex.all_gather(rec)
-    return collective_all_gather(rec, group)
+    return collective_all_gather(rec, group, out)
 
 
-def collective_all_gather(rec, group=None):
+def collective_all_gather(rec, group=None, out=None):
     """all_gather_records through torch.distributed (RCCL / gloo)."""
     w = world_size(group)
     rec = rec.contiguous()
-    out = torch.empty((w,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+    if out is None:
+        out = torch.empty((w,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
     if w == 1 and not forced_exchange():
         out[0].copy_(rec)
         return out

@@ -329,6 +329,26 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
                                             int(resident), _stream(x)),
                 'cnnq_pc_minmax_qdq_auto')
         return y
+    if (exchanging and not (want_codes or want_entropy or want_parts)
+            and os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') != '1'):
+        # the multi-GPU hot call: local extrema (one C call) -> all_gather of [2, C] -> parameters + Q/DQ (one C
+        # call), all in cached workspaces; the collective is the only torch.distributed call
+        key = (N, C, HW)
+        plan = _WS_BYTES.get(key)
+        nbytes = plan[0] if plan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+        if nbytes == 0:
+            L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+        ws = _scratch(x, 'cfg2', nbytes)
+        base = ws.data_ptr()
+        local = ws[12 * C:20 * C].view(torch.float32).view(2, C)            # the mm[2][C] slot of the workspace
+        gathered = _scratch(x, 'gath', 8 * C * world)[:8 * C * world].view(torch.float32).view(world, 2, C)
+        y = _out_like(x, out)
+        L.check(lib.cnnq_pc_minmax_local(_ptr(x), N, C, HW, ctypes.c_void_p(base + 20 * C), ctypes.c_void_p(base + 12 * C),
+                                         _stream(x)), 'cnnq_pc_minmax_local')
+        gathered = D.all_gather_records(local, group, out=gathered)
+        L.check(lib.cnnq_pc_gathered_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(gathered), world, int(num_bits),
+                                         int(bool(positive)), ctypes.c_void_p(base), _stream(x)), 'cnnq_pc_gathered_qdq')
+        return y
     if not exchanging and resident and not want_codes and not want_entropy:
         res = minmax_qdq_resident(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
         if res is None:

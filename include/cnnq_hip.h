@@ -264,6 +264,13 @@ int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              void* ws, float* qp, float* mm, unsigned flags, void* stream);
 
+/* The two halves of config 2 around the cross-rank exchange (multi-GPU: every rank holds a batch shard), one call
+ * each: cnnq_pc_minmax_local = cnnq_pc_minmax + cnnq_pc_minmax_reduce -> local[2][C]; after the all_gather of the
+ * W ranks' records, cnnq_pc_gathered_qdq = cnnq_pc_minmax_params(gathered[W][2][C]) + cnnq_pc_qdq. */
+int cnnq_pc_minmax_local(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, float* local, void* stream);
+int cnnq_pc_gathered_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* gathered, int W,
+                         int num_bits, int positive, float* qp, void* stream);
+
 /* Config 2 behind one call.  `ws`: caller workspace of cnnq_pc_minmax_qdq_workspace(N, C, HW) bytes (4-byte aligned;
  * floats qp[CNNQ_NQP][C], mm[2][C], pmm[G][2][C]).  allow_single_launch != 0: the resident single launch when the
  * shape has one, else - when `gws` (a zeroed-once group workspace of gws_bytes >= cnnq_pc_group_workspace(...), see
