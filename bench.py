@@ -469,8 +469,12 @@ def main():
         if not D.p2p_exchange(group).healthy():
             exchange_name += ' - UNHEALTHY: a wait timed out, results of this run are invalid'
     else:
-        exchange_name = '%s all_gather of the per-channel {min, max} records, one per tensor%s' % (
-            'RCCL' if backend == 'nccl' else backend, ' (forced on a 1-rank group)' if args.force_exchange else '')
+        from cnn_quantization_amd import rccl
+        direct = backend == 'nccl' and rccl.direct_comm(group) is not None
+        exchange_name = '%s all_gather of the per-channel {min, max} records, one per tensor%s%s' % (
+            'RCCL' if backend == 'nccl' else backend,
+            ' (ncclAllGather enqueued directly on the compute stream)' if direct else ' (through torch.distributed)',
+            ' (forced on a 1-rank group)' if args.force_exchange else '')
     value = total_elems * args.steps / dt
 
     verified = verify_outputs(ops, layers, group, world)
@@ -506,6 +510,8 @@ def main():
                 out['cpu_baseline'] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1 or args.force_exchange:
+        from cnn_quantization_amd import rccl
+        rccl.close_all()
         dist.destroy_process_group()
 
 

@@ -60,6 +60,11 @@ def collective_all_gather(rec, group=None, out=None):
     if w == 1 and not forced_exchange():
         out[0].copy_(rec)
         return out
+    if rec.is_cuda:
+        from . import rccl
+        dc = rccl.direct_comm(group)                 # RCCL on the caller's stream, ~3 us of host time (rccl.py)
+        if dc is not None:
+            return dc.all_gather(rec, out)
     try:
         dist.all_gather_into_tensor(out.view(-1), rec.view(-1), group=group)   # flat: same on RCCL and gloo
     except RuntimeError:
