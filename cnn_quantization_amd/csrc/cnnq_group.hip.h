@@ -11,17 +11,23 @@
 //
 //   * partial {min, max} pairs are 8-byte agent-scope (sc1, write-through) stores, every storing wave drains its
 //     vmcnt, then ONE lane bumps the group's arrival counter.  NO release fence: buffer_wbl2 would have to write
-//     back the megabytes of y that this very kernel keeps dirtying in the XCD's L2 - with it the kernel ran 3x
+//     back the megabytes of y that this very kernel keeps dirtying in the XCD's L2 - with it the kernel ran 2-3x
 //     slower than the two-pass chain;
-//   * every group's pairs live in their own 128-byte-aligned block: a line is written only by its group and read
-//     only after that group's counter is complete.  With the pairs of neighbouring groups sharing lines, a
-//     workgroup that read its own (complete) group pulled the line into its XCD's L2 with the neighbour's slots
-//     still unwritten, and the neighbour's members on that XCD later hit that stale copy (buffer_inv sc1 drops
-//     L1, not L2) - wrong scales in groups dispatched late, found by the rotating-buffer tests;
-//   * lane 0 polls the counter (relaxed sc1 load, s_sleep back-off up to 3.4 us: hundreds of pollers on one word
-//     otherwise saturate it), one agent acquire, plain loads of the group's block;
-//   * departures are counted too and the last one to leave a counter line zeroes it: the workspace is zeroed ONCE
-//     by the caller, the launch is replayable from a HIP graph;
+//   * the workspace is fine-grained (uncached) device memory and every group's pairs live in their own
+//     128-byte-aligned block, written only by that group and read only after its counter is complete: what a
+//     member reads never depends on what an XCD's L2 (not coherent with the other XCDs') or a CU's L1 may still
+//     hold, within a launch or from the previous one - so no agent-scope acquire is needed either (buffer_inv sc1
+//     per workgroup cost 6 %; switch GRP_ACQUIRE);
+//   * every counter has a 256-byte line of its own, in a region of the workspace that no geometry ever uses for
+//     pairs (16 counters per line serialised 16 groups' traffic: 3x slower than the chain; counters at a
+//     geometry-dependent offset got overwritten by another geometry's pairs: wrong scales for groups >= 64);
+//   * a line holds three words - arrivals, departures, ready flag - and whoever performs the LAST departure zeroes
+//     it: arrivals are never confused with early leavers (timeout, test flag), every launch leaves the workspace
+//     zero under any interleaving, the caller zeroes it ONCE, the launch replays from a HIP graph.  Groups of more
+//     than GRP_SUB members arrive in sub-groups whose last arrivers meet on a top counter; the very last raises one
+//     flag per sub-group (208 members on one word cost the 112x112 layer 60 % of its time);
+//   * lane 0 polls (relaxed sc1 load, s_sleep back-off 0.2 -> 1.7 us), every member then reads the group's block with
+//     plain loads; its own departure is counted after its stores are issued;
 //   * forward progress does not depend on dispatch order: the wait is bounded twice (20 ms of the 100 MHz clock,
 //     2^20 polls); a workgroup that gives up recomputes its channels' extrema from x itself (exact, hence the
 //     same bits) and raises bit 0 of the status word.

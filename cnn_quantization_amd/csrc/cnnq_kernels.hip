@@ -396,10 +396,9 @@ size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW) {
 }
 
 // The exchange workspace lives in fine-grained (uncached) device memory: the pairs one XCD writes must be what
-// another XCD reads in the same launch AND in the next one.  In ordinary (cached) device memory a reader's L2 can
-// still hold a pair line of an EARLIER launch - the same slot, other data - when little else ran in between
-// (small tensors, found by the tests; agent-scope acquires drop L1, not L2).  These are the only entry points of
-// the path that allocate; they synchronise the device.
+// another XCD reads in the same launch AND in the next one, whatever a per-XCD L2 (not coherent with the others;
+// agent-scope acquires drop L1, not L2) may still hold of the same slots.  These are the only entry points of the
+// path that allocate; they synchronise the device.
 int cnnq_group_ws_alloc(size_t bytes, void** ws) {
     if (!ws || bytes < GRP_WS_PAIRS) return CNNQ_EINVAL;
     hipError_t e = hipExtMallocWithFlags(ws, bytes, hipDeviceMallocUncached);

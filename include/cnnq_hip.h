@@ -248,8 +248,8 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
  * their {min, max} pairs through `ws` (write-through stores, one arrival counter per channel group, a bounded wait
  * that falls back to recomputing the extrema from x - never a deadlock, never different bits).
  *   ws   from cnnq_group_ws_alloc(bytes >= cnnq_pc_group_workspace(N, C, HW)): fine-grained (uncached) device
- *        memory, zeroed once (the kernel re-arms it) - in cached device memory a reader's L2 may still hold a pair
- *        line of an earlier launch; one workspace must not be used by two launches that can run concurrently.
+ *        memory, zeroed once (the kernel re-arms it), so that what a workgroup reads never depends on the state of
+ *        a per-XCD L2; one workspace must not be used by two launches that can run concurrently.
  *        Word 0 is a status word (cnnq_group_ws_status copies it to the host, synchronising): bit 0 is set when
  *        a wait timed out (diagnostic only, results are unaffected).
  *   qp   out: qp[CNNQ_NQP][C].   mm: optional out [2][C] = the per-channel min and max.
