@@ -205,6 +205,7 @@ GROUP_WS_BYTES = 16 << 20
 
 
 _GROUP_POOL = {}
+_GROUP_KEEP = []
 GROUP_POOL_SIZE = 4
 
 
@@ -219,6 +220,12 @@ def _group_workspace(x):
     key = (dev, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _GROUP_WS.get(key)
     if ws is not None:
+        return ws
+    if os.environ.get('CNNQ_GROUP_WS_CACHED', '0') == '1':
+        # experiment switch: ordinary (L2-cached) device memory instead of the fine-grained allocation
+        t = torch.zeros(GROUP_WS_BYTES, dtype=torch.uint8, device=x.device)
+        _GROUP_KEEP.append(t)
+        ws = _GROUP_WS[key] = ctypes.c_void_p(t.data_ptr())
         return ws
     pool = _GROUP_POOL.setdefault(dev, [])
     if not pool:
