@@ -185,6 +185,78 @@ __device__ __forceinline__ void grp_leave(unsigned* ln, unsigned actors) {
     }
 }
 
+// ---- the meeting of a group's workgroups (lane 0 of each member) -------------------------------------------------
+// Counter lines (256 bytes each; words: [0] arrivals A, [1] departures D, [2] ready flag F).  Up to GRP_SUB members
+// share one line; larger groups arrive in sub-groups of GRP_SUB whose last arrivers meet on the group's top line, and
+// the very last one raises every sub-group's flag: no word ever sees more than GRP_SUB + 1 increments or GRP_SUB
+// pollers (208 members on ONE word cost the 112x112 layer 60 % of its time).  Arrivals and departures are counted
+// apart, so a workgroup that gives up waiting (or the test flag) and leaves early cannot be mistaken for an arrival;
+// whoever performs the LAST departure of a line - members and, with two levels, the flag raiser - zeroes it: every
+// launch leaves the workspace zero under any interleaving.
+// A group owns lines_per_group(Gs) consecutive lines per exchange; kernels with several exchanges per launch
+// (k_stats_group) use `nex` line sets per group, `ex` selects one.
+__device__ __forceinline__ int grp_lines_per_group(int Gs) {
+    const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    return nsub > 1 ? nsub + 1 : 1;
+}
+__device__ __forceinline__ unsigned* grp_lines(unsigned* cnt, int group, int Gs, int ex, int nex) {
+    return cnt + ((size_t)group * nex + ex) * grp_lines_per_group(Gs) * GRP_CNT_STRIDE;
+}
+
+// arrive and wait; returns 1 when the wait was given up (timeout, or flags & 1).  `on_sub_last()` runs in the LAST
+// arriver of a sub-group, before it reports to the top line (two-level groups only): the place to fold the
+// sub-group's records.  wait = false: arrive (and do a last arriver's duties) without waiting for the others.
+template <typename F>
+__device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsigned flags, F on_sub_last,
+                                        bool wait = true) {
+    const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    const int si = member / GRP_SUB;
+    const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
+    unsigned* line = (nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top;
+    const unsigned seen = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    bool ready = (nsub == 1) && seen >= m_i;
+    if (nsub > 1 && seen == m_i) {
+        on_sub_last();
+        // last arrival of this sub-group -> the group's top counter (exactly nsub arrivals per launch)
+        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsub - 1u) {
+            __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < nsub; ++j)
+                __hip_atomic_store(top + (size_t)(1 + j) * GRP_CNT_STRIDE + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flags are out before this actor departs
+            for (int j = 0; j < nsub; ++j)
+                grp_leave(top + (size_t)(1 + j) * GRP_CNT_STRIDE, (unsigned)min(GRP_SUB, Gs - j * GRP_SUB) + 1u);
+            ready = true;
+        }
+    }
+    if (!wait) return 0;   // arrival only: this member does not need the group's result
+    int timed_out = (flags & 1u) ? 1 : 0;
+    if (!timed_out && !ready) {
+        const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals
+        const unsigned want = (nsub > 1) ? 1u : m_i;
+        const long long t0 = wall_clock64();
+        for (int spins = 0;; ++spins) {
+            // back-off in units of 64 clocks (swept 4/8/16 ... 32/64/127: +-1.5 %, the schedule hardly matters)
+            if (spins < 2) __builtin_amdgcn_s_sleep(8);
+            else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(64);
+            if (__hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            if (wall_clock64() - t0 > GRP_TIMEOUT_TICKS || spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
+        }
+    }
+#if GRP_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    return timed_out;
+}
+
+// leave the group (the last departure of a counter line re-arms it for the next launch)
+__device__ __forceinline__ void grp_depart(unsigned* top, int member, int Gs) {
+    const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    const int si = member / GRP_SUB;
+    const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
+    grp_leave((nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top, (nsub > 1) ? m_i + 1u : m_i);
+}
+
 // ws: [0] status word, [256 ..) 16384 arrival/departure counters, one per group and per 256-byte line (a fixed
 // region, so that no geometry's pairs ever land on another geometry's counters), then one 128-byte-aligned block of 8-byte
 // {min, max} pairs per group: [member] (mode 1) or [member][k] (mode 2)
@@ -237,50 +309,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
     __syncthreads();
     if (tid == 0) {
-        // Counter lines (256 bytes each; words: [0] arrivals A, [1] departures D, [2] ready flag F).  Up to GRP_SUB
-        // members share one line; larger groups arrive in sub-groups of GRP_SUB whose last arrivers meet on the
-        // group's top line, and the very last one raises every sub-group's flag: no word ever sees more than
-        // GRP_SUB + 1 increments or GRP_SUB pollers (208 members on ONE word cost the 112x112 layer 60 % of its
-        // time).  Arrivals and departures are counted apart, so a workgroup that gives up waiting (or the test
-        // flag) and leaves early cannot be mistaken for an arrival; whoever performs the LAST departure of a line
-        // - members and, with two levels, the flag raiser - zeroes it: every launch leaves the workspace zero
-        // under any interleaving.
-        const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
-        const int si = rb.member / GRP_SUB;
-        const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
-        unsigned* top = ws.cnt + (size_t)rb.group * (nsub > 1 ? nsub + 1 : 1) * GRP_CNT_STRIDE;
-        unsigned* line = (nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top;
-        const unsigned seen = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        bool ready = (nsub == 1) && seen >= m_i;
-        if (nsub > 1 && seen == m_i) {
-            // last arrival of this sub-group -> the group's top counter (exactly nsub arrivals per launch)
-            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsub - 1u) {
-                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int j = 0; j < nsub; ++j)
-                    __hip_atomic_store(top + (size_t)(1 + j) * GRP_CNT_STRIDE + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flags are out before this actor departs
-                for (int j = 0; j < nsub; ++j)
-                    grp_leave(top + (size_t)(1 + j) * GRP_CNT_STRIDE, (unsigned)min(GRP_SUB, Gs - j * GRP_SUB) + 1u);
-                ready = true;
-            }
-        }
-        int timed_out = (flags & 1u) ? 1 : 0;
-        if (!timed_out && !ready) {
-            const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals
-            const unsigned want = (nsub > 1) ? 1u : m_i;
-            const long long t0 = wall_clock64();
-            for (int spins = 0;; ++spins) {
-                // back-off in units of 64 clocks (swept 4/8/16 ... 32/64/127: +-1.5 %, the schedule hardly matters)
-                if (spins < 2) __builtin_amdgcn_s_sleep(8);
-                else if (spins < 6) __builtin_amdgcn_s_sleep(32);
-                else __builtin_amdgcn_s_sleep(64);
-                if (__hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-                if (wall_clock64() - t0 > GRP_TIMEOUT_TICKS || spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
-            }
-        }
-#if GRP_ACQUIRE
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+        const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {});
         if (timed_out) atomicOr(ws.status, 1u);
         sh_timed_out = timed_out;
     }
@@ -358,13 +387,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     }
     // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
     //      counter line re-arms it for the next launch
-    if (tid == 0) {
-        const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
-        const int si = rb.member / GRP_SUB;
-        const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
-        unsigned* top = ws.cnt + (size_t)rb.group * (nsub > 1 ? nsub + 1 : 1) * GRP_CNT_STRIDE;
-        grp_leave((nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top, (nsub > 1) ? m_i + 1u : m_i);
-    }
+    if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
 }
 
 }  // namespace

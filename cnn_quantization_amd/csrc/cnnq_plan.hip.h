@@ -300,4 +300,47 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// the single-read statistics kernel (cnnq_stats_group.hip.h): the tiling of plan_group, two exchanges per launch
+// ------------------------------------------------------------------------------------------
+struct SGPlan {
+    GPlan gp;
+    int slots;        // records per group block: Gs * kk member records + nsub sub-group records
+    size_t ws_bytes;
+};
+
+int plan_stats_group(int64_t N, int64_t C, int64_t HW, bool aligned16, SGPlan* p) {
+    const int rc = plan_group(N, C, HW, aligned16, &p->gp);
+    if (rc) return rc;
+    const GPlan& gp = p->gp;
+    if (gp.v.A != 1) return CNNQ_ENOTSUP;   // rows of whole float4s only (HW % 4 == 0)
+    const int64_t nsub = (gp.Gs + GRP_SUB - 1) / GRP_SUB;
+    if ((int64_t)gp.ngroups * 2 * (nsub > 1 ? nsub + 1 : 1) > GRP_MAX_LINES) return CNNQ_ENOTSUP;
+    p->slots = gp.Gs * ((gp.g.mode == 1) ? 1 : gp.g.k) + (int)nsub;
+    p->ws_bytes = GRP_WS_PAIRS + (size_t)gp.ngroups * p->slots * (SG_REC + SG_DEV) * sizeof(double);
+    return 0;
+}
+
+int launch_stats_group(const float* x, const SGPlan& p, int need_dev, int need_kurt, int need_relu, void* ws, double* mom,
+                       float* stats, unsigned flags, hipStream_t st) {
+    SGWs w;
+    w.status = reinterpret_cast<unsigned*>(ws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
+    w.rec_a = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.rec_b = w.rec_a + (size_t)p.gp.ngroups * p.slots * SG_REC;
+    w.slots = p.slots;
+    const Geo& g = p.gp.g;
+    const dim3 grid((unsigned)((int64_t)g.S * g.ncb)), block(TPB);
+#define LAUNCH_SG(K)                                                                                                      \
+    do {                                                                                                                  \
+        if (need_relu && need_kurt) hipLaunchKernelGGL((k_stats_group<K, true, true>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);   \
+        else if (need_relu) hipLaunchKernelGGL((k_stats_group<K, true, false>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);          \
+        else if (need_kurt) hipLaunchKernelGGL((k_stats_group<K, false, true>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);          \
+        else hipLaunchKernelGGL((k_stats_group<K, false, false>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);                        \
+    } while (0)
+    if (p.gp.K == 32) LAUNCH_SG(32); else if (p.gp.K == 16) LAUNCH_SG(16); else if (p.gp.K == 8) LAUNCH_SG(8); else LAUNCH_SG(4);
+#undef LAUNCH_SG
+    return launch_status();
+}
+
 }  // namespace
