@@ -38,9 +38,6 @@ SIGNATURES = {
     'cnnq_pc_combine_dev': (_I, [_P, _I, _L, _P, _I, _P, _P, _P]),
     'cnnq_pc_stats_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_stats': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
-    'cnnq_pc_stats_group_workspace': (ctypes.c_size_t, [_L, _L, _L]),
-    'cnnq_pc_stats_group': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _P, ctypes.c_uint, _P]),
-    'cnnq_pc_stats_auto': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, ctypes.c_size_t, _P, _P, _P]),
     'cnnq_pc_params': (_I, [_P, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P]),
     'cnnq_pc_qdq': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _P]),
     'cnnq_pc_quantize_pack4': (_I, [_P, _P, _L, _L, _L, _P, _P]),
@@ -70,7 +67,6 @@ SIGNATURES = {
     'cnnq_pc_minmax_qdq_auto': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, ctypes.c_size_t, _I, _P]),
     'cnnq_pc_aciq_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_aciq_qdq': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P]),
-    'cnnq_pc_aciq_qdq_auto': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),
     'cnnq_pc_bcorr_sums': (_I, [_P, _P, _L, _L, _L, _I, _P, _P]),
     'cnnq_pc_qdq_bcorr_sums': (_I, [_P, _L, _L, _L, _P, _I, _P, _P]),

@@ -193,8 +193,8 @@ __device__ __forceinline__ void grp_leave(unsigned* ln, unsigned actors) {
 // apart, so a workgroup that gives up waiting (or the test flag) and leaves early cannot be mistaken for an arrival;
 // whoever performs the LAST departure of a line - members and, with two levels, the flag raiser - zeroes it: every
 // launch leaves the workspace zero under any interleaving.
-// A group owns lines_per_group(Gs) consecutive lines per exchange; kernels with several exchanges per launch
-// (k_stats_group) use `nex` line sets per group, `ex` selects one.
+// A group owns lines_per_group(Gs) consecutive lines per exchange (`nex` line sets per group for a kernel with
+// several exchanges per launch, `ex` selects one).
 __device__ __forceinline__ int grp_lines_per_group(int Gs) {
     const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
     return nsub > 1 ? nsub + 1 : 1;
@@ -205,10 +205,9 @@ __device__ __forceinline__ unsigned* grp_lines(unsigned* cnt, int group, int Gs,
 
 // arrive and wait; returns 1 when the wait was given up (timeout, or flags & 1).  `on_sub_last()` runs in the LAST
 // arriver of a sub-group, before it reports to the top line (two-level groups only): the place to fold the
-// sub-group's records.  wait = false: arrive (and do a last arriver's duties) without waiting for the others.
+// sub-group's records.
 template <typename F>
-__device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsigned flags, F on_sub_last,
-                                        bool wait = true) {
+__device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsigned flags, F on_sub_last) {
     const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
     const int si = member / GRP_SUB;
     const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
@@ -228,7 +227,6 @@ __device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsig
             ready = true;
         }
     }
-    if (!wait) return 0;   // arrival only: this member does not need the group's result
     int timed_out = (flags & 1u) ? 1 : 0;
     if (!timed_out && !ready) {
         const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals

@@ -41,7 +41,6 @@
 #include "cnnq_pertensor.hip.h"
 #include "cnnq_resident.hip.h"
 #include "cnnq_group.hip.h"
-#include "cnnq_stats_group.hip.h"
 #include "cnnq_plan.hip.h"
 #include "cnnq_kld.hip.h"
 #include "cnnq_p2p.hip.h"
@@ -92,7 +91,7 @@ int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_r
 
 int cnnq_pc_combine(const double* part, int G, int64_t C, int has_relu, double* mom, float* stats, void* stream) {
     if (!part || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!mom && !stats)) return CNNQ_EINVAL;
-    const dim3 grid((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), block(TPB);
+    const dim3 grid((unsigned)((C + merge_cpw(G, (int)C) - 1) / merge_cpw(G, (int)C))), block(TPB);
     hipLaunchKernelGGL(k_combine, grid, block, 0, (hipStream_t)stream, part, G, (int)C, has_relu, mom, stats);
     return launch_status();
 }
@@ -160,55 +159,22 @@ int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, 
     double* part = reinterpret_cast<double*>(ws);
     double* part2 = part + (size_t)G * CNNQ_NMOM * C;
     hipStream_t st = (hipStream_t)stream;
-    // rows nobody writes (KURT / STD_POS / B when not requested) must not hold NaN garbage for later readers
-    if (hipMemsetAsync(stats, 0, (size_t)CNNQ_NSTAT * C * sizeof(float), st) != hipSuccess) return launch_status();
+    // the merge kernels write every row of the table (zero where nothing was requested): no memset
     int rc = cnnq_pc_moments(x, N, C, HW, need_relu, part, stream);
     if (rc) return rc;
     if (!(need_b || need_kurt)) return cnnq_pc_combine(part, G, C, need_relu, mom, stats, stream);
     rc = absdev_raw(x, N, C, HW, part, need_kurt, part2, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_combine_all, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, st, part, part2, G,
+    hipLaunchKernelGGL(k_combine_all, dim3((unsigned)((C + merge_cpw(G, (int)C) - 1) / merge_cpw(G, (int)C))), dim3(TPB), 0, st, part, part2, G,
                        (int)C, need_relu, need_kurt, mom, stats);
     return launch_status();
-}
-
-// The same table from ONE launch and ONE read of x (cnnq_stats_group.hip.h) for rows of whole float4s whose tiling
-// has a group plan; gws = a workspace from cnnq_group_ws_alloc of at least cnnq_pc_stats_group_workspace bytes.
-size_t cnnq_pc_stats_group_workspace(int64_t N, int64_t C, int64_t HW) {
-    SGPlan p;
-    return plan_stats_group(N, C, HW, true, &p) ? 0 : p.ws_bytes;
-}
-
-int cnnq_pc_stats_group(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu,
-                        void* gws, double* mom, float* stats, unsigned flags, void* stream) {
-    if (!x || !gws || !stats || ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
-    SGPlan p;
-    const int rc = plan_stats_group(N, C, HW, al16(x), &p);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, (size_t)CNNQ_NSTAT * C * sizeof(float), st) != hipSuccess) return launch_status();
-    return launch_stats_group(x, p, (need_b || need_kurt) ? 1 : 0, need_kurt ? 1 : 0, need_relu ? 1 : 0, gws, mom, stats,
-                              flags, st);
-}
-
-// one launch when the shape has a group plan and the caller brought a large enough exchange workspace, else the chain
-int cnnq_pc_stats_auto(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu,
-                       void* ws, void* gws, size_t gws_bytes, double* mom, float* stats, void* stream) {
-    if (gws) {
-        const size_t need = cnnq_pc_stats_group_workspace(N, C, HW);
-        if (need > 0 && need <= gws_bytes) {
-            const int rc = cnnq_pc_stats_group(x, N, C, HW, need_b, need_kurt, need_relu, gws, mom, stats, 0u, stream);
-            if (rc != CNNQ_ENOTSUP) return rc;
-        }
-    }
-    return cnnq_pc_stats(x, N, C, HW, need_b, need_kurt, need_relu, ws, mom, stats, stream);
 }
 
 int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom, int want_kurt, double* dev_out,
                         float* stats, void* stream) {
     if (!part2 || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!dev_out && !stats) || (stats && !mom))
         return CNNQ_EINVAL;
-    const dim3 grid((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), block(TPB);
+    const dim3 grid((unsigned)((C + merge_cpw(G, (int)C) - 1) / merge_cpw(G, (int)C))), block(TPB);
     hipLaunchKernelGGL(k_combine_dev, grid, block, 0, (hipStream_t)stream, part2, G, (int)C, mom, want_kurt, dev_out,
                        stats);
     return launch_status();
@@ -533,8 +499,8 @@ size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16) {
            (size_t)CNNQ_NSTAT * (size_t)C * sizeof(float);
 }
 
-int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
-                          void* gws, size_t gws_bytes, float* qp, float* diag, void* stream) {
+int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                     float* qp, float* diag, void* stream) {
     if (!x || !y || !cfg || !ws || !qp || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
@@ -545,28 +511,14 @@ int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_
     const bool use_ba = cfg->bit_alloc && cfg->num_bits <= 4;
     const bool need_b = cfg->clip == 1 || (use_ba && cfg->prior_is_b);
     hipStream_t st = (hipStream_t)stream;
-    if (gws) {
-        // statistics in one launch and one read of x (12 instead of 16 bytes per element for the pipeline)
-        const size_t need = cnnq_pc_stats_group_workspace(N, C, HW);
-        if (need > 0 && need <= gws_bytes) {
-            int rc = cnnq_pc_stats_group(x, N, C, HW, need_b ? 1 : 0, 0, 0, gws, mom, stats, 0u, stream);
-            if (rc == 0) {
-                rc = cnnq_pc_params(stats, C, cfg, qp, diag, stream);
-                if (rc) return rc;
-                return cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, /*reverse=*/1, stream);
-            }
-            if (rc != CNNQ_ENOTSUP) return rc;
-        }
-    }
-    // rows nobody writes (KURT, STD_POS; B without pass B) must not hold NaN garbage for the parameter kernel
-    if (hipMemsetAsync(stats, 0, (size_t)CNNQ_NSTAT * C * sizeof(float), st) != hipSuccess) return launch_status();
+    // the merge kernels write every row of the table (zero for KURT, STD_POS; B without pass B)
     int rc = cnnq_pc_moments(x, N, C, HW, 0, part, stream);
     if (rc) return rc;
     if (need_b) {
         // pass B merges the pass-A records of its own channels in its prologue; one final merge writes all rows
         rc = absdev_raw(x, N, C, HW, part, 0, part2, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_combine_all, dim3((unsigned)((C + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, st, part, part2, G,
+        hipLaunchKernelGGL(k_combine_all, dim3((unsigned)((C + merge_cpw(G, (int)C) - 1) / merge_cpw(G, (int)C))), dim3(TPB), 0, st, part, part2, G,
                            (int)C, 0, 0, mom, stats);
         rc = launch_status();
     } else {
@@ -577,11 +529,6 @@ int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_
     if (rc) return rc;
     // pass B walks the tensor descending, so the Q/DQ after it ascends; straight after pass A it descends
     return cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, /*reverse=*/need_b ? 0 : 1, stream);
-}
-
-int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
-                     float* qp, float* diag, void* stream) {
-    return cnnq_pc_aciq_qdq_auto(x, y, N, C, HW, cfg, ws, nullptr, 0, qp, diag, stream);
 }
 
 int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_w, const float* stats_q, int vcorr,

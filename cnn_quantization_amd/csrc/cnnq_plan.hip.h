@@ -12,6 +12,12 @@ namespace {
 // ------------------------------------------------------------------------------------------
 int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
+// development knobs (kernel sweeps) come from the environment
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
 constexpr int MAXG = 64;   // upper bound on batch splits S (partial groups per channel = S * nb)
 
 // Load shape for a tensor.  For the aligned float4 shape the loads per lane per sample (J) adapt
@@ -27,7 +33,8 @@ int choose_variant(int64_t N, int64_t C, int64_t HW, bool aligned16, Variant* v)
             for (J = 4; J > 1; J >>= 1) {
                 const int64_t cap = TPB * J;
                 const int64_t ncb = (cpc > cap) ? C * ((cpc + cap - 1) / cap) : (C + cap / cpc - 1) / (cap / cpc);
-                if (ncb * smax >= 2048) break;
+                static const int64_t minwgs = env_int("CNNQ_PLAN_MINWGS", 2048);   // development knob
+                if (ncb * smax >= minwgs) break;
             }
         }
         *v = {4, 1, J};
@@ -80,8 +87,11 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, i
             g->ncb = (int)((Cn + g->k - 1) / g->k);
         }
     }
-    // enough workgroups to fill 256 CUs (x 6-8 resident each) a few times over
-    const int64_t target = 4096;
+    // enough workgroups to fill 256 CUs (x 6-8 resident each) a few times over; half as many when a workgroup owns
+    // many channels (small H*W): every workgroup reduces and writes one partial record per channel, and pass B reads
+    // them all back (measured on the 14x14 / 7x7 layers of ResNet-50 b512: 4-12 % per layer)
+    static const int64_t forced = env_int("CNNQ_PLAN_WGS", 0);   // development knob
+    const int64_t target = forced ? forced : (g->mode == 2 && g->k >= 8) ? 2048 : 4096;
     int64_t S = (target + g->ncb - 1) / g->ncb;
     if (S > N) S = N;
     if (max_groups > 0 && S > max_groups) S = max_groups;
@@ -146,12 +156,6 @@ struct WPlan {
     WGeo g;
     int wgs;       // workgroups = ceil(C / k)
 };
-
-// development knob (kernel sweeps): CNNQ_RES_T forces the workgroup size
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
 
 // A channel block (k channels, a multiple of the m channels that share float4s) of the WHOLE batch must fit
 // RL x K samples of T / CL row lanes.  Smallest workgroup first; CNNQ_ENOTSUP when nothing fits.
@@ -297,49 +301,6 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         if (p.K == 32) LAUNCH_G(1, 32); else if (p.K == 16) LAUNCH_G(1, 16); else if (p.K == 8) LAUNCH_G(1, 8); else LAUNCH_G(1, 4);
     }
 #undef LAUNCH_G
-    return launch_status();
-}
-
-// ------------------------------------------------------------------------------------------
-// the single-read statistics kernel (cnnq_stats_group.hip.h): the tiling of plan_group, two exchanges per launch
-// ------------------------------------------------------------------------------------------
-struct SGPlan {
-    GPlan gp;
-    int slots;        // records per group block: Gs * kk member records + nsub sub-group records
-    size_t ws_bytes;
-};
-
-int plan_stats_group(int64_t N, int64_t C, int64_t HW, bool aligned16, SGPlan* p) {
-    const int rc = plan_group(N, C, HW, aligned16, &p->gp);
-    if (rc) return rc;
-    const GPlan& gp = p->gp;
-    if (gp.v.A != 1) return CNNQ_ENOTSUP;   // rows of whole float4s only (HW % 4 == 0)
-    const int64_t nsub = (gp.Gs + GRP_SUB - 1) / GRP_SUB;
-    if ((int64_t)gp.ngroups * 2 * (nsub > 1 ? nsub + 1 : 1) > GRP_MAX_LINES) return CNNQ_ENOTSUP;
-    p->slots = gp.Gs * ((gp.g.mode == 1) ? 1 : gp.g.k) + (int)nsub;
-    p->ws_bytes = GRP_WS_PAIRS + (size_t)gp.ngroups * p->slots * (SG_REC + SG_DEV) * sizeof(double);
-    return 0;
-}
-
-int launch_stats_group(const float* x, const SGPlan& p, int need_dev, int need_kurt, int need_relu, void* ws, double* mom,
-                       float* stats, unsigned flags, hipStream_t st) {
-    SGWs w;
-    w.status = reinterpret_cast<unsigned*>(ws);
-    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
-    w.rec_a = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
-    w.rec_b = w.rec_a + (size_t)p.gp.ngroups * p.slots * SG_REC;
-    w.slots = p.slots;
-    const Geo& g = p.gp.g;
-    const dim3 grid((unsigned)((int64_t)g.S * g.ncb)), block(TPB);
-#define LAUNCH_SG(K)                                                                                                      \
-    do {                                                                                                                  \
-        if (need_relu && need_kurt) hipLaunchKernelGGL((k_stats_group<K, true, true>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);   \
-        else if (need_relu) hipLaunchKernelGGL((k_stats_group<K, true, false>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);          \
-        else if (need_kurt) hipLaunchKernelGGL((k_stats_group<K, false, true>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);          \
-        else hipLaunchKernelGGL((k_stats_group<K, false, false>), grid, block, 0, st, x, g, p.gp.Gs, w, need_dev, mom, stats, flags);                        \
-    } while (0)
-    if (p.gp.K == 32) LAUNCH_SG(32); else if (p.gp.K == 16) LAUNCH_SG(16); else if (p.gp.K == 8) LAUNCH_SG(8); else LAUNCH_SG(4);
-#undef LAUNCH_SG
     return launch_status();
 }
 

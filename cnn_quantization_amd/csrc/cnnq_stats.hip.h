@@ -5,6 +5,30 @@
 
 namespace {
 
+// Segmented reductions of the epilogues and merges: SEG lanes per channel (a power of two, SEG | 64) fold their
+// share of the channel's entries serially (lane j: entries j, j + SEG, ...) and finish with a log2(SEG)-step xor
+// tree.  A full wave per channel (SEG = 64) costs 6 x 7 double shuffles per channel whatever the entry count: with
+// 20 channels of 49 entries per workgroup (14x14 and 7x7 rows) that tree was a third of the pass (measured: the
+// 1024x14x14 layer 0.200 -> 0.155 ms without it); SEG = 8 folds 8 channels per wave in one 3-step tree.
+// The segment width is a function of the entry count alone, so every kernel merging the same records agrees on
+// the order of the additions.
+__host__ __device__ constexpr int seg_of(int entries) { return entries <= 16 ? 1 : entries < 128 ? 8 : 64; }
+// Lanes per channel when the G partial records of C channels are merged.  Narrow segments pay when a workgroup of
+// pass B owns many channels (small H*W - those layers have C >= 512); with one or two channels per workgroup a full
+// wave per channel loads the records in parallel and starts streaming sooner (measured: 8 lanes per channel on
+// the 64..256-channel layers cost them 2-10 %).  A function of (G, C) alone, so that every kernel merging the same
+// records - k_combine, k_combine_all, the prologue of k_absdev<RAW> - adds them in the same order.
+__host__ __device__ constexpr int mseg_of(int G, int C) { return (G <= 64 && C >= 512) ? (G <= 16 ? 1 : 8) : 64; }
+template <int V>
+struct IntC { static constexpr int value = V; };
+#define CNNQ_SEG_DISPATCH(seg, f)              \
+    do {                                       \
+        const int seg_ = (seg);                \
+        if (seg_ == 64) f(IntC<64>{});         \
+        else if (seg_ == 8) f(IntC<8>{});      \
+        else f(IntC<1>{});                     \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------
 // Pass A: per-channel min / max / sum / sumsq / count (+ relu sums)
 // ------------------------------------------------------------------------------------------
@@ -52,6 +76,19 @@ struct Mom {
         s += o.s;
         ss += o.ss;
         if constexpr (RELU) { rs += o.rs; rss += o.rss; }
+    }
+    template <bool RELU, int SEG>
+    __device__ __forceinline__ void seg_reduce() {
+#pragma unroll
+        for (int m = SEG >> 1; m >= 1; m >>= 1) {   // constant masks: the compiler may use DPP instead of ds_bpermute
+            Mom o;
+            o.mn = shfl_xor_f(mn, m);
+            o.mx = shfl_xor_f(mx, m);
+            o.s = shfl_xor_d(s, m);
+            o.ss = shfl_xor_d(ss, m);
+            if constexpr (RELU) { o.rs = shfl_xor_d(rs, m); o.rss = shfl_xor_d(rss, m); }
+            merge<RELU>(o);
+        }
     }
     template <bool RELU>
     __device__ __forceinline__ void wave_reduce() {
@@ -106,7 +143,8 @@ __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, co
         for (int a = 0; a < A; ++a) acc[j][a].init();
 
     const float* row = x + (size_t)b.n0 * (size_t)g.P;
-#pragma unroll 2
+    constexpr int NU = (8 / J) < 2 ? 2 : 8 / J;   // 8 16-byte loads in flight per lane
+#pragma unroll NU
     for (int n = b.n0; n < b.n1; ++n, row += g.P) {
         float v[J][VEC];
 #pragma unroll
@@ -169,62 +207,55 @@ __global__ void __launch_bounds__(TPB) k_moments(const float* __restrict__ x, co
     }
     __syncthreads();
     const int epc = g.HW * A / VEC;  // LDS entries per channel
-    const int wv = tid >> 6, lane = tid & 63;
     const double count = (double)g.HW * rows;
-    if (epc <= 16) {
-        // tiny rows: one lane per channel, serial over its few entries
-        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
-            const int lo = (ch - b.c0) * epc;
+    const int nch = b.c1 - b.c0;
+    auto fold = [&](auto SEGC) {
+        constexpr int SEG = decltype(SEGC)::value;
+        for (int base = 0; base < nch; base += TPB / SEG) {   // uniform: whole waves take part in the shuffles
+            const int i = base + tid / SEG, j = tid & (SEG - 1);
             Mom r;
             r.init();
-            for (int e = lo; e < lo + epc; ++e) {
-                Mom o;
-                o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
-                if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
-                r.template merge<RELU>(o);
-            }
-            write_mom<RELU>(part, b.grp, g.C, ch, r, count);
+            if (i < nch)
+                for (int e = i * epc + j; e < (i + 1) * epc; e += SEG) {
+                    Mom o;
+                    o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
+                    if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
+                    r.template merge<RELU>(o);
+                }
+            r.template seg_reduce<RELU, SEG>();
+            if (i < nch && j == 0) write_mom<RELU>(part, b.grp, g.C, b.c0 + i, r, count);
         }
-        return;
-    }
-    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
-        const int lo = (ch - b.c0) * epc;
-        Mom r;
-        r.init();
-        for (int e = lo + lane; e < lo + epc; e += 64) {
-            Mom o;
-            o.mn = l_mn[e]; o.mx = l_mx[e]; o.s = l_s[e]; o.ss = l_ss[e];
-            if constexpr (RELU) { o.rs = l_rs[e]; o.rss = l_rss[e]; }
-            r.template merge<RELU>(o);
-        }
-        r.template wave_reduce<RELU>();
-        if (lane == 0) write_mom<RELU>(part, b.grp, g.C, ch, r, count);
-    }
+    };
+    CNNQ_SEG_DISPATCH(seg_of(epc), fold);
 }
 
-// One wave64 merges the G pass-A records of channel c (lanes stride over the groups, then a shuffle tree): the
-// single definition of the merge order, shared by k_combine, k_combine_all and the prologue of k_absdev<RAW>, so
-// the mean a fused pass B subtracts is bit for bit the mean the statistics table reports.
+// SEG = mseg_of(G, C) lanes merge the G pass-A records of channel c (lane j: records j, j + SEG, ..., then the xor tree;
+// inactive lanes only take part in the shuffles): the single definition of the merge order, shared by k_combine,
+// k_combine_all and the prologue of k_absdev<RAW>, so the mean a fused pass B subtracts is bit for bit the mean the
+// statistics table reports.
 struct MomSum {
     double mn, mx, s, ss, cnt, rs, rss;
 };
-__device__ __forceinline__ MomSum merge_moments(const double* __restrict__ part, int G, int C, int c, bool has_relu) {
-    const int lane = threadIdx.x & 63;
+template <int SEG>
+__device__ __forceinline__ MomSum merge_moments_seg(const double* __restrict__ part, int G, int C, int c, bool has_relu,
+                                                    bool active) {
+    const int j = threadIdx.x & (SEG - 1);
     MomSum r{INFINITY, -INFINITY, 0., 0., 0., 0., 0.};
-    for (int gi = lane; gi < G; gi += 64) {
-        const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
-        r.mn = pmind(r.mn, p[(size_t)CNNQ_MOM_MIN * C]);
-        r.mx = pmaxd(r.mx, p[(size_t)CNNQ_MOM_MAX * C]);
-        r.s += p[(size_t)CNNQ_MOM_SUM * C];
-        r.ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
-        r.cnt += p[(size_t)CNNQ_MOM_COUNT * C];
-        if (has_relu) {
-            r.rs += p[(size_t)CNNQ_MOM_SUM_RELU * C];
-            r.rss += p[(size_t)CNNQ_MOM_SUMSQ_RELU * C];
+    if (active)
+        for (int gi = j; gi < G; gi += SEG) {
+            const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
+            r.mn = pmind(r.mn, p[(size_t)CNNQ_MOM_MIN * C]);
+            r.mx = pmaxd(r.mx, p[(size_t)CNNQ_MOM_MAX * C]);
+            r.s += p[(size_t)CNNQ_MOM_SUM * C];
+            r.ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
+            r.cnt += p[(size_t)CNNQ_MOM_COUNT * C];
+            if (has_relu) {
+                r.rs += p[(size_t)CNNQ_MOM_SUM_RELU * C];
+                r.rss += p[(size_t)CNNQ_MOM_SUMSQ_RELU * C];
+            }
         }
-    }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = SEG >> 1; m >= 1; m >>= 1) {
         r.mn = pmind(r.mn, shfl_xor_d(r.mn, m));
         r.mx = pmaxd(r.mx, shfl_xor_d(r.mx, m));
         r.s += shfl_xor_d(r.s, m);
@@ -235,6 +266,66 @@ __device__ __forceinline__ MomSum merge_moments(const double* __restrict__ part,
     }
     return r;
 }
+__device__ __forceinline__ MomSum merge_moments(const double* __restrict__ part, int G, int C, int c, bool has_relu,
+                                                bool active) {
+    const int seg = mseg_of(G, C);
+    if (seg == 64) return merge_moments_seg<64>(part, G, C, c, has_relu, active);
+    if (seg == 8) return merge_moments_seg<8>(part, G, C, c, has_relu, active);
+    return merge_moments_seg<1>(part, G, C, c, has_relu, active);
+}
+// The two sums pass B needs (mean; the standard deviation for kurtosis), merged in exactly the order of
+// merge_moments - the min / max / count / relu rows are not even loaded (the count is N * H*W by construction).
+template <int SEG, bool NEED_SS>
+__device__ __forceinline__ void merge_sums_seg(const double* __restrict__ part, int G, int C, int c, bool active, double& s,
+                                               double& ss) {
+    const int j = threadIdx.x & (SEG - 1);
+    s = 0.;
+    ss = 0.;
+    if (active)
+        for (int gi = j; gi < G; gi += SEG) {
+            const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
+            s += p[(size_t)CNNQ_MOM_SUM * C];
+            if constexpr (NEED_SS) ss += p[(size_t)CNNQ_MOM_SUMSQ * C];
+        }
+#pragma unroll
+    for (int m = SEG >> 1; m >= 1; m >>= 1) {
+        s += shfl_xor_d(s, m);
+        if constexpr (NEED_SS) ss += shfl_xor_d(ss, m);
+    }
+}
+template <bool NEED_SS>
+__device__ __forceinline__ void merge_sums(const double* __restrict__ part, int G, int C, int c, bool active, double& s,
+                                           double& ss) {
+    const int seg = mseg_of(G, C);
+    if (seg == 64) merge_sums_seg<64, NEED_SS>(part, G, C, c, active, s, ss);
+    else if (seg == 8) merge_sums_seg<8, NEED_SS>(part, G, C, c, active, s, ss);
+    else merge_sums_seg<1, NEED_SS>(part, G, C, c, active, s, ss);
+}
+// pass-B sums of channel c over the G records, same lane layout
+template <int SEG>
+__device__ __forceinline__ void merge_dev_seg(const double* __restrict__ part2, int G, int C, int c, bool active,
+                                              double& sa, double& sk) {
+    const int j = threadIdx.x & (SEG - 1);
+    sa = 0.;
+    sk = 0.;
+    if (active)
+        for (int gi = j; gi < G; gi += SEG) {
+            const double* p = part2 + (size_t)gi * CNNQ_NDEV * C + c;
+            sa += p[(size_t)CNNQ_DEV_ABS * C];
+            sk += p[(size_t)CNNQ_DEV_Z4 * C];
+        }
+#pragma unroll
+    for (int m = SEG >> 1; m >= 1; m >>= 1) { sa += shfl_xor_d(sa, m); sk += shfl_xor_d(sk, m); }
+}
+__device__ __forceinline__ void merge_dev(const double* __restrict__ part2, int G, int C, int c, bool active, double& sa,
+                                          double& sk) {
+    const int seg = mseg_of(G, C);
+    if (seg == 64) merge_dev_seg<64>(part2, G, C, c, active, sa, sk);
+    else if (seg == 8) merge_dev_seg<8>(part2, G, C, c, active, sa, sk);
+    else merge_dev_seg<1>(part2, G, C, c, active, sa, sk);
+}
+// channels a 256-thread workgroup of the merge kernels handles, and their grid
+__host__ __device__ constexpr int merge_cpw(int G, int C) { return TPB / mseg_of(G, C); }
 __device__ __forceinline__ float mean_of(const MomSum& r) { return (float)(r.s / r.cnt); }
 __device__ __forceinline__ float std_of(const MomSum& r) {
     const double mean = r.s / r.cnt;
@@ -243,14 +334,13 @@ __device__ __forceinline__ float std_of(const MomSum& r) {
     return (float)sqrt(var);
 }
 
-// merge G records per channel; one wave64 per channel, lanes stride over the groups
+// merge G records per channel; mseg_of(G, C) lanes per channel (grid: ceil(C / merge_cpw(G, C)))
 __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part, int G, int C, int has_relu,
                                                  double* __restrict__ mom, float* __restrict__ stats) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (TPB / 64) + wv;
-    if (c >= C) return;
-    const MomSum r = merge_moments(part, G, C, c, has_relu != 0);
-    if (lane != 0) return;
+    const int seg = mseg_of(G, C);
+    const int c = blockIdx.x * (TPB / seg) + threadIdx.x / seg;
+    const MomSum r = merge_moments(part, G, C, c, has_relu != 0, c < C);
+    if (c >= C || (threadIdx.x & (seg - 1)) != 0) return;
     if (mom) {
         mom[(size_t)CNNQ_MOM_MIN * C + c] = r.mn;
         mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
@@ -265,11 +355,16 @@ __global__ void __launch_bounds__(TPB) k_combine(const double* __restrict__ part
         stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)r.mx;
         stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean_of(r);
         stats[(size_t)CNNQ_STAT_STD * C + c] = std_of(r);
+        float std_pos = 0.f;
         if (has_relu) {
             double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
             if (rv < 0.) rv = 0.;
-            stats[(size_t)CNNQ_STAT_STD_POS * C + c] = (float)sqrt(rv);
+            std_pos = (float)sqrt(rv);
         }
+        // the table is written completely: rows nobody computed are zero (B / KURT are filled in later by k_combine_dev)
+        stats[(size_t)CNNQ_STAT_STD_POS * C + c] = std_pos;
+        stats[(size_t)CNNQ_STAT_B * C + c] = 0.f;
+        stats[(size_t)CNNQ_STAT_KURT * C + c] = 0.f;
     }
 }
 
@@ -290,9 +385,13 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
     const Blk b = blk_of<VEC>(g);
     const int tid = threadIdx.x;
     if constexpr (RAW) {
-        for (int i = tid >> 6; i < b.c1 - b.c0; i += TPB / 64) {
-            const MomSum r = merge_moments(part, G, g.C, b.c0 + i, false);
-            if ((tid & 63) == 0) { sh_mean[i] = mean_of(r); sh_std[i] = std_of(r); }
+        const int mseg = mseg_of(G, g.C);
+        for (int base = 0; base < b.c1 - b.c0; base += TPB / mseg) {
+            const int i = base + tid / mseg;
+            const bool act = i < b.c1 - b.c0;
+            MomSum r{0., 0., 0., 0., (double)g.N * (double)g.HW, 0., 0.};
+            merge_sums<KURT>(part, G, g.C, b.c0 + (act ? i : 0), act, r.s, r.ss);
+            if (act && (tid & (mseg - 1)) == 0) { sh_mean[i] = mean_of(r); sh_std[i] = KURT ? std_of(r) : 1.f; }
         }
     } else {
         for (int i = tid; i < b.c1 - b.c0; i += TPB) {
@@ -321,7 +420,8 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
         }
     }
     const int nrows = b.n1 - b.n0;
-#pragma unroll 2
+    constexpr int NU = (8 / J) < 2 ? 2 : 8 / J;
+#pragma unroll NU
     for (int r = 0; r < nrows; ++r) {
         // pass B follows pass A over the same tensor: walking it backwards (g.rev) re-reads what
         // pass A touched last from the Infinity Cache
@@ -380,23 +480,20 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
         }
     __syncthreads();
     const int epc = g.HW * A / VEC;
-    if (epc <= 16) {
-        for (int ch = b.c0 + tid; ch < b.c1; ch += TPB) {
-            const int lo = (ch - b.c0) * epc;
+    const int nch = b.c1 - b.c0;
+    auto fold = [&](auto SEGC) {
+        constexpr int SEG = decltype(SEGC)::value;
+        for (int base = 0; base < nch; base += TPB / SEG) {
+            const int i = base + tid / SEG, j = tid & (SEG - 1);
             double ra = 0., rk = 0.;
-            for (int e = lo; e < lo + epc; ++e) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
-            emit(ch, ra, rk);
-        }
-        return;
-    }
-    for (int ch = b.c0 + wv; ch < b.c1; ch += TPB / 64) {
-        const int lo = (ch - b.c0) * epc;
-        double ra = 0., rk = 0.;
-        for (int e = lo + lane; e < lo + epc; e += 64) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
+            if (i < nch)
+                for (int e = i * epc + j; e < (i + 1) * epc; e += SEG) { ra += l_a[e]; if constexpr (KURT) rk += l_k[e]; }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { ra += shfl_xor_d(ra, m); rk += shfl_xor_d(rk, m); }
-        if (lane == 0) emit(ch, ra, rk);
-    }
+            for (int m = SEG >> 1; m >= 1; m >>= 1) { ra += shfl_xor_d(ra, m); if constexpr (KURT) rk += shfl_xor_d(rk, m); }
+            if (i < nch && j == 0) emit(b.c0 + i, ra, rk);
+        }
+    };
+    CNNQ_SEG_DISPATCH(seg_of(epc), fold);
 }
 
 // final merge of BOTH passes (the fused form: k_moments -> k_absdev<RAW> -> this): rows MIN, MAX, MEAN, STD (STD_POS)
@@ -404,19 +501,12 @@ __global__ void __launch_bounds__(TPB) k_absdev(const float* __restrict__ x, con
 __global__ void __launch_bounds__(TPB) k_combine_all(const double* __restrict__ part, const double* __restrict__ part2,
                                                      int G, int C, int has_relu, int want_kurt, double* __restrict__ mom,
                                                      float* __restrict__ stats) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (TPB / 64) + wv;
-    if (c >= C) return;
-    const MomSum r = merge_moments(part, G, C, c, has_relu != 0);
-    double sa = 0., sk = 0.;
-    for (int gi = lane; gi < G; gi += 64) {
-        const double* p = part2 + (size_t)gi * CNNQ_NDEV * C + c;
-        sa += p[(size_t)CNNQ_DEV_ABS * C];
-        sk += p[(size_t)CNNQ_DEV_Z4 * C];
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { sa += shfl_xor_d(sa, m); sk += shfl_xor_d(sk, m); }
-    if (lane != 0) return;
+    const int seg = mseg_of(G, C);
+    const int c = blockIdx.x * (TPB / seg) + threadIdx.x / seg;
+    const MomSum r = merge_moments(part, G, C, c, has_relu != 0, c < C);
+    double sa, sk;
+    merge_dev(part2, G, C, c, c < C, sa, sk);
+    if (c >= C || (threadIdx.x & (seg - 1)) != 0) return;
     if (mom) {
         mom[(size_t)CNNQ_MOM_MIN * C + c] = r.mn;
         mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
@@ -430,30 +520,25 @@ __global__ void __launch_bounds__(TPB) k_combine_all(const double* __restrict__ 
     stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)r.mx;
     stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean_of(r);
     stats[(size_t)CNNQ_STAT_STD * C + c] = std_of(r);
+    float std_pos = 0.f;
     if (has_relu) {
         double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
         if (rv < 0.) rv = 0.;
-        stats[(size_t)CNNQ_STAT_STD_POS * C + c] = (float)sqrt(rv);
+        std_pos = (float)sqrt(rv);
     }
+    stats[(size_t)CNNQ_STAT_STD_POS * C + c] = std_pos;   // every row is written: no memset in front of the chain
     stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sa / r.cnt);
-    if (want_kurt) stats[(size_t)CNNQ_STAT_KURT * C + c] = (float)(sk / r.cnt - 3.);
+    stats[(size_t)CNNQ_STAT_KURT * C + c] = want_kurt ? (float)(sk / r.cnt - 3.) : 0.f;
 }
 
 __global__ void __launch_bounds__(TPB) k_combine_dev(const double* __restrict__ part2, int G, int C,
                                                      const double* __restrict__ mom, int want_kurt,
                                                      double* __restrict__ dev_out, float* __restrict__ stats) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (TPB / 64) + wv;
-    if (c >= C) return;
-    double sa = 0., sk = 0.;
-    for (int gi = lane; gi < G; gi += 64) {
-        const double* p = part2 + (size_t)gi * CNNQ_NDEV * C + c;
-        sa += p[(size_t)CNNQ_DEV_ABS * C];
-        sk += p[(size_t)CNNQ_DEV_Z4 * C];
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { sa += shfl_xor_d(sa, m); sk += shfl_xor_d(sk, m); }
-    if (lane != 0) return;
+    const int seg = mseg_of(G, C);
+    const int c = blockIdx.x * (TPB / seg) + threadIdx.x / seg;
+    double sa, sk;
+    merge_dev(part2, G, C, c, c < C, sa, sk);
+    if (c >= C || (threadIdx.x & (seg - 1)) != 0) return;
     if (dev_out) {
         dev_out[(size_t)CNNQ_DEV_ABS * C + c] = sa;
         dev_out[(size_t)CNNQ_DEV_Z4 * C + c] = sk;

@@ -129,11 +129,8 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
             L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
         stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
         mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
-        # one launch and one read of x when the geometry has a group plan (cnnq_pc_stats_group), else the chain
-        gws = _stats_group_workspace(x, N, C, HW)
-        L.check(lib.cnnq_pc_stats_auto(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)),
-                                       _ptr(_scratch(x, 'stats', nbytes)), gws, GROUP_WS_BYTES if gws is not None else 0,
-                                       _ptr(mom), _ptr(stats), _stream(x)), 'cnnq_pc_stats_auto')
+        L.check(lib.cnnq_pc_stats(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)),
+                                  _ptr(_scratch(x, 'stats', nbytes)), _ptr(mom), _ptr(stats), _stream(x)), 'cnnq_pc_stats')
         return stats, mom
     part = pc_moments(x, N, C, HW, need_relu)
     if world > 1:
@@ -241,43 +238,6 @@ def _group_workspace(x):
             pool.append(w)
     ws = _GROUP_WS[key] = pool.pop()
     return ws
-
-
-_SG_OK = {}
-
-
-def _stats_group_workspace(x, N, C, HW):
-    """The exchange workspace when the single-read statistics kernel covers (N, C, HW), else None."""
-    if os.environ.get('CNNQ_RESIDENT', '1') == '0' or os.environ.get('CNNQ_STATS_GROUP', '1') == '0':
-        return None
-    key = (N, C, HW)
-    ok = _SG_OK.get(key)
-    if ok is None:
-        ok = _SG_OK[key] = 0 < L.load().cnnq_pc_stats_group_workspace(N, C, HW) <= GROUP_WS_BYTES
-    if not ok or x.data_ptr() % 16:
-        return None
-    return _group_workspace(x)
-
-
-def pc_stats_group(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, flags=0):
-    """The statistics table from ONE launch and ONE read of x (cnnq_pc_stats_group); None when the geometry is not
-    supported.  flags bit 0 (tests): every wait gives up at once."""
-    lib = L.load()
-    x = _dev_f32(x, 'x')
-    nbytes = lib.cnnq_pc_stats_group_workspace(N, C, HW)
-    if nbytes == 0 or nbytes > GROUP_WS_BYTES:
-        return None
-    gws = _group_workspace(x)
-    if gws is None:
-        return None
-    stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
-    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
-    rc = lib.cnnq_pc_stats_group(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)), gws,
-                                 _ptr(mom), _ptr(stats), int(flags), _stream(x))
-    if rc == L.ENOTSUP:
-        return None
-    L.check(rc, 'cnnq_pc_stats_group')
-    return stats, mom
 
 
 def group_status(x):
@@ -662,10 +622,8 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         ws = torch.empty(lib.cnnq_pc_aciq_workspace(N, C, HW, int(x.data_ptr() % 16 == 0)), dtype=torch.uint8,
                          device=x.device)
         qd = torch.empty((L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
-        gws = _stats_group_workspace(x, N, C, HW)
-        L.check(lib.cnnq_pc_aciq_qdq_auto(_ptr(x), _ptr(y), N, C, HW, ctypes.byref(cfg), _ptr(ws), gws,
-                                          GROUP_WS_BYTES if gws is not None else 0, _ptr(qd), _ptr(qd[L.NQP:]),
-                                          _stream(x)), 'cnnq_pc_aciq_qdq_auto')
+        L.check(lib.cnnq_pc_aciq_qdq(_ptr(x), _ptr(y), N, C, HW, ctypes.byref(cfg), _ptr(ws), _ptr(qd),
+                                     _ptr(qd[L.NQP:]), _stream(x)), 'cnnq_pc_aciq_qdq')
         return y
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)

@@ -103,8 +103,9 @@ int cnnq_pc_moments(const float* x, int64_t N, int64_t C, int64_t HW, int want_r
 
 /* Merge G moment records per channel (G = groups of one tensor, or G = world size after an
  * all_gather of per-rank records) into mom[CNNQ_NMOM][C] and, when `stats` is not NULL, write
- * rows MIN, MAX, MEAN, STD (and STD_POS when the records carry relu sums) of stats[CNNQ_NSTAT][C].
- * Fixed merge order -> deterministic.  `mom` may be NULL. */
+ * the whole table stats[CNNQ_NSTAT][C]: rows MIN, MAX, MEAN, STD, STD_POS (zero unless the records carry relu
+ * sums), and zeros in rows B and KURT (cnnq_pc_combine_dev fills them after pass B).
+ * Fixed merge order (a function of G and C) -> deterministic.  `mom` may be NULL. */
 int cnnq_pc_combine(const double* part, int G, int64_t C, int has_relu, double* mom, float* stats,
                     void* stream);
 
@@ -129,20 +130,6 @@ int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom
 size_t cnnq_pc_stats_workspace(int64_t N, int64_t C, int64_t HW, int aligned16);
 int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws,
                   double* mom, float* stats, void* stream);
-
-/* The same table from ONE launch and ONE read of x (4 instead of 8 bytes per element): workgroups keep their tile in
- * registers across both passes and exchange per-channel records twice inside the launch (the meeting protocol of
- * cnnq_pc_minmax_qdq_group).  Needs rows of whole float4s (HW % 4 == 0, 16-byte aligned x) and a group plan:
- * cnnq_pc_stats_group_workspace returns the bytes of exchange workspace `gws` (from cnnq_group_ws_alloc) the
- * geometry needs, 0 = not supported (cnnq_pc_stats_group then returns CNNQ_ENOTSUP).  min / max equal the chain's
- * exactly, the fp64 sums to fp64 rounding (another partition of the same additions).  flags bit 0 (tests): every
- * wait gives up at once and the cold path recomputes from x.  cnnq_pc_stats_auto takes the single launch when
- * gws / gws_bytes allow it, else cnnq_pc_stats with `ws`. */
-size_t cnnq_pc_stats_group_workspace(int64_t N, int64_t C, int64_t HW);
-int cnnq_pc_stats_group(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu,
-                        void* gws, double* mom, float* stats, unsigned flags, void* stream);
-int cnnq_pc_stats_auto(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu,
-                       void* ws, void* gws, size_t gws_bytes, double* mom, float* stats, void* stream);
 
 /* Per-channel statistics -> quantisation parameters, entirely on the device (the reference
  * takes >= 6 host round trips here: iq.py:248,285-288,355,405).  One workgroup.
@@ -302,10 +289,6 @@ int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int6
 size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16);
 int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
                      float* qp, float* diag, void* stream);
-/* same, with the statistics from the single-read kernel (cnnq_pc_stats_group) when `gws` (exchange workspace of
- * gws_bytes bytes, may be NULL) covers the geometry: 12 instead of 16 bytes per element */
-int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
-                          void* gws, size_t gws_bytes, float* qp, float* diag, void* stream);
 
 /* Weight bias / variance correction after quantization (iqm.py:374-391), in place on
  * wq[C][HW]: vcorr: wq = (wq - mean_q) * std_w/(std_q + 1e-8) + mean_q; bcorr: wq = wq - mean_q + mean_w

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-layer time of the statistics of one tensor: single-read kernel (cnnq_pc_stats_group) vs the two-pass chain
-(cnnq_pc_stats), ResNet-50 conv outputs at BATCH (default 512).  Development aid."""
+"""Per-layer time of the per-channel statistics (cnnq_pc_stats: pass A, pass B, merge) on the ResNet-50 conv outputs
+at BATCH (default 512); FULL=1 (default) = all seven statistics (config 4), FULL=0 = min/max/mean/std/b (config 3).
+Development aid."""
 import os
 import sys
 
@@ -11,7 +12,7 @@ from bench import RESNET50_CONV_OUTPUTS, laplace_activation  # noqa: E402
 from cnn_quantization_amd import ops  # noqa: E402
 
 
-def timed(fn, reps=5):
+def timed(fn, reps=7):
     fn()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -29,23 +30,17 @@ def main():
     batch = int(os.environ.get('BATCH', '512'))
     full = os.environ.get('FULL', '1') == '1'
     dev = torch.device('cuda')
-    tot = [0., 0.]
-    seen = {}
+    tot = ideal = 0.
     for (C, hw, _half, rep) in RESNET50_CONV_OUTPUTS:
         x = laplace_activation((batch, C, hw, hw), 3, dev)
         kw = dict(need_b=True, need_kurt=full, need_relu=full)
-        os.environ['CNNQ_STATS_GROUP'] = '0'
-        tc = timed(lambda: ops.pc_stats(x, batch, C, hw * hw, **kw))
-        os.environ['CNNQ_STATS_GROUP'] = '1'
-        tg = timed(lambda: ops.pc_stats(x, batch, C, hw * hw, **kw))
-        sup = ops.pc_stats_group(x, batch, C, hw * hw, **kw) is not None
+        t = timed(lambda: ops.pc_stats(x, batch, C, hw * hw, **kw))
         gb = x.numel() * 4 / 1e9
-        print('C=%4d hw=%3d x%d  chain %.3f ms (%.2f TB/s @8B)  single %.3f ms (%.2f TB/s @4B) %s' % (
-            C, hw, rep, tc, 2 * gb / tc, tg, gb / tg, '' if sup else '[chain]'), flush=True)
-        tot[0] += tc * rep
-        tot[1] += tg * rep
+        print('C=%4d hw=%3d x%-2d  %.3f ms  %.2f TB/s (8 B/elem)' % (C, hw, rep, t, 2 * gb / t), flush=True)
+        tot += t * rep
+        ideal += 2 * gb / 8.0 * rep
         del x
-    print('total chain %.3f ms, default route %.3f ms, status %d' % (tot[0], tot[1], 0))
+    print('total %.3f ms = %.1f %% of 8 TB/s' % (tot, ideal / tot * 100))
 
 
 if __name__ == '__main__':
