@@ -15,8 +15,14 @@ STAT_MIN, STAT_MAX, STAT_MEAN, STAT_STD, STAT_B, STAT_KURT, STAT_STD_POS, NSTAT 
 MOM_MIN, MOM_MAX, MOM_SUM, MOM_SUMSQ, MOM_COUNT, MOM_SUM_RELU, MOM_SUMSQ_RELU, NMOM = 0, 1, 2, 3, 4, 5, 6, 7
 DEV_ABS, DEV_Z4, NDEV = 0, 1, 2
 QP_SCALE, QP_ZP, QP_QMAX, NQP = 0, 1, 2, 3
-MT_DELTA, MT_CMIN, MT_CMAX, MT_OMEGA, MT_ALPHA, NMT = 0, 1, 2, 3, 4, 5
+MT_DELTA, MT_CMIN, MT_CMAX, MT_OMEGA, MT_ALPHA, MT_WSTART, NMT = 0, 1, 2, 3, 4, 5, 6
 MT_HIST_BINS = 131072
+MT_HIST_WINDOW, MT_HIST_REPLICAS = 128, 256
+
+
+def mt_hist_words(C):
+    """CNNQ_MT_HIST_WORDS(C) of include/cnnq_hip.h"""
+    return MT_HIST_BINS + 2 + 2 * C + MT_HIST_REPLICAS * MT_HIST_WINDOW + 1
 KLD_BINS, KLD_QBINS, KLD_NCAND = 2001, 15, 994
 DIAG_BITS, DIAG_ALPHA, DIAG_DELTA, DIAG_OFFSET, NDIAG = 0, 1, 2, 3, 4
 

@@ -38,10 +38,12 @@ struct Blk {
     int grp;         // partial group index
 };
 
+// tile `id` of `total` (a launch with one workgroup per tile passes blockIdx.x / gridDim.x; persistent kernels walk
+// id = blockIdx.x, blockIdx.x + gridDim.x, ...)
 template <int VEC>
-__device__ __forceinline__ Blk blk_of(const Geo& g) {
+__device__ __forceinline__ Blk blk_of_id(const Geo& g, int id, int total) {
     Blk b;
-    const int bid = g.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int bid = g.rev ? total - 1 - id : id;
     const int cb = bid % g.ncb;
     const int s = bid / g.ncb;
     b.n0 = (int)(((int64_t)s * g.N) / g.S);
@@ -64,6 +66,11 @@ __device__ __forceinline__ Blk blk_of(const Geo& g) {
         b.grp = s;
     }
     return b;
+}
+
+template <int VEC>
+__device__ __forceinline__ Blk blk_of(const Geo& g) {
+    return blk_of_id<VEC>(g, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int VEC>

@@ -632,17 +632,19 @@ int cnnq_pc_midtread_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t
     if (!x || !y || !mt) return CNNQ_EINVAL;
     Variant v;
     Geo g;
-        // the histogram variant keeps long-lived workgroups: each zeroes and flushes an LDS table (with short
-    // workgroups config 5 ran 41.7 ms instead of 21.2)
-    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || al16(codes)), 0, &v, &g, /*fine=*/hist ? 0 : 1);
+    // short tiles in address order (14 KB); 56 KB with the histogram, whose per-workgroup flush - one global atomic per
+    // live bin - wants fewer workgroups (swept 14 .. 448 KB on VGG-16 b512: 21.7 / 20.2 / 19.4 / 19.5 / 20.3 / 20.9 ms)
+    const int rc = plan(N, C, HW, al16(x) && al16(y) && (!codes || al16(codes)), 0, &v, &g, /*fine=*/hist ? 57344 : 1);
     if (rc) return rc;
-    const dim3 grid((unsigned)(g.S * g.ncb)), block(TPB);
+    const int total = g.S * g.ncb;
+    const int wgs = total;
+    const dim3 grid((unsigned)wgs), block(TPB);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* h = reinterpret_cast<unsigned long long*>(hist);
-#define LAUNCH_MT3(VEC, A, J, CL, HI)                                                                            \
-    do {                                                                                                        \
-        if (codes) hipLaunchKernelGGL((k_mt_qdq<VEC, A, J, CL, HI, true>), grid, block, 0, st, x, y, g, mt, codes, h); \
-        else hipLaunchKernelGGL((k_mt_qdq<VEC, A, J, CL, HI, false>), grid, block, 0, st, x, y, g, mt, codes, h);      \
+#define LAUNCH_MT3(VEC, A, J, CL, HI)                                                                                   \
+    do {                                                                                                               \
+        if (codes) hipLaunchKernelGGL((k_mt_qdq<VEC, A, J, CL, HI, true>), grid, block, 0, st, x, y, g, mt, codes, h, total); \
+        else hipLaunchKernelGGL((k_mt_qdq<VEC, A, J, CL, HI, false>), grid, block, 0, st, x, y, g, mt, codes, h, total);      \
     } while (0)
 #define LAUNCH_MT(VEC, A, J)                                      \
     do {                                                          \

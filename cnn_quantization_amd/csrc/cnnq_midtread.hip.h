@@ -16,6 +16,11 @@ struct MtCfg {
 };
 
 constexpr int MT_NB = CNNQ_MT_HIST_BINS;  // integer-code bins, codes -MT_NB/2 .. MT_NB/2-1
+constexpr int MT_W = CNNQ_MT_HIST_WINDOW; // codes of the histogram window [wstart, wstart + MT_W): LDS bins, replica bins
+constexpr int MT_GR = CNNQ_MT_HIST_REPLICAS;
+constexpr int MT_REP = 8;                 // LDS copies of a window bin (by lane)
+// last word of the histogram: non-zero when any count went to the global bins [0, MT_NB + 2) (a code outside the window)
+__host__ __device__ constexpr size_t mt_flag_word(int C) { return (size_t)MT_NB + 2 + 2 * (size_t)C + (size_t)MT_GR * MT_W; }
 
 __global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ stats, int C, const MtCfg cfg,
                                                     const double* __restrict__ tabs, int ntab,
@@ -34,6 +39,7 @@ __global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ st
     for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(vstd[c], (float)(2. / 3));
     const float psum = (float)block_sum(psum_d, sh);
     const float B = (float)((double)C * pow(2., cfg.target));
+    float wmin = 1e9f;
     for (int c = tid; c < C; c += PTPB) {
         const float p = powf(vstd[c], (float)(2. / 3));
         const float omega = rintf((B * p) / psum);
@@ -68,117 +74,168 @@ __global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ st
         mt[(size_t)CNNQ_MT_CMAX * C + c] = cmax;
         mt[(size_t)CNNQ_MT_OMEGA * C + c] = omega;
         mt[(size_t)CNNQ_MT_ALPHA * C + c] = am;
+        if (cfg.clip) wmin = fminf(wmin, floorf(fminf(fmaxf(cmin, -1e9f), 1e9f)));
     }
+    // first code of the histogram window: the smallest clamp bound of the tensor (codes are >= c_min); without
+    // clipping the window is centred on zero
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wmin = fminf(wmin, shfl_xor_f(wmin, m));
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = (double)wmin;
+    __syncthreads();
+    float w0 = 1e9f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) w0 = fminf(w0, (float)sh[i]);
+    const float wstart = cfg.clip ? fmaxf(w0, (float)(-MT_NB / 2)) : (float)(-MT_W / 2);
+    for (int c = tid; c < C; c += PTPB) mt[(size_t)CNNQ_MT_WSTART * C + c] = wstart;
 }
 
-// hist layout (uint64): [0, MT_NB) integer codes -MT_NB/2.., [MT_NB] below range, [MT_NB+1] above
-// range, then C counts of "clamped to a non-integer c_min[c]" and C of "... c_max[c]".
+// hist layout (uint64): [0, MT_NB) integer codes -MT_NB/2.., [MT_NB] below range, [MT_NB+1] above range, C counts of
+// "clamped to a non-integer c_min[c]" and C of "... c_max[c]", then MT_GR replicas of the MT_W window bins
+// (code = wstart + i; k_mt_entropy adds them to the integer bins).
+//
+// Where the histogram's cost was (measured, VGG-16 b512): not in the update - with the LDS atomics compiled out, or
+// the branchy update made branch-free, the kernel ran the same 1190 us per large layer against 950 us without
+// histogram - but in the launch shape the per-workgroup table forced: a 22 KB LDS table (512 codes, 8-32 copies)
+// zeroed and flushed per workgroup, and ~30 global atomics per flush on the SAME few addresses, were only affordable
+// with 4096 long-lived workgroups, and long-lived workgroups stream x -> y at 5.4 instead of 6.1 TB/s (a persistent
+// loop over short tiles was slower still: 19.5 vs 18.0 ms even without histogram).  Now the histogram variant runs on
+// the same short tiles as the plain one: a 4 KB LDS table (MT_W codes x 8 copies by lane; zero is counted in a
+// register) and a flush of one atomic per live bin into one of MT_GR replica tables (by workgroup id), which keeps
+// the same-address chains short.  Codes outside the window go to the global bins directly (correct, slow, rare: the
+// window starts at the tensor's smallest clamp bound and a channel has ~2^target bins).
+// The kernel walks tiles id = blockIdx.x, blockIdx.x + gridDim.x, ... of `total` (launched with one workgroup per tile).
 template <int VEC, int A, int J, bool CLIP, bool HIST, bool CODES>
 __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
                                                 const float* __restrict__ mt, float* __restrict__ codes,
-                                                unsigned long long* __restrict__ hist) {
-    // LDS histogram window: MT_W integer codes starting at the smallest clamp bound of this
-    // workgroup's channels (codes are >= c_min), MT_REP replicas by lane to spread equal codes;
-    // codes beyond the window (a channel with > MT_W bins) go to the global bins directly.
-    // The first MT_HOT codes of the window (where the mass is) get 32 lane-replicas = conflict-free,
-    // the tail 8.
-    constexpr int MT_W = 512, MT_HOT = 64, MT_REP = 8;
-    constexpr int MT_WORDS = MT_HOT * 32 + (MT_W - MT_HOT) * MT_REP;
-    auto hidx = [](unsigned kk, int tid) -> unsigned {
-        return kk < (unsigned)MT_HOT ? kk * 32u + (unsigned)(tid & 31)
-                                     : (unsigned)(MT_HOT * 32) + (kk - MT_HOT) * MT_REP + (unsigned)(tid & (MT_REP - 1));
-    };
+                                                unsigned long long* __restrict__ hist, const int total) {
+    constexpr int MT_WORDS = MT_W * MT_REP;
+    auto hidx = [](unsigned kk, int tid) -> unsigned { return kk * MT_REP + (unsigned)(tid & (MT_REP - 1)); };
     __shared__ float sh_d[MAXCH], sh_lo[MAXCH], sh_hi[MAXCH];
     __shared__ unsigned sh_hist[HIST ? MT_WORDS : 1];
     __shared__ unsigned sh_clo[HIST ? MAXCH : 1], sh_chi[HIST ? MAXCH : 1];
-    __shared__ int sh_wstart;
-    const Blk b = blk_of<VEC>(g);
     const int tid = threadIdx.x;
-    const int nch = b.c1 - b.c0;
     if constexpr (HIST) {
         for (int i = tid; i < MT_WORDS; i += TPB) sh_hist[i] = 0u;
-        for (int i = tid; i < nch; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
-        if (tid == 0) sh_wstart = CLIP ? 0x7fffffff : -MT_W / 2;
+        for (int i = tid; i < MAXCH; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = tid; i < nch; i += TPB) {
-        sh_d[i] = mt[(size_t)CNNQ_MT_DELTA * g.C + b.c0 + i];
-        const float lo_i = mt[(size_t)CNNQ_MT_CMIN * g.C + b.c0 + i];
-        sh_lo[i] = lo_i;
-        sh_hi[i] = mt[(size_t)CNNQ_MT_CMAX * g.C + b.c0 + i];
-        if constexpr (HIST && CLIP) atomicMin(&sh_wstart, (int)floorf(fminf(fmaxf(lo_i, -1e9f), 1e9f)));
-    }
-    __syncthreads();
-    const int wstart = HIST ? max(sh_wstart, -MT_NB / 2) : 0;
-    int col[J], chl[J][A];
-    bool ok[J];
-    float d[J][A], lo[J][A], hi[J][A];
+    const int wstart = HIST ? (int)mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
     unsigned nzero = 0;  // code 0 (the mode of the distribution) is counted in a register, see k_qdq
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int c = b.col0 + j * TPB + tid;
-        ok[j] = c < b.col1;
-        col[j] = ok[j] ? c : b.col0;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-            const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
-            const int ch = (int)(e / (unsigned)g.HW) - b.c0;
-            chl[j][a] = ch;
-            d[j][a] = sh_d[ch];
-            lo[j][a] = sh_lo[ch];
-            hi[j][a] = sh_hi[ch];
+    for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
+        const Blk b = blk_of_id<VEC>(g, vb, total);
+        const int nch = b.c1 - b.c0;
+        for (int i = tid; i < nch; i += TPB) {
+            sh_d[i] = mt[(size_t)CNNQ_MT_DELTA * g.C + b.c0 + i];
+            sh_lo[i] = mt[(size_t)CNNQ_MT_CMIN * g.C + b.c0 + i];
+            sh_hi[i] = mt[(size_t)CNNQ_MT_CMAX * g.C + b.c0 + i];
         }
-    }
-    const int nrows = b.n1 - b.n0;
-    constexpr int NU = (J == 1) ? 4 : 2;
-#pragma unroll NU
-    for (int r = 0; r < nrows; ++r) {
-        const size_t off = (size_t)(b.n0 + r) * (size_t)g.P;
-        float v[J][VEC];
-#pragma unroll
-        for (int j = 0; j < J; ++j) ldv_nt<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+        __syncthreads();
+        int col[J], chl[J][A];
+        bool ok[J];
+        float d[J][A], lo[J][A], hi[J][A];
+        bool hi_ni[J][A], lo_ni[J][A];      // histogram: the clamp bound is not an integer code
+        unsigned nhi[J][A], nlo[J][A];      // ... and how often this lane clamped to it in this tile
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            float o[VEC], q[VEC];
+            const int c = b.col0 + j * TPB + tid;
+            ok[j] = c < b.col1;
+            col[j] = ok[j] ? c : b.col0;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int a = (A == 1 ? 0 : e);
-                float t = rintf(v[j][e] / d[j][a]);          // iq.py:202-203
-                if constexpr (CLIP) {
-                    // torch.min(t, hi) = t < hi ? t : hi and torch.max(t, lo) = t > lo ? t : lo, NaN kept
-                    // (the bound wins ties: max(-0, +0) is +0, iq.py:213-214)
-                    t = (t < hi[j][a] || t != t) ? t : hi[j][a];
-                    t = (t > lo[j][a] || t != t) ? t : lo[j][a];
+            for (int a = 0; a < A; ++a) {
+                const unsigned e = (unsigned)col[j] * VEC + (A == 1 ? 0 : a);
+                const int ch = (int)(e / (unsigned)g.HW) - b.c0;
+                chl[j][a] = ch;
+                d[j][a] = sh_d[ch];
+                lo[j][a] = sh_lo[ch];
+                hi[j][a] = sh_hi[ch];
+                if constexpr (HIST && CLIP) {
+                    hi_ni[j][a] = hi[j][a] != rintf(hi[j][a]);   // a non-integer bound is a value of its own
+                    lo_ni[j][a] = lo[j][a] != rintf(lo[j][a]);
+                    nhi[j][a] = 0u;
+                    nlo[j][a] = 0u;
                 }
-                q[e] = t;
-                o[e] = t * d[j][a];                          // iq.py:224
             }
-            if (ok[j]) {
-                stv_nt<VEC>(y + off + (size_t)col[j] * VEC, o);
-                if constexpr (CODES) stv<VEC>(codes + off + (size_t)col[j] * VEC, q);
-                if constexpr (HIST) {
+        }
+        const int nrows = b.n1 - b.n0;
+        constexpr int NU = (J == 1) ? 4 : 2;
+#pragma unroll NU
+        for (int r = 0; r < nrows; ++r) {
+            const size_t off = (size_t)(b.n0 + r) * (size_t)g.P;
+            float v[J][VEC];
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int a = (A == 1 ? 0 : e);
-                        const float t = q[e];
-                        // fast path (branch-light): integer code inside the LDS window
-                        const int k = (int)t;                       // saturating; NaN -> 0
-                        const bool isint = ((float)k == t);
-                        const unsigned kk = (unsigned)(k - wstart);
-                        if (t == 0.f) {
-                            ++nzero;
-                        } else if (isint && kk < (unsigned)MT_W) {
-                            atomicAdd(&sh_hist[hidx(kk, tid)], 1u);
-                        } else if (t == rintf(t)) {                 // rare: integer code outside the window
-                            if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
-                            else atomicAdd(&hist[t < 0.f ? MT_NB : MT_NB + 1], 1ull);
-                        } else if (CLIP && t == hi[j][a]) {         // rare: clamped to a non-integer bound
-                            atomicAdd(&sh_chi[chl[j][a]], 1u);
-                        } else {
-                            atomicAdd(&sh_clo[chl[j][a]], 1u);      // non-integer c_min (or NaN)
+            for (int j = 0; j < J; ++j) ldv_nt<VEC>(x + off + (size_t)col[j] * VEC, v[j]);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                float o[VEC], q[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int a = (A == 1 ? 0 : e);
+                    float t = rintf(v[j][e] / d[j][a]);          // iq.py:202-203
+                    if constexpr (CLIP) {
+                        // torch.min(t, hi) = t < hi ? t : hi and torch.max(t, lo) = t > lo ? t : lo, NaN kept
+                        // (the bound wins ties: max(-0, +0) is +0, iq.py:213-214)
+                        t = (t < hi[j][a] || t != t) ? t : hi[j][a];
+                        t = (t > lo[j][a] || t != t) ? t : lo[j][a];
+                    }
+                    q[e] = t;
+                    o[e] = t * d[j][a];                          // iq.py:224
+                }
+                if (ok[j]) {
+                    stv_nt<VEC>(y + off + (size_t)col[j] * VEC, o);
+                    if constexpr (CODES) stv<VEC>(codes + off + (size_t)col[j] * VEC, q);
+                    if constexpr (HIST) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const int a = (A == 1 ? 0 : e);
+                            const float t = q[e];
+                            // Branch-free for everything common: zero and "clamped to a non-integer bound" are
+                            // counted in registers (carry adds), an integer code inside the window is one LDS
+                            // atomic under the lane mask.  The if / else-if chain this replaces executed all its
+                            // arms on nearly every step (some lane always takes each): 2.2x the VALU and 3.3x the
+                            // SALU instructions of the kernel without histogram.
+                            const bool z = (t == 0.f);
+                            const bool at_hi = CLIP && hi_ni[j][a] && t == hi[j][a];
+                            const bool at_lo = CLIP && lo_ni[j][a] && t == lo[j][a];
+                            nzero += z ? 1u : 0u;
+                            if constexpr (CLIP) { nhi[j][a] += at_hi ? 1u : 0u; nlo[j][a] += at_lo ? 1u : 0u; }
+                            const int k = (int)t;                       // saturating; NaN -> 0
+                            const unsigned kk = (unsigned)(k - wstart);
+                            const bool fast = ((float)k == t) && kk < (unsigned)MT_W;
+                            if (fast && !z) {
+#ifdef MT_EXP_NOATOMIC
+                                nzero += kk;
+#else
+                                atomicAdd(&sh_hist[hidx(kk, tid)], 1u);
+#endif
+                            } else if (!(z || at_hi || at_lo)) {        // rare
+                                if (t == rintf(t)) {                    // integer code outside the window (or inf)
+                                    if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
+                                    else atomicAdd(&hist[t < 0.f ? MT_NB : MT_NB + 1], 1ull);
+                                    atomicAdd(&hist[mt_flag_word(g.C)], 1ull);   // the global bins are in use
+                                } else {
+                                    atomicAdd(&sh_clo[chl[j][a]], 1u);  // NaN
+                                }
+                            }
                         }
                     }
                 }
+            }
+        }
+        if constexpr (HIST && CLIP) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    if (nhi[j][a]) atomicAdd(&sh_chi[chl[j][a]], nhi[j][a]);
+                    if (nlo[j][a]) atomicAdd(&sh_clo[chl[j][a]], nlo[j][a]);
+                }
+        }
+        __syncthreads();   // the tile's channel tables (and clamp counters) are complete / no longer read
+        if constexpr (HIST) {
+            // the clamp counters are indexed by the tile's channels: hand them over before the next tile
+            for (int i = tid; i < nch; i += TPB) {
+                if (sh_clo[i]) { atomicAdd(&hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]); sh_clo[i] = 0u; }
+                if (sh_chi[i]) { atomicAdd(&hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]); sh_chi[i] = 0u; }
             }
         }
     }
@@ -189,16 +246,19 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
             else atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
         }
         __syncthreads();
+        unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)g.C + (size_t)(blockIdx.x & (MT_GR - 1)) * MT_W;
         for (int i = tid; i < MT_W; i += TPB) {
             unsigned tot = 0;
-            const int nrep = i < MT_HOT ? 32 : MT_REP;
-            for (int r = 0; r < nrep; ++r) tot += sh_hist[hidx((unsigned)i, r + tid)];
-            const int k = wstart + i;
-            if (tot && k < MT_NB / 2) atomicAdd(&hist[k + MT_NB / 2], (unsigned long long)tot);
-        }
-        for (int i = tid; i < nch; i += TPB) {
-            if (sh_clo[i]) atomicAdd(&hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]);
-            if (sh_chi[i]) atomicAdd(&hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]);
+#pragma unroll
+            for (int r = 0; r < MT_REP; ++r) tot += sh_hist[hidx((unsigned)i, r + tid)];
+            if (tot) {
+                if (wstart + i < MT_NB / 2) {
+                    atomicAdd(&rep[i], (unsigned long long)tot);
+                } else {
+                    atomicAdd(&hist[MT_NB + 1], (unsigned long long)tot);
+                    atomicAdd(&hist[mt_flag_word(g.C)], 1ull);
+                }
+            }
         }
     }
 }
@@ -209,19 +269,36 @@ __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* _
                                                      const float* __restrict__ mt, int C, double total,
                                                      float* __restrict__ out) {
     __shared__ double sh[PTPB / 64];
+    __shared__ unsigned long long lrep[MT_W];
     const int tid = threadIdx.x;
     const float ftotal = (float)total;
     double e = 0.;
+    // the window bins live in MT_GR replica tables: fold them (bin i of the window is code wstart + i)
+    const unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C;
+    const int wbase = (int)mt[(size_t)CNNQ_MT_WSTART * C] + MT_NB / 2;
+    for (int i = tid; i < MT_W; i += PTPB) {
+        unsigned long long t = 0;
+        for (int r = 0; r < MT_GR; ++r) t += rep[(size_t)r * MT_W + i];
+        lrep[i] = t;
+    }
+    __syncthreads();
     // 131074 bins through one workgroup: 16 independent loads in flight per thread (a dependent
     // load per iteration made this kernel 150 us of pure latency); each thread still adds its bins in
     // ascending order, so the sum is unchanged
     constexpr int UNR = 16;
-    for (int base = 0; base < MT_NB + 2; base += PTPB * UNR) {
+    const bool global_bins = hist[mt_flag_word(C)] != 0ull;   // uniform
+    if (!global_bins) {
+        // every count sits in the window (the normal case): 128 bins instead of 131074
+        for (int i = tid; i < MT_W; i += PTPB)
+            if (lrep[i]) { const float pr = (float)lrep[i] / ftotal; e += (double)(-pr * log2f(pr)); }
+    }
+    for (int base = 0; global_bins && base < MT_NB + 2; base += PTPB * UNR) {
         unsigned long long c[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int i = base + u * PTPB + tid;
             c[u] = i < MT_NB + 2 ? hist[i] : 0ull;
+            if ((unsigned)(i - wbase) < (unsigned)MT_W && i < MT_NB) c[u] += lrep[i - wbase];
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -232,7 +309,7 @@ __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* _
     // list entry walks the whole list with broadcast reads, branch-free: the entry represents its value
     // if no earlier list entry has the same value, and then carries the hits of all equal entries.
     // (2*C <= MT_ENT entries; beyond that a plain global-memory scan.)
-    const unsigned long long* cl = hist + MT_NB + 2;
+    const unsigned long long* cl = hist + MT_NB + 2;   // 2*C clamp counters
     constexpr int MT_ENT = 4096;
     __shared__ float lv[MT_ENT];
     __shared__ unsigned long long lc[MT_ENT];

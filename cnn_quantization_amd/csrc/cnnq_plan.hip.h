@@ -101,7 +101,8 @@ int make_geo(int64_t N, int64_t C, int64_t HW, const Variant& v, int64_t cbeg, i
         // markedly faster than long-lived ones (6.1-6.7 vs 5.4 TB/s measured)
         const int64_t cols = (g->mode == 1) ? g->w : (int64_t)g->k * HW * v.A / v.vec / v.A;
         const int64_t row_bytes = cols * v.vec * 4;
-        int64_t rows = (14336 + row_bytes / 2) / (row_bytes > 0 ? row_bytes : 1);   // swept 8-32 KB
+        const int64_t tile = fine > 1 ? (int64_t)fine : 14336;                      // fine > 1: bytes per tile
+        int64_t rows = (tile + row_bytes / 2) / (row_bytes > 0 ? row_bytes : 1);    // swept 8-32 KB
         if (rows < 1) rows = 1;
         S = (N + rows - 1) / rows;
     }

@@ -738,7 +738,7 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
                                         tabs.shape[1], _ptr(mt), _stream(x)), 'cnnq_pc_midtread_params')
     y = torch.empty_like(x)
     codes = torch.empty_like(x) if want_codes else None
-    hist = torch.zeros(L.MT_HIST_BINS + 2 + 2 * C, dtype=torch.int64, device=x.device) if want_entropy else None
+    hist = torch.zeros(L.mt_hist_words(C), dtype=torch.int64, device=x.device) if want_entropy else None
     L.check(lib.cnnq_pc_midtread_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(mt), int(bool(clip)), _ptr(codes), _ptr(hist),
                                      _stream(x)), 'cnnq_pc_midtread_qdq')
     entropy = None

@@ -69,11 +69,21 @@ enum { CNNQ_QP_SCALE = 0, CNNQ_QP_ZP = 1, CNNQ_QP_QMAX = 2, CNNQ_NQP = 3 };
 /* Rows of the diagnostic table `diag[CNNQ_NDIAG][C]` written by cnnq_pc_params. */
 enum { CNNQ_DIAG_BITS = 0, CNNQ_DIAG_ALPHA = 1, CNNQ_DIAG_DELTA = 2, CNNQ_DIAG_OFFSET = 3, CNNQ_NDIAG = 4 };
 
-/* Rows of the mid-tread parameter table `mt[CNNQ_NMT][C]` and the size of its code histogram
- * (uint64 words: CNNQ_MT_HIST_BINS integer-code bins centred on 0, 2 out-of-range bins, then
- * 2*C counters for codes clamped to a non-integer c_min[c] / c_max[c]). */
-enum { CNNQ_MT_DELTA = 0, CNNQ_MT_CMIN = 1, CNNQ_MT_CMAX = 2, CNNQ_MT_OMEGA = 3, CNNQ_MT_ALPHA = 4, CNNQ_NMT = 5 };
+/* Rows of the mid-tread parameter table `mt[CNNQ_NMT][C]` (row WSTART: the first integer code of the histogram
+ * window, the same value in every column) and the size of its code histogram in uint64 words,
+ * CNNQ_MT_HIST_WORDS(C): CNNQ_MT_HIST_BINS integer-code bins centred on 0, 2 out-of-range bins, 2*C counters for
+ * codes clamped to a non-integer c_min[c] / c_max[c], then CNNQ_MT_HIST_REPLICAS copies of the
+ * CNNQ_MT_HIST_WINDOW bins of the codes WSTART .. WSTART + WINDOW - 1 (workgroups spread their updates over the
+ * copies; cnnq_midtread_entropy adds them up), and one flag word: non-zero when a count went to the
+ * CNNQ_MT_HIST_BINS + 2 global bins, i.e. a code fell outside the window. */
+enum {
+    CNNQ_MT_DELTA = 0, CNNQ_MT_CMIN = 1, CNNQ_MT_CMAX = 2, CNNQ_MT_OMEGA = 3, CNNQ_MT_ALPHA = 4, CNNQ_MT_WSTART = 5,
+    CNNQ_NMT = 6
+};
 #define CNNQ_MT_HIST_BINS 131072
+#define CNNQ_MT_HIST_WINDOW 128
+#define CNNQ_MT_HIST_REPLICAS 256
+#define CNNQ_MT_HIST_WORDS(C) (CNNQ_MT_HIST_BINS + 2 + 2 * (C) + CNNQ_MT_HIST_REPLICAS * CNNQ_MT_HIST_WINDOW + 1)
 
 /* library / build identification ("cnnq-hip <version> gfx950") */
 const char* cnnq_version(void);
@@ -324,7 +334,7 @@ int cnnq_pc_bcorr_apply(float* y, int64_t N, int64_t C, int64_t HW, const float*
  *       quantized mean; clip == 0 (weights): range = max-min (sym) or max.  One workgroup.
  *   cnnq_pc_midtread_qdq     y = clamp(round(x/Delta[c]), c_min[c], c_max[c]) * Delta[c] in one pass;
  *       `codes` (optional) fp32 codes; `hist` (optional, zeroed by the caller,
- *       CNNQ_MT_HIST_BINS + 2 + 2*C uint64 words) the code histogram.
+ *       CNNQ_MT_HIST_WORDS(C) uint64 words) the code histogram.
  *   cnnq_midtread_entropy    Shannon entropy of that histogram (equal clamp values merged). */
 int cnnq_pc_midtread_params(const float* stats, int64_t C, double target, int clip, int sym, const double* tables,
                             int ntab, float* mt, void* stream);

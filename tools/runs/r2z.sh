@@ -1,8 +1,5 @@
 #!/bin/bash
 O=gpurun_out/r2z; mkdir -p $O
-for r in 1 2; do
-timeout 300 python tools/bench_stats_layers.py > $O/sl_new$r.log 2>&1
-CNNQ_PLAN_MINWGS=1024 timeout 300 python tools/bench_stats_layers.py > $O/sl_min1k$r.log 2>&1
-CNNQ_PLAN_MINWGS=1600 timeout 300 python tools/bench_stats_layers.py > $O/sl_min16$r.log 2>&1
-paste <(cut -c1-28 $O/sl_new$r.log) <(cut -c19-24 $O/sl_min1k$r.log) <(cut -c19-24 $O/sl_min16$r.log)
-done
+timeout 600 python -m pytest tests/test_midtread_hist_gpu.py -q -x > $O/pytest1.log 2>&1; tail -n 25 $O/pytest1.log
+timeout 600 python -m pytest tests -m gpu -q -x -k "mid or tread or entropy or cfg5 or vgg or mt or fuzz" > $O/pytest.log 2>&1; tail -n 5 $O/pytest.log
+CFGS=5 timeout 300 python tools/bench_configs.py 2>&1 | tail -n 2
