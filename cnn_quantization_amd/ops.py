@@ -17,8 +17,14 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# the raw handle of the current stream of a device: torch keeps a direct accessor (the one its own compiled code
+# uses); torch.cuda.current_stream() builds a Stream object per call, ~1.5 us, three times per hot call before
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (
+    lambda index: torch.cuda.current_stream(index).cuda_stream)
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(t.device.index))
 
 
 def _dev_f32(x, what='tensor'):
@@ -39,11 +45,11 @@ _SCRATCH = {}
 _WS_BYTES = {}
 
 
-def _scratch(x, tag, nbytes):
+def _scratch(x, tag, nbytes, st=None):
     """A per-(device, stream, tag) scratch buffer (uint8, at least nbytes), grown on demand and never returned
     to callers: launches on one stream are ordered, so consecutive calls may share it.  Saves the 2-4
     torch.empty calls (8-15 us of host time) the small layers would otherwise pay per call."""
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, tag)
+    key = (x.device.index, _raw_stream(x.device.index) if st is None else st, tag)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=x.device)
@@ -209,7 +215,7 @@ _GROUP_KEEP = []
 GROUP_POOL_SIZE = 4
 
 
-def _group_workspace(x):
+def _group_workspace(x, st=None):
     """The exchange workspace of the group single launch (cnnq_pc_minmax_qdq_group): fine-grained device memory
     from cnnq_group_ws_alloc, zeroed ONCE, one per (device, stream) - launches on one stream are ordered, so they
     share it; the kernel re-arms its counters.  Allocation synchronises the device, which a stream capture does
@@ -217,7 +223,7 @@ def _group_workspace(x):
     take from it; with the pool empty under capture there is no workspace (None: the caller takes the chain).
     Returns the raw device pointer (a ctypes.c_void_p)."""
     dev = x.device.index
-    key = (dev, torch.cuda.current_stream(x.device).cuda_stream)
+    key = (dev, _raw_stream(dev) if st is None else st)
     ws = _GROUP_WS.get(key)
     if ws is not None:
         return ws
@@ -243,7 +249,7 @@ def _group_workspace(x):
 def group_status(x):
     """Status word of this stream's group workspace (synchronises): bit 0 = some wait timed out and its workgroup
     recomputed the extrema from x (results are unaffected)."""
-    ws = _GROUP_WS.get((x.device.index, torch.cuda.current_stream(x.device).cuda_stream))
+    ws = _GROUP_WS.get((x.device.index, _raw_stream(x.device.index)))
     if ws is None:
         return 0
     v = ctypes.c_uint32()
@@ -301,7 +307,7 @@ def minmax_qdq_resident(x, N, C, HW, num_bits, positive=False, out=None, want_pa
 
 
 def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
-                     want_parts=False, group=None):
+                     want_parts=False, group=None, _checked=False):
     """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials -> parameter table (one tiny
     launch) -> fused Q/DQ in descending address order; no host sync.
 
@@ -309,7 +315,8 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     parameter kernel reduces the W gathered pairs instead - exact, so the result is bit-identical to
     a single GPU holding the whole batch."""
     lib = L.load()
-    x = _dev_f32(x, 'x')
+    if not _checked:
+        x = _dev_f32(x, 'x')
     world = D.world_size(group)
     exchanging = world > 1 or D.forced_exchange()
     resident = os.environ.get('CNNQ_RESIDENT', '1') != '0'
@@ -330,11 +337,13 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
             plan = _WS_BYTES[key] = (nbytes, wants_group)
         nbytes, wants_group = plan
         y = _out_like(x, out)
-        gws = _group_workspace(x) if (resident and wants_group) else None
-        L.check(lib.cnnq_pc_minmax_qdq_auto(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)),
-                                            _ptr(_scratch(x, 'cfg2', nbytes)), gws, GROUP_WS_BYTES if gws is not None else 0,
-                                            int(resident), _stream(x)),
-                'cnnq_pc_minmax_qdq_auto')
+        st = _raw_stream(x.device.index)          # looked up once: workspace keys and the launch stream
+        gws = _group_workspace(x, st) if (resident and wants_group) else None
+        rc = lib.cnnq_pc_minmax_qdq_auto(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
+                                         _scratch(x, 'cfg2', nbytes, st).data_ptr(), gws,
+                                         GROUP_WS_BYTES if gws is not None else 0, 1 if resident else 0, st)
+        if rc:
+            L.check(rc, 'cnnq_pc_minmax_qdq_auto')
         return y
     if (exchanging and not (want_codes or want_entropy or want_parts)
             and os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') != '1'):
@@ -610,20 +619,27 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         raise L.CnnqError('bcorr combines only with the plain per-channel activation Q/DQ')
     if stats is None and clip == 'no' and not use_ba and not whole_tensor:
         res = minmax_qdq_fused(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out,
-                               want_parts=want_parts, group=None if world == 1 else group)
+                               want_parts=want_parts, group=None if world == 1 else group, _checked=True)
         if bcorr is not None:
             res = act_bias_correction_(x, res, bool(bcorr), group=None if group is False else group)
         return res
     if (stats is None and world == 1 and bcorr is None and not (want_codes or want_entropy or want_parts)):
-        # one host call for the whole chain (cnnq_pc_aciq_qdq): the six launches are the same
+        # one host call for the whole chain (cnnq_pc_aciq_qdq): five launches, one cached workspace (statistics
+        # partials, then the parameter and diagnostic tables, which nobody outside the chain reads)
         lib = L.load()
         cfg = _params_cfg(num_bits, positive, clip, use_ba, prior_is_b, target, round_mode, whole_tensor)
         y = _out_like(x, out)
-        ws = torch.empty(lib.cnnq_pc_aciq_workspace(N, C, HW, int(x.data_ptr() % 16 == 0)), dtype=torch.uint8,
-                         device=x.device)
-        qd = torch.empty((L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
-        L.check(lib.cnnq_pc_aciq_qdq(_ptr(x), _ptr(y), N, C, HW, ctypes.byref(cfg), _ptr(ws), _ptr(qd),
-                                     _ptr(qd[L.NQP:]), _stream(x)), 'cnnq_pc_aciq_qdq')
+        al = int(x.data_ptr() % 16 == 0)
+        key = ('aciq', N, C, HW, al)
+        nbytes = _WS_BYTES.get(key)
+        if nbytes is None:
+            nbytes = _WS_BYTES[key] = (lib.cnnq_pc_aciq_workspace(N, C, HW, al) + 15) // 16 * 16
+        st = _raw_stream(x.device.index)
+        base = _scratch(x, 'aciq', nbytes + (L.NQP + L.NDIAG) * C * 4, st).data_ptr()
+        qd = base + nbytes
+        rc = lib.cnnq_pc_aciq_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), base, qd, qd + L.NQP * C * 4, st)
+        if rc:
+            L.check(rc, 'cnnq_pc_aciq_qdq')
         return y
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)
