@@ -284,15 +284,26 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
                          const float* qp, const float* bits, const uint32_t* rowoff, void* stream) {
     if (!packed || !qp || !bits || !rowoff || N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31 || C > 65535) return CNNQ_ERANGE;
-    int64_t S = (4096 + C - 1) / C;           // ~4096 workgroups
-    if (S > N) S = N;
-    const dim3 grid((unsigned)(C * S)), block(TPB);
+    // k adjacent channels per workgroup: >= 512 eight-element groups per sample (16 KB contiguous) when the layer has
+    // the channels for it
+    const int64_t ngroups = (HW + 7) / 8;
+    int64_t k = (512 + ngroups - 1) / ngroups;
+    if (k > MAXCH) k = MAXCH;
+    if (k > C) k = C;
+    const int64_t ncb = (C + k - 1) / k;
+    // short workgroups in address order, like the other elementwise passes: ~14-28 KB of x each
+    int64_t rows = (14336 + k * HW * 2) / (k * HW * 4);
+    if (rows < 1) rows = 1;
+    int64_t S = (N + rows - 1) / rows;
+    if (S * ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
+    if (k * ngroups >= (int64_t)1 << 24) return CNNQ_ERANGE;   // the in-loop index arithmetic is exact in fp32 below that
+    const dim3 grid((unsigned)(ncb * S)), block(TPB);
     if (quant)
         hipLaunchKernelGGL((k_packed<true>), grid, block, 0, (hipStream_t)stream, x, y, packed, (int)N, (int)C, (int)HW,
-                           (int)S, qp, bits, rowoff);
+                           (int)S, (int)k, qp, bits, rowoff);
     else
         hipLaunchKernelGGL((k_packed<false>), grid, block, 0, (hipStream_t)stream, x, y, packed, (int)N, (int)C, (int)HW,
-                           (int)S, qp, bits, rowoff);
+                           (int)S, (int)k, qp, bits, rowoff);
     return launch_status();
 }
 

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-layer time of the bit-allocated packed storage pass (quantize_packed / dequantize_packed) on the
+ResNet-50 conv outputs at BATCH (default 512).  Development aid."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import RESNET50_CONV_OUTPUTS, laplace_activation  # noqa: E402
+from cnn_quantization_amd import _lib as L  # noqa: E402
+from cnn_quantization_amd import ops  # noqa: E402
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    best = 1e9
+    for _ in range(reps):
+        ev[0].record()
+        fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        best = min(best, ev[0].elapsed_time(ev[1]))
+    return best
+
+
+def main():
+    batch = int(os.environ.get('BATCH', '512'))
+    dev = torch.device('cuda')
+    tq = td = byts = 0.
+    for (C, hw, half, rep) in RESNET50_CONV_OUTPUTS:
+        x = laplace_activation((batch, C, hw, hw), 3, dev)
+        _, parts = ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, want_parts=True)
+        qp, bits = parts['qp'], parts['diag'][L.DIAG_BITS].contiguous()
+        if os.environ.get('FORCE_BITS'):
+            bits = torch.full_like(bits, float(os.environ['FORCE_BITS']))
+        buf = torch.empty(ops.packed_capacity(x.shape), dtype=torch.uint8, device=dev)
+        packed, rowoff = ops.quantize_packed(x, qp, bits, out=buf)
+        used = batch * int(rowoff[C])
+        a = timed(lambda: ops.quantize_packed(x, qp, bits, out=buf))
+        y = ops.dequantize_packed(packed, x.shape, qp, bits, rowoff)
+        b = timed(lambda: ops.dequantize_packed(packed, x.shape, qp, bits, rowoff))
+        gb = (x.numel() * 4 + used) / 1e9
+        print('C=%4d hw=%3d x%-2d  %.2f bits  pack %.3f ms (%.2f TB/s)  unpack %.3f ms (%.2f TB/s)' % (
+            C, hw, rep, used * 8 / x.numel(), a, gb / a, b, gb / b), flush=True)
+        tq += a * rep
+        td += b * rep
+        byts += gb * rep
+        del x, y, buf, packed
+    print('total pack %.3f ms (%.2f TB/s)  unpack %.3f ms (%.2f TB/s)' % (tq, byts / tq, td, byts / td))
+
+
+if __name__ == '__main__':
+    main()
