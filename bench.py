@@ -283,11 +283,17 @@ def other_configs(ops, device, batch):
     torch.cuda.empty_cache()
     bufs = [torch.empty(ops.packed_capacity(x.shape), dtype=torch.uint8, device=device) for x, _, _ in pk]
     t = timed_best(lambda: [ops.quantize_packed(x, qp, bits, out=b) for (x, qp, bits), b in zip(pk, bufs)])
-    del bufs
     bpe = 4 + nbytes / elems
+    # ... and the way back: stored codes -> fp32 (what the next layer's kernel would fuse into its load)
+    offs = [ops.quantize_packed(x, qp, bits, out=b)[1] for (x, qp, bits), b in zip(pk, bufs)]
+    t_load = timed_best(lambda: [ops.dequantize_packed(b, x.shape, qp, bits, ro)
+                                 for (x, qp, bits), b, ro in zip(pk, bufs, offs)])
+    del bufs, offs
     out['config3_packed_storage'] = obj(elems, t, bpe, 'ResNet-50 b%d, the quantize+pack pass of config 3 with the bit-allocated '
                                         'codes as the stored format: %.3f bytes per element written (fp32 dequantized: 4), into '
                                         'preallocated buffers (no host read)' % (batch, nbytes / elems))
+    out['config3_packed_load'] = obj(elems, t_load, bpe, 'ResNet-50 b%d, the inverse pass: bit-allocated stored codes -> '
+                                     'dequantized fp32 (%.3f bytes per element read, 4 written)' % (batch, nbytes / elems))
     del pk
     t = timed_best(lambda: [ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True,
                                          need_relu=True) for x, _ in layers])

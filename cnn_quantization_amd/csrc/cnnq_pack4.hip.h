@@ -161,6 +161,13 @@ __device__ __forceinline__ void slot_split(int q, int nslots, float inv_ns, int 
     sl = t;
 }
 
+struct PkUnit {            // one wave-chunk: 128 slots of one sample
+    int n, base;           // sample, first slot of the chunk within the block's slots of that sample
+    int cha, chb, cnta, cntb;
+    unsigned offa, offb;   // element offsets of the lane's two slots from the block's first element of the sample
+    bool live;
+};
+
 template <bool QUANT>
 __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, float* __restrict__ y,
                                                 uint8_t* __restrict__ packed, int N, int C, int HW, int S, int k,
@@ -174,6 +181,51 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
     const int s = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - s * ncb;
     const int c0 = cb * k, nch = min(k, C - c0);
     const int n0 = (int)(((int64_t)s * N) / S), n1 = (int)(((int64_t)(s + 1) * N) / S);
+    const int ngroups = (HW + 7) / 8;
+    const int nslots = 2 * ngroups;              // slots per row (the last one may be empty)
+    const int W = nch * nslots;                  // slots of the block per sample (even)
+    const float inv_ns = 1.f / (float)nslots;
+    const bool vec4 = (HW % 4 == 0) && (((uintptr_t)(QUANT ? (const void*)x : (const void*)y) & 15) == 0);
+    const int src = (2 * lane) & 63;             // lane holding slot 2 * lane of the wave's chunk (view A or B)
+    // A wave's unit is a chunk of 128 slots of one sample; the workgroup's chunks (samples x chunks per sample) are
+    // dealt to its waves round-robin.
+    const int cps = (W + 127) / 128;             // chunks per sample
+    const int nchunks = (n1 - n0) * cps;
+    int it = wv, itn = 0, itc = wv;              // chunk index, its sample offset and chunk within the sample
+    while (itc >= cps) { itc -= cps; ++itn; }
+    const int dn = (TPB / 64) / cps, dc = (TPB / 64) % cps;
+    auto locate = [&]() {                        // the unit at the cursor; advances the cursor
+        PkUnit u;
+        u.live = it < nchunks;
+        u.n = n0 + (u.live ? itn : 0);
+        u.base = (u.live ? itc : 0) * 128;
+        const int Wl = u.live ? W : 0;           // a dead unit has no slots
+        const int qa = u.base + lane, qb = qa + 64;
+        int sla, slb;
+        slot_split(min(qa, W - 1), nslots, inv_ns, nch, u.cha, sla);
+        slot_split(min(qb, W - 1), nslots, inv_ns, nch, u.chb, slb);
+        u.cnta = qa < Wl ? max(0, min(4, HW - sla * 4)) : 0;
+        u.cntb = qb < Wl ? max(0, min(4, HW - slb * 4)) : 0;
+        u.offa = (unsigned)(u.cha * HW + sla * 4);
+        u.offb = (unsigned)(u.chb * HW + slb * 4);
+        it += TPB / 64;
+        itn += dn;
+        itc += dc;
+        if (itc >= cps) { itc -= cps; ++itn; }
+        return u;
+    };
+    auto loadx = [&](const PkUnit& u, float (&va)[4], float (&vb)[4]) {
+        const float* xs = x + ((size_t)u.n * C + c0) * (size_t)HW;     // the block's first element of the sample
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { va[e] = 0.f; vb[e] = 0.f; }
+        if (u.cnta) { if (vec4) ldv_nt<4>(xs + u.offa, va); else for (int e = 0; e < u.cnta; ++e) va[e] = xs[u.offa + e]; }
+        if (u.cntb) { if (vec4) ldv_nt<4>(xs + u.offb, vb); else for (int e = 0; e < u.cntb; ++e) vb[e] = xs[u.offb + e]; }
+    };
+    // x does not depend on the parameter tables: the first unit's loads are in flight while the tables arrive, every
+    // further unit's while the previous one is being encoded (one unit at a time, no overlap: 4.0 TB/s of reads)
+    PkUnit cur = locate();
+    float va[4], vb[4];
+    if constexpr (QUANT) loadx(cur, va, vb);
     for (int i = tid; i < nch; i += TPB) {
         sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * C + c0 + i];
         sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * C + c0 + i];
@@ -183,127 +235,81 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
     }
     __syncthreads();
     const uint32_t plane = rowoff[C];
-    const int ngroups = (HW + 7) / 8;
-    const int nslots = 2 * ngroups;              // slots per row (the last one may be empty)
-    const int W = nch * nslots;                  // slots of the block per sample (even)
-    const float inv_ns = 1.f / (float)nslots;
-    const bool vec4 = (HW % 4 == 0) && (((uintptr_t)(QUANT ? (const void*)x : (const void*)y) & 15) == 0);
-    const int src = (2 * lane) & 63;             // lane holding slot 2 * lane of the wave's chunk (view A or B)
-    // A wave's unit is a chunk of 128 slots of one sample; the workgroup's chunks (samples x chunks per sample) are
-    // dealt to its waves round-robin and taken U at a time: all 2 * U loads of a lane are issued before the first
-    // code is computed (a tile of ~14-28 KB per workgroup is in flight as a whole; with one chunk at a time the pass
-    // was latency-bound at 4.1 TB/s).
-    constexpr int U = 1;   // U = 4 / 2 (more loads in flight, 100 VGPRs) ran the quantize pass at 2.7 instead of 4.3 TB/s
-    const int cps = (W + 127) / 128;             // chunks per sample
-    const int nchunks = (n1 - n0) * cps;
-    int it = wv, itn = 0, itc = wv;              // chunk index, its sample offset and chunk within the sample
-    while (itc >= cps) { itc -= cps; ++itn; }
-    const int dn = (TPB / 64) / cps, dc = (TPB / 64) % cps;
-    while (it < nchunks) {
-        int cha[U], chb[U], chg[U], cnta[U], cntb[U], gi[U];
-        unsigned offa[U], offb[U];
-        uint32_t nb[U];
-        size_t sbase[U];
-        uint8_t* gp[U];
-        float va[U][4], vb[U][4];
+    while (cur.live) {
+        PkUnit nxt = locate();
+        float na[4], nbv[4];
+        if constexpr (QUANT) loadx(nxt, na, nbv);
+        // the lane's group: slots 2 * lane, 2 * lane + 1 of the chunk
+        const int qg = cur.base + 2 * lane;
+        int chg, slg;
+        slot_split(min(qg, W - 2), nslots, inv_ns, nch, chg, slg);
+        const int b = sh_b[chg];
+        const int gi = slg >> 1;
+        const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
+        // bytes of this group: b whole bytes, or - last group of the row - everything up to the padded row end
+        const uint32_t boff = (uint32_t)gi * (uint32_t)b;
+        const uint32_t nb = qg < W ? ((gi == ngroups - 1) ? rowbytes - boff : (uint32_t)b) : 0u;
+        uint8_t* g = packed + (size_t)cur.n * plane + sh_off[chg] + boff;
+        if constexpr (QUANT) {
+            // 4 codes of b' <= 8 bits each (b' of the slot's own channel): one 32-bit word, full-rate shift-or
+            auto half_of = [&](const float (&v)[4], int cnt, int ch) -> unsigned {
+                const int bb = sh_b[ch];
+                const float sc = sh_sc[ch], zp = sh_zp[ch], qm = sh_qm[ch];
+                unsigned cds[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool live = it < nchunks;
-            const int n = n0 + (live ? itn : 0), base = (live ? itc : 0) * 128;
-            const int Wl = live ? W : 0;          // a dead unit has no slots
-            const int qa = base + lane, qb = qa + 64, qg = base + 2 * lane;
-            int sla, slb, slg;
-            slot_split(min(qa, W - 1), nslots, inv_ns, nch, cha[u], sla);
-            slot_split(min(qb, W - 1), nslots, inv_ns, nch, chb[u], slb);
-            slot_split(min(qg, W - 2), nslots, inv_ns, nch, chg[u], slg);
-            cnta[u] = qa < Wl ? max(0, min(4, HW - sla * 4)) : 0;
-            cntb[u] = qb < Wl ? max(0, min(4, HW - slb * 4)) : 0;
-            offa[u] = (unsigned)(cha[u] * HW + sla * 4);
-            offb[u] = (unsigned)(chb[u] * HW + slb * 4);
-            sbase[u] = ((size_t)n * C + c0) * (size_t)HW;          // the block's first element of this sample
-            const int b = sh_b[chg[u]];
-            gi[u] = slg >> 1;
-            const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
-            // bytes of this group: b whole bytes, or - last group of the row - everything up to the padded row end
-            const uint32_t boff = (uint32_t)gi[u] * (uint32_t)b;
-            nb[u] = qg < Wl ? ((gi[u] == ngroups - 1) ? rowbytes - boff : (uint32_t)b) : 0u;
-            gp[u] = packed + (size_t)n * plane + sh_off[chg[u]] + boff;
-            if constexpr (QUANT) {
-                const float* xs = x + sbase[u];
+                for (int e = 0; e < 4; ++e) {
+                    float cd;
+                    (void)qdq1(v[e], sc, zp, qm, cd);
+                    cds[e] = (e < cnt) ? (unsigned)cd : 0u;
+                }
+                return cds[0] | (cds[1] << bb) | (cds[2] << (2 * bb)) | (cds[3] << (3 * bb));
+            };
+            const unsigned ha = half_of(va, cur.cnta, cur.cha), hb = half_of(vb, cur.cntb, cur.chb);
+            // group `lane` is in view A for lane < 32, else in view B
+            const unsigned a0 = (unsigned)__shfl((int)ha, src, 64), b0 = (unsigned)__shfl((int)hb, src, 64);
+            const unsigned a1 = (unsigned)__shfl((int)ha, src + 1, 64), b1 = (unsigned)__shfl((int)hb, src + 1, 64);
+            const unsigned lo = lane < 32 ? a0 : b0, hi = lane < 32 ? a1 : b1;
+            const unsigned long long ww = (unsigned long long)lo | ((unsigned long long)hi << (4 * b));
+            // widest naturally aligned stores (the group starts at gi * b): 8 / 4 / 2-byte pieces where b allows
+            if (nb == 8u && b == 8) *reinterpret_cast<unsigned long long*>(g) = ww;
+            else if (nb == 4u && b == 4) *reinterpret_cast<uint32_t*>(g) = (uint32_t)ww;
+            else if ((b & 1) == 0 && (nb & 1u) == 0u)
+                for (uint32_t kk = 0; kk < nb; kk += 2) *reinterpret_cast<uint16_t*>(g + kk) = (uint16_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
+            else
+                for (uint32_t kk = 0; kk < nb; ++kk) g[kk] = (uint8_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { va[u][e] = 0.f; vb[u][e] = 0.f; }
-                if (cnta[u]) { if (vec4) ldv_nt<4>(xs + offa[u], va[u]); else for (int e = 0; e < cnta[u]; ++e) va[u][e] = xs[offa[u] + e]; }
-                if (cntb[u]) { if (vec4) ldv_nt<4>(xs + offb[u], vb[u]); else for (int e = 0; e < cntb[u]; ++e) vb[u][e] = xs[offb[u] + e]; }
-            }
-            it += TPB / 64;
-            itn += dn;
-            itc += dc;
-            if (itc >= cps) { itc -= cps; ++itn; }
+            for (int e = 0; e < 4; ++e) { va[e] = na[e]; vb[e] = nbv[e]; }
+        } else {
+            float* ys = y + ((size_t)cur.n * C + c0) * (size_t)HW;
+            unsigned long long w = 0;
+            const uint32_t nr = nb < 8 ? nb : 8;
+            if (nr == 8u && b == 8) w = *reinterpret_cast<const unsigned long long*>(g);
+            else if (nr == 4u && b == 4) w = *reinterpret_cast<const uint32_t*>(g);
+            else if ((b & 1) == 0)
+                for (uint32_t kk = 0; kk < nr; kk += 2) w |= (unsigned long long)*reinterpret_cast<const uint16_t*>(g + kk) << (8 * kk);
+            else
+                for (uint32_t kk = 0; kk < nr; ++kk) w |= (unsigned long long)g[kk] << (8 * kk);
+            const unsigned wl = (unsigned)w, wh = (unsigned)(w >> (4 * b));   // codes 0-3 (4b <= 32 bits), 4-7
+            // slot L of view A is half (L & 1) of group L >> 1; slot L of view B of group 32 + (L >> 1)
+            const int ga = lane >> 1, gb = 32 + (lane >> 1);
+            const unsigned al = (unsigned)__shfl((int)wl, ga, 64), ah = (unsigned)__shfl((int)wh, ga, 64);
+            const unsigned bl = (unsigned)__shfl((int)wl, gb, 64), bh = (unsigned)__shfl((int)wh, gb, 64);
+            const unsigned ma = (lane & 1) ? ah : al, mb = (lane & 1) ? bh : bl;
+            auto emit = [&](unsigned mine, unsigned off, int cnt, int ch) {
+                if (!cnt) return;
+                const int bb = sh_b[ch];
+                const float sc = sh_sc[ch], zp = sh_zp[ch];
+                const unsigned mask = (1u << bb) - 1u;                        // bb <= 8
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ((float)((mine >> (e * bb)) & mask) - zp) * sc;   // iq.py:591-592
+                if (vec4) stv_nt<4>(ys + off, o);
+                else for (int e = 0; e < cnt; ++e) ys[off + e] = o[e];
+            };
+            emit(ma, cur.offa, cur.cnta, cur.cha);
+            emit(mb, cur.offb, cur.cntb, cur.chb);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = sh_b[chg[u]];
-            if constexpr (QUANT) {
-                // 4 codes of b' <= 8 bits each (b' of the slot's own channel): one 32-bit word, full-rate shift-or
-                auto half_of = [&](const float (&v)[4], int cnt, int ch) -> unsigned {
-                    const int bb = sh_b[ch];
-                    const float sc = sh_sc[ch], zp = sh_zp[ch], qm = sh_qm[ch];
-                    unsigned cds[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float cd;
-                        (void)qdq1(v[e], sc, zp, qm, cd);
-                        cds[e] = (e < cnt) ? (unsigned)cd : 0u;
-                    }
-                    return cds[0] | (cds[1] << bb) | (cds[2] << (2 * bb)) | (cds[3] << (3 * bb));
-                };
-                const unsigned ha = half_of(va[u], cnta[u], cha[u]), hb = half_of(vb[u], cntb[u], chb[u]);
-                // group `lane` = slots 2 * lane, 2 * lane + 1 of the chunk: in view A for lane < 32, else in view B
-                const unsigned a0 = (unsigned)__shfl((int)ha, src, 64), b0 = (unsigned)__shfl((int)hb, src, 64);
-                const unsigned a1 = (unsigned)__shfl((int)ha, src + 1, 64), b1 = (unsigned)__shfl((int)hb, src + 1, 64);
-                const unsigned lo = lane < 32 ? a0 : b0, hi = lane < 32 ? a1 : b1;
-                const unsigned long long ww = (unsigned long long)lo | ((unsigned long long)hi << (4 * b));
-                // widest naturally aligned stores (the group starts at gi * b): 8 / 4 / 2-byte pieces where b allows
-                uint8_t* g = gp[u];
-                const uint32_t nbu = nb[u];
-                if (nbu == 8u && b == 8) *reinterpret_cast<unsigned long long*>(g) = ww;
-                else if (nbu == 4u && b == 4) *reinterpret_cast<uint32_t*>(g) = (uint32_t)ww;
-                else if ((b & 1) == 0 && (nbu & 1u) == 0u)
-                    for (uint32_t kk = 0; kk < nbu; kk += 2) *reinterpret_cast<uint16_t*>(g + kk) = (uint16_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
-                else
-                    for (uint32_t kk = 0; kk < nbu; ++kk) g[kk] = (uint8_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
-            } else {
-                float* ys = y + sbase[u];
-                const uint8_t* g = gp[u];
-                unsigned long long w = 0;
-                const uint32_t nr = nb[u] < 8 ? nb[u] : 8;
-                if (nr == 8u && b == 8) w = *reinterpret_cast<const unsigned long long*>(g);
-                else if (nr == 4u && b == 4) w = *reinterpret_cast<const uint32_t*>(g);
-                else if ((b & 1) == 0)
-                    for (uint32_t kk = 0; kk < nr; kk += 2) w |= (unsigned long long)*reinterpret_cast<const uint16_t*>(g + kk) << (8 * kk);
-                else
-                    for (uint32_t kk = 0; kk < nr; ++kk) w |= (unsigned long long)g[kk] << (8 * kk);
-                const unsigned wl = (unsigned)w, wh = (unsigned)(w >> (4 * b));   // codes 0-3 (4b <= 32 bits), 4-7
-                // slot L of view A is half (L & 1) of group L >> 1; slot L of view B of group 32 + (L >> 1)
-                const int ga = lane >> 1, gb = 32 + (lane >> 1);
-                const unsigned al = (unsigned)__shfl((int)wl, ga, 64), ah = (unsigned)__shfl((int)wh, ga, 64);
-                const unsigned bl = (unsigned)__shfl((int)wl, gb, 64), bh = (unsigned)__shfl((int)wh, gb, 64);
-                const unsigned ma = (lane & 1) ? ah : al, mb = (lane & 1) ? bh : bl;
-                auto emit = [&](unsigned mine, unsigned off, int cnt, int ch) {
-                    if (!cnt) return;
-                    const int bb = sh_b[ch];
-                    const float sc = sh_sc[ch], zp = sh_zp[ch];
-                    const unsigned mask = (1u << bb) - 1u;                        // bb <= 8
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = ((float)((mine >> (e * bb)) & mask) - zp) * sc;   // iq.py:591-592
-                    if (vec4) stv_nt<4>(ys + off, o);
-                    else for (int e = 0; e < cnt; ++e) ys[off + e] = o[e];
-                };
-                emit(ma, offa[u], cnta[u], cha[u]);
-                emit(mb, offb[u], cntb[u], chb[u]);
-            }
-        }
+        cur = nxt;
     }
 }
 
