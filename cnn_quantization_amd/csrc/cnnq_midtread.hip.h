@@ -276,12 +276,20 @@ __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* _
     // the window bins live in MT_GR replica tables: fold them (bin i of the window is code wstart + i)
     const unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C;
     const int wbase = (int)mt[(size_t)CNNQ_MT_WSTART * C] + MT_NB / 2;
-    for (int i = tid; i < MT_W; i += PTPB) {
+    {   // all PTPB threads: thread (g, i) adds every (PTPB / MT_W)-th replica of bin i, then MT_W threads add the partials
+        __shared__ unsigned long long lpart[PTPB / MT_W][MT_W];
+        const int i = tid % MT_W, g = tid / MT_W;
         unsigned long long t = 0;
-        for (int r = 0; r < MT_GR; ++r) t += rep[(size_t)r * MT_W + i];
-        lrep[i] = t;
+        for (int r = g; r < MT_GR; r += PTPB / MT_W) t += rep[(size_t)r * MT_W + i];
+        lpart[g][i] = t;
+        __syncthreads();
+        if (tid < MT_W) {
+            unsigned long long a = 0;
+            for (int q = 0; q < PTPB / MT_W; ++q) a += lpart[q][tid];
+            lrep[tid] = a;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // 131074 bins through one workgroup: 16 independent loads in flight per thread (a dependent
     // load per iteration made this kernel 150 us of pure latency); each thread still adds its bins in
     // ascending order, so the sum is unchanged
