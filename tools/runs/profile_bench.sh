@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2 profiles: rocprofv3 kernel trace + stats and the two PMC passes, of the driver's bench command (b512)
-# and of the batch-64 shard; summaries go to gpurun_out/r2prof/ (copied into profiles/ by hand)
-O=$PWD/gpurun_out/r2prof; mkdir -p $O
+# and of the batch-64 shard; summaries go to gpurun_out/profile_bench/ (copied into profiles/ by hand)
+O=$PWD/gpurun_out/profile_bench; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for B in 512 64; do

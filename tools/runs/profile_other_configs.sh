@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel-level breakdown of configs 3 / 4 / 5 (tools/bench_configs.py) under rocprofv3
-O=$PWD/gpurun_out/r2y; mkdir -p $O
+O=$PWD/gpurun_out/profile_other_configs; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in 3 4 5; do
