@@ -298,12 +298,14 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
     if (S * ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
     if (k * ngroups >= (int64_t)1 << 24) return CNNQ_ERANGE;   // the in-loop index arithmetic is exact in fp32 below that
     const dim3 grid((unsigned)(ncb * S)), block(TPB);
-    if (quant)
-        hipLaunchKernelGGL((k_packed<true>), grid, block, 0, (hipStream_t)stream, x, y, packed, (int)N, (int)C, (int)HW,
-                           (int)S, (int)k, qp, bits, rowoff);
-    else
-        hipLaunchKernelGGL((k_packed<false>), grid, block, 0, (hipStream_t)stream, x, y, packed, (int)N, (int)C, (int)HW,
-                           (int)S, (int)k, qp, bits, rowoff);
+    static const int64_t rows_min = env_int("CNNQ_PACK_ROWS_MIN", 256);   // development knob (slots per row)
+    const bool rows_form = 2 * ngroups >= rows_min;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PK(Q, R) \
+    hipLaunchKernelGGL((k_packed<Q, R>), grid, block, 0, st, x, y, packed, (int)N, (int)C, (int)HW, (int)S, (int)k, qp, bits, rowoff)
+    if (quant) { if (rows_form) LAUNCH_PK(true, true); else LAUNCH_PK(true, false); }
+    else { if (rows_form) LAUNCH_PK(false, true); else LAUNCH_PK(false, false); }
+#undef LAUNCH_PK
     return launch_status();
 }
 

@@ -168,7 +168,11 @@ struct PkUnit {            // one wave-chunk: 128 slots of one sample
     bool live;
 };
 
-template <bool QUANT>
+// ROWS: chunks are aligned to rows (a row = ceil(nslots / 128) chunks, the last one partly empty): every lane of a wave
+// then works on the SAME channel - one set of parameters per chunk instead of three per lane, no per-slot index split.
+// Pays for long rows (>= 256 slots, i.e. H*W >= 1024), where the per-slot bookkeeping of the flat form was half of the
+// instructions of an ALU-bound kernel.
+template <bool QUANT, bool ROWS>
 __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, float* __restrict__ y,
                                                 uint8_t* __restrict__ packed, int N, int C, int HW, int S, int k,
                                                 const float* __restrict__ qp, const float* __restrict__ bits,
@@ -189,7 +193,9 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
     const int src = (2 * lane) & 63;             // lane holding slot 2 * lane of the wave's chunk (view A or B)
     // A wave's unit is a chunk of 128 slots of one sample; the workgroup's chunks (samples x chunks per sample) are
     // dealt to its waves round-robin.
-    const int cps = (W + 127) / 128;             // chunks per sample
+    const int cpr = (nslots + 127) / 128;        // ROWS: chunks per row
+    const float inv_cpr = 1.f / (float)cpr;
+    const int cps = ROWS ? nch * cpr : (W + 127) / 128;   // chunks per sample
     const int nchunks = (n1 - n0) * cps;
     int it = wv, itn = 0, itc = wv;              // chunk index, its sample offset and chunk within the sample
     while (itc >= cps) { itc -= cps; ++itn; }
@@ -198,16 +204,31 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
         PkUnit u;
         u.live = it < nchunks;
         u.n = n0 + (u.live ? itn : 0);
-        u.base = (u.live ? itc : 0) * 128;
-        const int Wl = u.live ? W : 0;           // a dead unit has no slots
-        const int qa = u.base + lane, qb = qa + 64;
-        int sla, slb;
-        slot_split(min(qa, W - 1), nslots, inv_ns, nch, u.cha, sla);
-        slot_split(min(qb, W - 1), nslots, inv_ns, nch, u.chb, slb);
-        u.cnta = qa < Wl ? max(0, min(4, HW - sla * 4)) : 0;
-        u.cntb = qb < Wl ? max(0, min(4, HW - slb * 4)) : 0;
-        u.offa = (unsigned)(u.cha * HW + sla * 4);
-        u.offb = (unsigned)(u.chb * HW + slb * 4);
+        if constexpr (ROWS) {
+            int ch, j;                           // wave-uniform: the chunk's channel and its index within the row
+            slot_split(u.live ? itc : 0, cpr, inv_cpr, nch, ch, j);
+            ch = __builtin_amdgcn_readfirstlane(ch);
+            j = __builtin_amdgcn_readfirstlane(j);
+            u.base = j * 128;                    // first slot of the chunk within its row
+            u.cha = u.chb = ch;
+            const int nl = u.live ? nslots : 0;
+            const int sla = u.base + lane, slb = sla + 64;
+            u.cnta = sla < nl ? max(0, min(4, HW - sla * 4)) : 0;
+            u.cntb = slb < nl ? max(0, min(4, HW - slb * 4)) : 0;
+            u.offa = (unsigned)(ch * HW + sla * 4);
+            u.offb = u.offa + 256u;
+        } else {
+            u.base = (u.live ? itc : 0) * 128;
+            const int Wl = u.live ? W : 0;       // a dead unit has no slots
+            const int qa = u.base + lane, qb = qa + 64;
+            int sla, slb;
+            slot_split(min(qa, W - 1), nslots, inv_ns, nch, u.cha, sla);
+            slot_split(min(qb, W - 1), nslots, inv_ns, nch, u.chb, slb);
+            u.cnta = qa < Wl ? max(0, min(4, HW - sla * 4)) : 0;
+            u.cntb = qb < Wl ? max(0, min(4, HW - slb * 4)) : 0;
+            u.offa = (unsigned)(u.cha * HW + sla * 4);
+            u.offb = (unsigned)(u.chb * HW + slb * 4);
+        }
         it += TPB / 64;
         itn += dn;
         itc += dc;
@@ -242,13 +263,21 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
         // the lane's group: slots 2 * lane, 2 * lane + 1 of the chunk
         const int qg = cur.base + 2 * lane;
         int chg, slg;
-        slot_split(min(qg, W - 2), nslots, inv_ns, nch, chg, slg);
+        bool ghere;
+        if constexpr (ROWS) {
+            chg = cur.cha;
+            slg = qg;
+            ghere = qg < nslots;
+        } else {
+            slot_split(min(qg, W - 2), nslots, inv_ns, nch, chg, slg);
+            ghere = qg < W;
+        }
         const int b = sh_b[chg];
         const int gi = slg >> 1;
         const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
         // bytes of this group: b whole bytes, or - last group of the row - everything up to the padded row end
         const uint32_t boff = (uint32_t)gi * (uint32_t)b;
-        const uint32_t nb = qg < W ? ((gi == ngroups - 1) ? rowbytes - boff : (uint32_t)b) : 0u;
+        const uint32_t nb = ghere ? ((gi == ngroups - 1) ? rowbytes - boff : (uint32_t)b) : 0u;
         uint8_t* g = packed + (size_t)cur.n * plane + sh_off[chg] + boff;
         if constexpr (QUANT) {
             // 4 codes of b' <= 8 bits each (b' of the slot's own channel): one 32-bit word, full-rate shift-or
