@@ -68,6 +68,7 @@ SIGNATURES = {
     'cnnq_pc_group_describe': (_I, [_L, _L, _L, ctypes.POINTER(ctypes.c_int32)]),
     'cnnq_pc_minmax_qdq_group': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, ctypes.c_uint32, _P]),
     'cnnq_pc_minmax_local': (_I, [_P, _L, _L, _L, _P, _P, _P]),
+    'cnnq_pc_minmax_local_auto': (_I, [_P, _L, _L, _L, _P, _P, ctypes.c_size_t, _P, _P]),
     'cnnq_pc_gathered_qdq': (_I, [_P, _P, _L, _L, _L, _P, _I, _I, _I, _P, _P]),
     'cnnq_pc_minmax_qdq_workspace': (ctypes.c_size_t, [_L, _L, _L]),
     'cnnq_pc_minmax_qdq_auto': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, ctypes.c_size_t, _I, _P]),

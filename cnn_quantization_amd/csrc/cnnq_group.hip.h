@@ -255,6 +255,22 @@ __device__ __forceinline__ void grp_depart(unsigned* top, int member, int Gs) {
     grp_leave((nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top, (nsub > 1) ? m_i + 1u : m_i);
 }
 
+// Arrival WITHOUT waiting: true in exactly one member per launch - the last one to arrive, which by then may read what
+// every other member published before its own arrival - and nobody waits, so there is nothing to time out.  The last
+// arriver of a line re-arms it (all of that line's arrivals are in).
+__device__ __forceinline__ bool grp_arrive_last(unsigned* top, int member, int Gs) {
+    const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    const int si = member / GRP_SUB;
+    const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
+    unsigned* line = (nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top;
+    if (__hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != m_i) return false;
+    __hip_atomic_store(line, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nsub == 1) return true;
+    if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nsub - 1u) return false;
+    __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // ws: [0] status word, [256 ..) 16384 arrival/departure counters, one per group and per 256-byte line (a fixed
 // region, so that no geometry's pairs ever land on another geometry's counters), then one 128-byte-aligned block of 8-byte
 // {min, max} pairs per group: [member] (mode 1) or [member][k] (mode 2)
@@ -386,6 +402,77 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
     //      counter line re-arms it for the next launch
     if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
+}
+
+// The rank-local extrema out[2][C] of a batch shard in ONE launch (the multi-GPU form of config 2 exchanges them
+// between its statistics pass and its Q/DQ pass): the tiling and the pair blocks of k_mmq_group, but nobody waits - the
+// LAST workgroup of a channel group to arrive folds the group's pairs and writes the channels' record.  Replaces
+// k_minmax + k_minmax_reduce (one launch boundary less in front of every exchange).  NTL: non-temporal loads (x is
+// too large for the Q/DQ pass to find it in the Infinity Cache anyway).
+template <int A, int K, bool NTL>
+__global__ void __launch_bounds__(TPB) k_minmax_group(const float* __restrict__ x, const Geo g, const int Gs, const GWs ws,
+                                                      float* __restrict__ out) {
+    __shared__ float l_mn[TPB * A], l_mx[TPB * A];
+    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH];
+    __shared__ int sh_last;
+    const RBlk rb = rblk_of(g, Gs);
+    const Blk& b = rb.b;
+    const int tid = threadIdx.x;
+    const int col = b.col0 + tid;
+    const bool ok = col < b.col1;
+    const int colc = ok ? col : b.col0;
+    const int nrows = b.n1 - b.n0;
+    const size_t base = (size_t)b.n0 * (size_t)g.P + (size_t)colc * 4;
+    float v[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int r = j < nrows ? j : nrows - 1;
+        ldv_sel<4, NTL>(x + base + (size_t)r * (size_t)g.P, v[j]);
+    }
+    float mn[A], mx[A];
+    bool nan = false;
+#pragma unroll
+    for (int a = 0; a < A; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+#pragma unroll
+    for (int j = 0; j < K; ++j) lane_acc<A>(v[j], mn, mx, nan);
+    if (A == 1 && nan) { mn[0] = NAN; mx[0] = NAN; }
+    wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
+    const int nch = b.c1 - b.c0;
+    unsigned long long* blk = ws.part + (size_t)rb.group * ws.gstride;
+    const int kk = (g.mode == 1) ? 1 : g.k;
+    for (int ch = tid; ch < nch; ch += TPB)
+        __hip_atomic_store(blk + (size_t)rb.member * kk + ch, pack_pair(sh_mn[ch], sh_mx[ch]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
+    __syncthreads();
+    if (tid == 0) sh_last = grp_arrive_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
+    __syncthreads();
+    if (!sh_last) return;
+    if (g.mode == 1) {
+        float tn = INFINITY, tx = -INFINITY;
+        for (int m = tid; m < Gs; m += TPB) {
+            float a, c;
+            unpack_pair(blk[m], a, c);
+            tn = pmin(tn, a);
+            tx = pmax(tx, c);
+        }
+        const float one_n[1] = {tn}, one_x[1] = {tx};
+        wg_channel_minmax<1>(g, b, true, one_n, one_x, l_mn, l_mx, sh_mn, sh_mx);
+        if (tid == 0) { out[b.c0] = sh_mn[0]; out[g.C + b.c0] = sh_mx[0]; }
+    } else {
+        for (int ch = tid; ch < nch; ch += TPB) {
+            float tn = INFINITY, tx = -INFINITY;
+#pragma unroll 8
+            for (int s = 0; s < Gs; ++s) {
+                float a, c;
+                unpack_pair(blk[(size_t)s * kk + ch], a, c);
+                tn = pmin(tn, a);
+                tx = pmax(tx, c);
+            }
+            out[b.c0 + ch] = tn;
+            out[g.C + b.c0 + ch] = tx;
+        }
+    }
 }
 
 }  // namespace

@@ -458,12 +458,33 @@ int cnnq_pc_minmax_local(const float* x, int64_t N, int64_t C, int64_t HW, float
     return cnnq_pc_minmax_reduce(pmm, G, C, local, stream);
 }
 
+// ... in ONE launch when the geometry has a group plan and the caller brought the exchange workspace (k_minmax_group:
+// the last workgroup of a channel group to arrive folds the group's pairs), else the two launches above
+int cnnq_pc_minmax_local_auto(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* gws, size_t gws_bytes,
+                              float* local, void* stream) {
+    if (!x || !local) return CNNQ_EINVAL;
+    // tensors beyond the Infinity Cache keep the streaming k_minmax (6.5-6.9 TB/s against ~5.5 for 128 KB register
+    // tiles; one launch boundary is nothing next to their 60+ us)
+    static const int64_t max_bytes = env_int("CNNQ_LOCAL_GROUP_MAX_MB", 384) * ((int64_t)1 << 20);   // development knob
+    if (gws && !((uintptr_t)gws & 127) && N * C * HW * 4 <= max_bytes) {
+        GPlan p;
+        if (plan_group(N, C, HW, al16(x), &p) == 0 && p.ws_bytes <= gws_bytes)
+            return launch_minmax_group(x, p, gws, local, false, (hipStream_t)stream);
+    }
+    return cnnq_pc_minmax_local(x, N, C, HW, pmm, local, stream);
+}
+
+// one launch: every workgroup of the fused Q/DQ derives the parameters of its channels from the W gathered records
 int cnnq_pc_gathered_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* gathered, int W,
                          int num_bits, int positive, float* qp, void* stream) {
-    if (!x || !y || !gathered || !qp || W <= 0) return CNNQ_EINVAL;
-    const int rc = cnnq_pc_minmax_params(gathered, W, C, num_bits, positive, qp, stream);
+    if (!x || !y || !gathered || W <= 0 || num_bits < 1 || num_bits > 32) return CNNQ_EINVAL;
+    Variant v;
+    Geo g;
+    // the local statistics pass walked x ascending: descend, so that what it touched last is re-read first
+    const int rc = plan(N, C, HW, al16(x) && al16(y), /*rev=*/1, &v, &g, /*fine=*/1);
     if (rc) return rc;
-    return cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, /*reverse=*/1, stream);
+    const GathArgs ga{W, num_bits, positive ? 1 : 0, qp};
+    return launch_qdq_gathered(x, y, g, v, gathered, ga, (hipStream_t)stream);
 }
 
 // Config 2 behind ONE call: the resident single launch when the shape has one, else the group-exchange single

@@ -182,10 +182,34 @@ __global__ void __launch_bounds__(TPB) k_minmax_params(const float* __restrict__
 // The fused Q/DQ.  Launched with MANY short workgroups in address order (about 14 KB of x each,
 // see make_geo `fine`): measured on MI355X, read+write streaming runs at 6.1-6.7 TB/s this way
 // against 5.4 TB/s when a workgroup walks 30+ samples (tools/ubench_copy.py, tools/split_probe.py).
-template <int VEC, int A, int J, bool CODES, bool HIST>
+// GATH (the multi-GPU form of config 2): there is no parameter table yet - `qp_in` holds the W gathered {min, max}
+// records [W][2][C] of the ranks, and every workgroup derives scale / zero point of its own channels in its
+// prologue with the arithmetic of k_minmax_params (min / max over the ranks are exact, so every workgroup and every
+// rank gets the same bits); the first batch split also writes them to `qp_out`.  One launch boundary less behind
+// every exchange.
+struct GathArgs {
+    int W, num_bits, positive;
+    float* qp_out;
+};
+__device__ __forceinline__ void gathered_params(const float* __restrict__ rec, const GathArgs& ga, int C, int c, float& sc,
+                                                float& zp, float& qm) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = 0; r < ga.W; ++r) {
+        mn = pmin(mn, rec[(size_t)(2 * r) * C + c]);
+        mx = pmax(mx, rec[(size_t)(2 * r + 1) * C + c]);
+    }
+    const float offset = ga.positive ? 0.f : mn;
+    const float delta = mx - offset;
+    qm = qmax_of(ga.num_bits);
+    sc = delta / qm;
+    sc = (sc < 1e-8f) ? 1e-8f : sc;
+    zp = rintf(0.f - offset / sc);
+}
+
+template <int VEC, int A, int J, bool CODES, bool HIST, bool GATH = false>
 __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float* __restrict__ y, const Geo g,
                                              const float* __restrict__ qp, uint8_t* __restrict__ codes,
-                                             unsigned long long* __restrict__ hist) {
+                                             unsigned long long* __restrict__ hist, const GathArgs ga = GathArgs{}) {
     __shared__ float sh_sc[MAXCH], sh_zp[MAXCH], sh_qm[MAXCH];
     __shared__ unsigned sh_hist[HIST ? 256 * HREP : 1];
     const Blk b = blk_of<VEC>(g);
@@ -197,17 +221,40 @@ __global__ void __launch_bounds__(TPB) k_qdq(const float* __restrict__ x, float*
     // a workgroup that owns a slice of ONE channel reads its three parameters directly (uniform
     // address -> scalar loads) and needs neither LDS nor a barrier before it starts streaming
     const bool single = (g.mode == 1) && !HIST;
-    if (!single) {
-        for (int i = tid; i < b.c1 - b.c0; i += TPB) {
-            sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
-            sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
-            sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+    float u_sc = 0.f, u_zp = 0.f, u_qm = 0.f;
+    if constexpr (GATH) {
+        const bool writer = b.n0 == 0 && ga.qp_out != nullptr && (g.mode != 1 || b.col0 == b.c0 * (g.HW / VEC));
+        auto publish = [&](int c, float sc_, float zp_, float qm_) {
+            ga.qp_out[(size_t)CNNQ_QP_SCALE * g.C + c] = sc_;
+            ga.qp_out[(size_t)CNNQ_QP_ZP * g.C + c] = zp_;
+            ga.qp_out[(size_t)CNNQ_QP_QMAX * g.C + c] = qm_;
+        };
+        if (single) {
+            gathered_params(qp, ga, g.C, b.c0, u_sc, u_zp, u_qm);     // uniform: every lane computes the same
+            if (writer && tid == 0) publish(b.c0, u_sc, u_zp, u_qm);
+        } else {
+            for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+                float sc_, zp_, qm_;
+                gathered_params(qp, ga, g.C, b.c0 + i, sc_, zp_, qm_);
+                sh_sc[i] = sc_; sh_zp[i] = zp_; sh_qm[i] = qm_;
+                if (writer) publish(b.c0 + i, sc_, zp_, qm_);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        if (!single) {
+            for (int i = tid; i < b.c1 - b.c0; i += TPB) {
+                sh_sc[i] = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0 + i];
+                sh_zp[i] = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0 + i];
+                sh_qm[i] = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0 + i];
+            }
+            __syncthreads();
+        } else {
+            u_sc = qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0];
+            u_zp = qp[(size_t)CNNQ_QP_ZP * g.C + b.c0];
+            u_qm = qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0];
+        }
     }
-    const float u_sc = single ? qp[(size_t)CNNQ_QP_SCALE * g.C + b.c0] : 0.f;
-    const float u_zp = single ? qp[(size_t)CNNQ_QP_ZP * g.C + b.c0] : 0.f;
-    const float u_qm = single ? qp[(size_t)CNNQ_QP_QMAX * g.C + b.c0] : 0.f;
     int col[J];
     bool ok[J];
     float sc[J][A], zp[J][A], qm[J][A];

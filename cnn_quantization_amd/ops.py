@@ -359,8 +359,11 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         local = ws[12 * C:20 * C].view(torch.float32).view(2, C)            # the mm[2][C] slot of the workspace
         gathered = _scratch(x, 'gath', 8 * C * world)[:8 * C * world].view(torch.float32).view(world, 2, C)
         y = _out_like(x, out)
-        L.check(lib.cnnq_pc_minmax_local(_ptr(x), N, C, HW, ctypes.c_void_p(base + 20 * C), ctypes.c_void_p(base + 12 * C),
-                                         _stream(x)), 'cnnq_pc_minmax_local')
+        st = _raw_stream(x.device.index)
+        gws = _group_workspace(x, st) if resident else None      # one launch for the local extrema when the plan allows
+        L.check(lib.cnnq_pc_minmax_local_auto(x.data_ptr(), N, C, HW, base + 20 * C, gws,
+                                              GROUP_WS_BYTES if gws is not None else 0, base + 12 * C, st),
+                'cnnq_pc_minmax_local_auto')
         gathered = D.all_gather_records(local, group, out=gathered)
         L.check(lib.cnnq_pc_gathered_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(gathered), world, int(num_bits),
                                          int(bool(positive)), ctypes.c_void_p(base), _stream(x)), 'cnnq_pc_gathered_qdq')

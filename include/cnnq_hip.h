@@ -276,9 +276,16 @@ int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int
                              void* ws, float* qp, float* mm, unsigned flags, void* stream);
 
 /* The two halves of config 2 around the cross-rank exchange (multi-GPU: every rank holds a batch shard), one call
- * each: cnnq_pc_minmax_local = cnnq_pc_minmax + cnnq_pc_minmax_reduce -> local[2][C]; after the all_gather of the
- * W ranks' records, cnnq_pc_gathered_qdq = cnnq_pc_minmax_params(gathered[W][2][C]) + cnnq_pc_qdq. */
+ * each: cnnq_pc_minmax_local = cnnq_pc_minmax + cnnq_pc_minmax_reduce -> local[2][C] (two launches);
+ * cnnq_pc_minmax_local_auto does the same in ONE launch when the geometry has a group plan and `gws` (the exchange
+ * workspace of cnnq_pc_minmax_qdq_group, gws_bytes >= cnnq_pc_group_workspace(...); may be NULL) is given: the last
+ * workgroup of a channel group to arrive folds the group's pairs - nobody waits.  After the all_gather of the W ranks'
+ * records, cnnq_pc_gathered_qdq is ONE launch as well: every workgroup of the fused Q/DQ derives scale / zero point
+ * of its channels from gathered[W][2][C] (the arithmetic of cnnq_pc_minmax_params: same bits on every rank) and the
+ * first batch split writes them to qp[CNNQ_NQP][C] (may be NULL). */
 int cnnq_pc_minmax_local(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, float* local, void* stream);
+int cnnq_pc_minmax_local_auto(const float* x, int64_t N, int64_t C, int64_t HW, float* pmm, void* gws, size_t gws_bytes,
+                              float* local, void* stream);
 int cnnq_pc_gathered_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* gathered, int W,
                          int num_bits, int positive, float* qp, void* stream);
 
