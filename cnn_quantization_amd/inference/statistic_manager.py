@@ -16,8 +16,10 @@ from pathlib import Path
 
 import numpy as np
 import pandas as pd
+import torch
 
 from .. import _lib as L
+from .. import distributed as D
 from .. import ops
 from ..utils.misc import Singleton, sorted_nicely
 
@@ -28,8 +30,9 @@ def base_dir():
 
 class StatisticManager(metaclass=Singleton):
     def __init__(self, folder, load_stats, stats=('max', 'min', 'std', 'mean', 'kurtosis', 'mean_abs', 'b', 'dim'),
-                 batch_avg=False, kld_threshold=False, collect_err=False):
+                 batch_avg=False, kld_threshold=False, collect_err=False, group=None):
         self.name = folder
+        self.group = group          # process group of a batch-sharded run (None: the default group, if any)
         self.folder = os.path.join(base_dir(), 'statistics', folder)
         self.stats_names = list(stats)
         self.collect_err = collect_err
@@ -54,22 +57,33 @@ class StatisticManager(metaclass=Singleton):
             raise NotImplementedError('error columns from quantized tensors: no caller in the reference')
         x = tensor.detach().contiguous()
         n = x.numel()
-        table, mom = ops.pc_stats(x, 1, 1, n, need_b=True, need_kurt=True, need_relu=True)
+        # with several ranks x is this rank's batch shard: the moment records travel (ops.pc_stats), every rank
+        # holds the statistics of the GLOBAL batch
+        world = D.world_size(self.group)
+        table, mom = ops.pc_stats(x, 1, 1, n, need_b=True, need_kurt=True, need_relu=True, group=self.group)
         host = table.cpu().numpy()[:, 0]
         m = mom.cpu().numpy()[:, 0]
+        total = m[L.MOM_COUNT]      # elements of the global batch (== n on one rank)
         vals = {'max': host[L.STAT_MAX], 'min': host[L.STAT_MIN], 'std': host[L.STAT_STD],
                 'mean': host[L.STAT_MEAN], 'kurtosis': host[L.STAT_KURT], 'b': host[L.STAT_B],
-                'mean_abs': np.float32((2. * m[L.MOM_SUM_RELU] - m[L.MOM_SUM]) / n), 'dim': n}
+                'mean_abs': np.float32((2. * m[L.MOM_SUM_RELU] - m[L.MOM_SUM]) / total), 'dim': int(total)}
         if self.batch_avg and not force_global_min_max and x.dim() > 1:
             rows, _ = ops.pc_stats(x, 1, x.shape[0], n // x.shape[0], local_only=True)
-            r = rows.cpu().numpy()
-            vals['max'] = r[L.STAT_MAX].mean(dtype=np.float32)
-            vals['min'] = r[L.STAT_MIN].mean(dtype=np.float32)
+            rec = torch.stack([rows[L.STAT_MAX].double().sum(), rows[L.STAT_MIN].double().sum(),
+                               torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)]).view(3, 1)
+            if world > 1:           # sums and sample counts travel: the mean over the global batch
+                rec = D.all_gather_records(rec, self.group).sum(dim=0)
+            r = rec.cpu().numpy()[:, 0]
+            vals['max'] = np.float32(r[0] / r[2])
+            vals['min'] = np.float32(r[1] / r[2])
         for s in self.stats_names:
             if s.startswith('mse_') or s.startswith('cos_'):
                 vals[s] = np.nan
         if self.kld_threshold:
-            vals['kld_th'] = float(ops.kld_thresholds(x, x.shape[0] if x.dim() > 1 else 1)[:, 0].max().item())
+            th = ops.kld_thresholds(x, x.shape[0] if x.dim() > 1 else 1)[:, 0].max().view(1, 1)
+            if world > 1:           # the maximum over the samples of every rank
+                th = D.all_gather_records(th, self.group).max().view(1, 1)
+            vals['kld_th'] = float(th.item())
         row = np.array([[vals[s] for s in self.stats_names]], dtype=np.float64)
         if id in self.stats:
             self.stats[id] = np.concatenate([self.stats[id], row])
@@ -92,6 +106,15 @@ class StatisticManager(metaclass=Singleton):
     def __exit__(self, *args):
         if not self.save_stats:
             return
+        if D.world_size(self.group) > 1:
+            # every rank holds the same (global) statistics: rank 0 writes, the others wait for the files
+            if D.rank(self.group) == 0:
+                self._write()
+            torch.distributed.barrier(group=self.group)
+            return
+        self._write()
+
+    def _write(self):
         if os.path.exists(self.folder):
             shutil.rmtree(self.folder)
         os.makedirs(self.folder)

@@ -51,6 +51,15 @@ def _worker(rank, world, port, tmp):
     os.environ['CNNQ_P2P_EXCHANGE'] = '0'
     st, mom = ops.pc_stats(xs, xs.shape[0], xs.shape[1], 14 * 14, need_b=True, need_kurt=True, need_relu=True)
     out['stats'] = st.cpu()
+    # per-tensor calibration statistics (-sm collect without -pcq_a): global on every rank, one writer
+    os.environ['HOME'] = tmp
+    from cnn_quantization_amd.inference.statistic_manager import StatisticManager
+    sm = StatisticManager('pt_dist', load_stats=False, batch_avg=True, kld_threshold=True)
+    sm.save_tensor_stats(xs, 'act', 'layer0')
+    out['pt_row'] = torch.from_numpy(sm.stats['layer0'][0].copy())
+    out['pt_names'] = list(sm.stats_names)
+    sm.__exit__()
+    out['pt_file'] = os.path.exists(os.path.join(tmp, 'mxt-sim', 'statistics', 'pt_dist', 'pt_dist_summary.csv'))
     torch.cuda.synchronize()
     torch.save(out, os.path.join(tmp, 'rank%d.pt' % rank))
     dist.barrier()
@@ -86,3 +95,22 @@ def test_two_ranks_equal_one_gpu(tmp_path):
         assert torch.equal(p['stats'][:2], st1.cpu()[:2])            # min / max exact
         assert torch.allclose(p['stats'], st1.cpu(), rtol=1e-5, atol=1e-5)
         assert torch.equal(p['stats_p2p'], p['stats'])               # same records, same merge order
+    # the per-tensor statistics manager: both ranks hold the row a single process computes on the whole batch,
+    # and the summary file exists once both have left __exit__
+    import numpy as np
+    from cnn_quantization_amd.inference.statistic_manager import StatisticManager
+    from cnn_quantization_amd.utils.misc import Singleton
+    os.environ['HOME'] = str(tmp_path / 'single')
+    Singleton.reset(StatisticManager)
+    sm = StatisticManager('pt_single', load_stats=False, batch_avg=True, kld_threshold=True)
+    sm.save_tensor_stats(x.cuda(), 'act', 'layer0')
+    ref_row = sm.stats['layer0'][0]
+    names = list(sm.stats_names)
+    for p in parts:
+        assert p['pt_file'] and p['pt_names'] == names
+        row = p['pt_row'].numpy()
+        for nm in ('max', 'min', 'dim', 'kld_th'):
+            assert row[names.index(nm)] == ref_row[names.index(nm)], nm
+        np.testing.assert_allclose(row, ref_row, rtol=2e-5, atol=1e-6)
+    assert torch.equal(parts[0]['pt_row'], parts[1]['pt_row'])
+    Singleton.reset(StatisticManager)
