@@ -272,7 +272,8 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
             slot_split(min(qg, W - 2), nslots, inv_ns, nch, chg, slg);
             ghere = qg < W;
         }
-        const int b = sh_b[chg];
+        // ROWS: one channel per wave - its bit width lives in a scalar register and selects straight-line store code
+        const int b = ROWS ? __builtin_amdgcn_readfirstlane(sh_b[chg]) : sh_b[chg];
         const int gi = slg >> 1;
         const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
         // bytes of this group: b whole bytes, or - last group of the row - everything up to the padded row end
@@ -300,12 +301,40 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
             const unsigned lo = lane < 32 ? a0 : b0, hi = lane < 32 ? a1 : b1;
             const unsigned long long ww = (unsigned long long)lo | ((unsigned long long)hi << (4 * b));
             // widest naturally aligned stores (the group starts at gi * b): 8 / 4 / 2-byte pieces where b allows
-            if (nb == 8u && b == 8) *reinterpret_cast<unsigned long long*>(g) = ww;
-            else if (nb == 4u && b == 4) *reinterpret_cast<uint32_t*>(g) = (uint32_t)ww;
-            else if ((b & 1) == 0 && (nb & 1u) == 0u)
-                for (uint32_t kk = 0; kk < nb; kk += 2) *reinterpret_cast<uint16_t*>(g + kk) = (uint16_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
-            else
-                for (uint32_t kk = 0; kk < nb; ++kk) g[kk] = (uint8_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
+            auto store_any = [&](uint32_t nbytes) {
+                if (nbytes == 8u && b == 8) *reinterpret_cast<unsigned long long*>(g) = ww;
+                else if (nbytes == 4u && b == 4) *reinterpret_cast<uint32_t*>(g) = (uint32_t)ww;
+                else if ((b & 1) == 0 && (nbytes & 1u) == 0u)
+                    for (uint32_t kk = 0; kk < nbytes; kk += 2) *reinterpret_cast<uint16_t*>(g + kk) = (uint16_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
+                else
+                    for (uint32_t kk = 0; kk < nbytes; ++kk) g[kk] = (uint8_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
+            };
+            if constexpr (ROWS) {
+                // every group but a row's last one is exactly b bytes: no loops, no per-lane width tests
+                const bool plain = ghere && gi != ngroups - 1;
+                if (plain) {
+                    const unsigned wl = (unsigned)ww, wh = (unsigned)(ww >> 32);
+                    switch (b) {   // uniform
+                        case 8: *reinterpret_cast<unsigned long long*>(g) = ww; break;
+                        case 4: *reinterpret_cast<uint32_t*>(g) = wl; break;
+                        case 2: *reinterpret_cast<uint16_t*>(g) = (uint16_t)wl; break;
+                        case 6:
+                            *reinterpret_cast<uint16_t*>(g) = (uint16_t)wl;
+                            *reinterpret_cast<uint16_t*>(g + 2) = (uint16_t)(wl >> 16);
+                            *reinterpret_cast<uint16_t*>(g + 4) = (uint16_t)wh;
+                            break;
+                        case 7: g[6] = (uint8_t)(wh >> 16); [[fallthrough]];
+                        case 5: g[4] = (uint8_t)wh; if (b == 7) g[5] = (uint8_t)(wh >> 8); g[3] = (uint8_t)(wl >> 24); [[fallthrough]];
+                        case 3: g[2] = (uint8_t)(wl >> 16); g[1] = (uint8_t)(wl >> 8); [[fallthrough]];
+                        case 1: g[0] = (uint8_t)wl; break;
+                        default: break;   // 0 bits: the channel stores nothing
+                    }
+                } else {
+                    store_any(nb);
+                }
+            } else {
+                store_any(nb);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { va[e] = na[e]; vb[e] = nbv[e]; }
         } else {
