@@ -43,6 +43,7 @@ def _dev_f32(x, what='tensor'):
 
 _SCRATCH = {}
 _WS_BYTES = {}
+_XPLAN = {}     # per (group, device, stream, geometry): what the multi-GPU hot call needs, looked up once
 
 
 def _scratch(x, tag, nbytes, st=None):
@@ -349,24 +350,46 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
             and os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') != '1'):
         # the multi-GPU hot call: local extrema (one C call) -> all_gather of [2, C] -> parameters + Q/DQ (one C
         # call), all in cached workspaces; the collective is the only torch.distributed call
-        key = (N, C, HW)
-        plan = _WS_BYTES.get(key)
-        nbytes = plan[0] if plan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
-        if nbytes == 0:
-            L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
-        ws = _scratch(x, 'cfg2', nbytes)
-        base = ws.data_ptr()
-        local = ws[12 * C:20 * C].view(torch.float32).view(2, C)            # the mm[2][C] slot of the workspace
-        gathered = _scratch(x, 'gath', 8 * C * world)[:8 * C * world].view(torch.float32).view(world, 2, C)
-        y = _out_like(x, out)
         st = _raw_stream(x.device.index)
+        p2p = os.environ.get('CNNQ_P2P_EXCHANGE', '0')
+        direct = os.environ.get('CNNQ_DIRECT_RCCL', '1')
+        key = (id(group), x.device.index, st, N, C, HW, world, p2p, direct)
+        plan = _XPLAN.get(key)
+        if plan is None:
+            # everything that does not change from call to call: workspace slices, the gathered buffer, the direct
+            # RCCL communicator (created collectively at first use).  The plan keeps `group` alive, so its id stays its
+            # own, and its scratch buffers too (a later, larger tensor may make _scratch hand out new ones).
+            wplan = _WS_BYTES.get((N, C, HW))
+            nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+            if nbytes == 0:
+                L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+            ws = _scratch(x, 'cfg2', nbytes, st)
+            gbuf = _scratch(x, 'gath', 8 * C * world, st)
+            dc = None
+            if p2p != '1' and x.is_cuda:
+                from . import rccl
+                dc = rccl.direct_comm(group)
+            plan = _XPLAN[key] = dict(
+                group=group, ws=ws, gbuf=gbuf, base=ws.data_ptr(), dc=dc,
+                local=ws[12 * C:20 * C].view(torch.float32).view(2, C),            # the mm[2][C] slot of the workspace
+                gathered=gbuf[:8 * C * world].view(torch.float32).view(world, 2, C))
+        base = plan['base']
+        y = _out_like(x, out)
         gws = _group_workspace(x, st) if resident else None      # one launch for the local extrema when the plan allows
-        L.check(lib.cnnq_pc_minmax_local_auto(x.data_ptr(), N, C, HW, base + 20 * C, gws,
-                                              GROUP_WS_BYTES if gws is not None else 0, base + 12 * C, st),
-                'cnnq_pc_minmax_local_auto')
-        gathered = D.all_gather_records(local, group, out=gathered)
-        L.check(lib.cnnq_pc_gathered_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(gathered), world, int(num_bits),
-                                         int(bool(positive)), ctypes.c_void_p(base), _stream(x)), 'cnnq_pc_gathered_qdq')
+        rc = lib.cnnq_pc_minmax_local_auto(x.data_ptr(), N, C, HW, base + 20 * C, gws,
+                                           GROUP_WS_BYTES if gws is not None else 0, base + 12 * C, st)
+        if rc:
+            L.check(rc, 'cnnq_pc_minmax_local_auto')
+        dc = plan['dc']
+        gathered = plan['gathered']
+        if dc is not None:
+            dc.all_gather_raw(base + 12 * C, gathered.data_ptr(), 8 * C, st)
+        else:
+            gathered = D.all_gather_records(plan['local'], group, out=gathered)
+        rc = lib.cnnq_pc_gathered_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, gathered.data_ptr(), world, int(num_bits),
+                                      1 if positive else 0, base, st)
+        if rc:
+            L.check(rc, 'cnnq_pc_gathered_qdq')
         return y
     if not exchanging and resident and not want_codes and not want_entropy:
         res = minmax_qdq_resident(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
