@@ -111,3 +111,46 @@ def test_gathered_qdq_one_launch(env, shape, W, half):
     y2 = torch.empty_like(x)                                   # the table is optional
     L.check(lib.cnnq_pc_gathered_qdq(ops._ptr(x), ops._ptr(y2), N, C, HW, ops._ptr(rec), W, 4, int(half), None, st), 'gathered_qdq')
     assert bits_equal(y2.cpu(), y_ref.cpu())
+
+
+# ---- random geometries (hypothesis, derandomised): odd H*W, single samples, unaligned base pointers, W ranks
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as hst  # noqa: E402
+
+_CFG = dict(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+_shapes = hst.tuples(hst.integers(1, 70), hst.integers(1, 40), hst.integers(1, 19), hst.integers(1, 19)).filter(
+    lambda s: s[2] * s[3] > 1)
+
+
+@settings(**_CFG)
+@given(shape=_shapes, seed=hst.integers(0, 2 ** 16), offset=hst.integers(0, 3), W=hst.integers(1, 4), half=hst.booleans(),
+       bits=hst.sampled_from([2, 4, 8]))
+def test_exchange_halves_random_geometry(shape, seed, offset, W, half, bits):
+    """local extrema (one launch where the geometry has a group plan) == torch; the shard quantized with W gathered
+    records == the oracle on the concatenation of W such shards (the other ranks' data only enters through their
+    records: here scaled copies of this shard)."""
+    from cnn_quantization_amd import _lib as L
+    from cnn_quantization_amd import ops
+    from oracle import quant_oracle as O
+    lib = L.load()
+    g = torch.Generator().manual_seed(seed)
+    n = shape[0] * shape[1] * shape[2] * shape[3]
+    x = torch.randn(shape, generator=g) * (0.2 + 3 * torch.rand(1, shape[1], 1, 1, generator=g))
+    if half:
+        x = x.abs()
+    base = torch.empty(n + 3, device='cuda')
+    xd = base[offset:offset + n].view(shape)                 # offset != 0: base pointer not 16-byte aligned
+    xd.copy_(x)
+    N, C, HW = shape[0], shape[1], shape[2] * shape[3]
+    out = local_auto((L, lib, ops), xd)
+    t = x.transpose(0, 1).reshape(C, -1)
+    assert bits_equal(out.cpu(), torch.stack([t.min(1)[0], t.max(1)[0]]))
+    scales = [1.0, 1.5, 0.25, 2.0][:W]
+    shards = [x * s_ for s_ in scales]                       # rank r holds shard r; this process is rank 0
+    rec = torch.stack([torch.stack([(sh.transpose(0, 1).reshape(C, -1)).min(1)[0], (sh.transpose(0, 1).reshape(C, -1)).max(1)[0]])
+                       for sh in shards]).cuda().contiguous()
+    y = torch.empty_like(xd)
+    L.check(lib.cnnq_pc_gathered_qdq(ops._ptr(xd), ops._ptr(y), N, C, HW, ops._ptr(rec), W, bits, int(half), None,
+                                     ops._stream(xd)), 'gathered_qdq')
+    ref = O.act_per_channel_qdq(torch.cat(shards), bits, half_range=half)[:N]
+    assert bits_equal(y.cpu().numpy(), ref.numpy())
