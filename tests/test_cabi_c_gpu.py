@@ -1,5 +1,6 @@
 """The C ABI from a plain C client on the GPU: tests/c/cabi_demo.c (gcc -std=c99, links libcnnq_hip.so and the
-HIP runtime only) quantizes a tensor with cnnq_pc_minmax_qdq and checks it bit for bit against scalar C."""
+HIP runtime only) quantizes a tensor with cnnq_pc_minmax_qdq and checks it bit for bit against scalar C, then runs the
+one-call single-launch route (with a group workspace) and the two halves of the multi-GPU form and compares the three."""
 import os
 import shutil
 import subprocess
@@ -23,4 +24,4 @@ def test_c_client_bit_exact(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ':/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert 'bit-exact' in r.stdout
+    assert 'bit-exact' in r.stdout and 'agree bit for bit' in r.stdout, r.stdout
