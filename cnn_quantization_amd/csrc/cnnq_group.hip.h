@@ -407,9 +407,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
 // The rank-local extrema out[2][C] of a batch shard in ONE launch (the multi-GPU form of config 2 exchanges them
 // between its statistics pass and its Q/DQ pass): the tiling and the pair blocks of k_mmq_group, but nobody waits - the
 // LAST workgroup of a channel group to arrive folds the group's pairs and writes the channels' record.  Replaces
-// k_minmax + k_minmax_reduce (one launch boundary less in front of every exchange).  NTL: non-temporal loads (x is
-// too large for the Q/DQ pass to find it in the Infinity Cache anyway).
-template <int A, int K, bool NTL>
+// k_minmax + k_minmax_reduce (one launch boundary less in front of every exchange).  Plain loads: the host uses it for
+// tensors the Q/DQ pass will still find in the Infinity Cache (larger ones keep the streaming k_minmax).
+template <int A, int K>
 __global__ void __launch_bounds__(TPB) k_minmax_group(const float* __restrict__ x, const Geo g, const int Gs, const GWs ws,
                                                       float* __restrict__ out) {
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_group(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int r = j < nrows ? j : nrows - 1;
-        ldv_sel<4, NTL>(x + base + (size_t)r * (size_t)g.P, v[j]);
+        ldv<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
     }
     float mn[A], mx[A];
     bool nan = false;

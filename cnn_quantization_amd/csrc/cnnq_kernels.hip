@@ -469,7 +469,7 @@ int cnnq_pc_minmax_local_auto(const float* x, int64_t N, int64_t C, int64_t HW, 
     if (gws && !((uintptr_t)gws & 127) && N * C * HW * 4 <= max_bytes) {
         GPlan p;
         if (plan_group(N, C, HW, al16(x), &p) == 0 && p.ws_bytes <= gws_bytes)
-            return launch_minmax_group(x, p, gws, local, false, (hipStream_t)stream);
+            return launch_minmax_group(x, p, gws, local, (hipStream_t)stream);
     }
     return cnnq_pc_minmax_local(x, N, C, HW, pmm, local, stream);
 }

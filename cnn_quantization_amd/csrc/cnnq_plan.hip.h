@@ -306,18 +306,14 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
 }
 
 // rank-local extrema in one launch (k_minmax_group): the plan and workspace of launch_group
-int launch_minmax_group(const float* x, const GPlan& p, void* ws, float* out, bool ntl, hipStream_t st) {
+int launch_minmax_group(const float* x, const GPlan& p, void* ws, float* out, hipStream_t st) {
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
     w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
-#define LAUNCH_MG(A, K)                                                                                     \
-    do {                                                                                                    \
-        if (ntl) hipLaunchKernelGGL((k_minmax_group<A, K, true>), grid, block, 0, st, x, p.g, p.Gs, w, out);  \
-        else hipLaunchKernelGGL((k_minmax_group<A, K, false>), grid, block, 0, st, x, p.g, p.Gs, w, out);     \
-    } while (0)
+#define LAUNCH_MG(A, K) hipLaunchKernelGGL((k_minmax_group<A, K>), grid, block, 0, st, x, p.g, p.Gs, w, out)
     if (p.v.A == 4) {
         if (p.K == 32) LAUNCH_MG(4, 32); else if (p.K == 16) LAUNCH_MG(4, 16); else if (p.K == 8) LAUNCH_MG(4, 8); else LAUNCH_MG(4, 4);
     } else {
