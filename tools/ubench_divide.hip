@@ -1,10 +1,10 @@
 // tools/ubench_divide.hip - is a three-instruction divide exact enough for the Q/DQ?  (measurement aid, not product code)
 // For a scale s with correctly rounded reciprocal r = 1 / s:  q0 = x * r;  e = fma(-q0, s, x);  q1 = fma(e, r, q0)
-// (Markstein's quotient refinement); huge |q0| keeps q0 (the refinement would turn an overflowed inf into NaN, and
-// the clamp decides those codes anyway).  The kernel runs ALL 2^32 bit patterns of x against `ns` scales and counts
+// (Markstein's quotient refinement); an infinite or zero q0 stays (the refinement would turn +-inf into NaN, -0 into +0).  The kernel runs ALL 2^32 bit patterns of x against `ns` scales and counts
 //   [0] quotients q1 != x / s (bitwise, NaN == NaN),  [1] integer codes that differ:
 //       rint(clamp(q + zp, 0, qmax)) with the IEEE quotient vs with q1  (iq.py:573-590),
-//   [2] the same for dequantized values (code - zp) * s.
+//   [3] quotient mismatches whose IEEE quotient is a normal number (the rest sit in the underflow range),
+//   [2] mid-tread outputs clamp(rint(q), lo, hi) * s that differ (bitwise, signed zeros included).
 // build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC tools/ubench_divide.hip -o tools/ubench_divide.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,7 +18,7 @@ __device__ __forceinline__ float code_of(float q, float zp, float qmax) {
 
 __global__ void __launch_bounds__(256) k_div(const float* __restrict__ scales, const float* __restrict__ zps, int ns,
                                              float qmax, unsigned long long* __restrict__ counts) {
-    unsigned nq = 0, nc = 0, ny = 0;
+    unsigned nq = 0, nc = 0, ny = 0, nn = 0;
     for (int half = 0; half < 2; ++half)                               // grid = 2^23 blocks x 2: every float
     for (int i = 0; i < ns; ++i) {
         const uint32_t xbits = ((uint32_t)half << 31) | (blockIdx.x * 256u + threadIdx.x);
@@ -29,19 +29,26 @@ __global__ void __launch_bounds__(256) k_div(const float* __restrict__ scales, c
         const float q0 = x * r;
         const float e = fmaf(-q0, s, x);
         float q1 = fmaf(e, r, q0);
-        q1 = (fabsf(q0) > 1e30f) ? q0 : q1;
+        q1 = __builtin_amdgcn_classf(q0, 0x264) ? q0 : q1;          // +-inf would refine to NaN, -0 to +0: keep q0
         const bool same_q = (__float_as_uint(qt) == __float_as_uint(q1)) || (qt != qt && q1 != q1);
         nq += same_q ? 0u : 1u;
+        nn += (!same_q && fabsf(qt) >= 1.1754944e-38f) ? 1u : 0u;     // ... of which with a NORMAL IEEE quotient
         const float ct = code_of(qt, zp, qmax), cf = code_of(q1, zp, qmax);
         const bool same_c = (__float_as_uint(ct) == __float_as_uint(cf)) || (ct != ct && cf != cf);
         nc += same_c ? 0u : 1u;
-        const float yt = (ct - zp) * s, yf = (cf - zp) * s;
+        // [2]: the mid-tread form (iq.py:202-224): t = clamp(rint(q), lo, hi) with float bounds, y = t * s
+        const float lo = -zp - 0.37f, hi = qmax - zp + 0.61f;
+        float tt = rintf(qt), tf = rintf(q1);
+        tt = (tt < hi || tt != tt) ? tt : hi; tt = (tt > lo || tt != tt) ? tt : lo;
+        tf = (tf < hi || tf != tf) ? tf : hi; tf = (tf > lo || tf != tf) ? tf : lo;
+        const float yt = tt * s, yf = tf * s;
         const bool same_y = (__float_as_uint(yt) == __float_as_uint(yf)) || (yt != yt && yf != yf);
         ny += same_y ? 0u : 1u;
     }
     if (nq) atomicAdd(&counts[0], (unsigned long long)nq);
     if (nc) atomicAdd(&counts[1], (unsigned long long)nc);
     if (ny) atomicAdd(&counts[2], (unsigned long long)ny);
+    if (nn) atomicAdd(&counts[3], (unsigned long long)nn);
 }
 
 extern "C" int udivide(const float* scales, const float* zps, int ns, float qmax, unsigned long long* counts) {
