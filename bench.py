@@ -397,6 +397,19 @@ def main():
                          'tensor) - measures what the collective costs on this box')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` started as a plain process: start the N ranks ourselves (one per GPU, the
+        # launcher the contract names); rank 0 of the children prints the one JSON line on the inherited stdout
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     # stdout carries exactly ONE line, the JSON: libraries that print to fd 1 (RCCL's version banner at communicator
     # creation, gloo's connection notes) are sent to stderr
     sys.stdout.flush()
@@ -462,11 +475,17 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     total_elems = elems
+    per_rank_ms = [dt * 1e3 / args.steps]
     if world > 1:
-        t = torch.tensor([dt, float(elems)], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        cdev = device if backend == 'nccl' else 'cpu'
+        t = torch.tensor([dt, float(elems)], device=cdev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        mine = torch.zeros(world, device=cdev, dtype=torch.float64)
+        mine[rank] = dt * 1e3 / args.steps
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(v) for v in mine.tolist()]
         dt, total_elems = float(tmax[0].item()), int(t[1].item())
     ms_per_step = dt * 1e3 / args.steps
     if world == 1 and not args.force_exchange:
@@ -483,6 +502,10 @@ def main():
             ' (ncclAllGather enqueued directly on the compute stream)' if direct else ' (through torch.distributed)',
             ' (forced on a 1-rank group)' if args.force_exchange else '')
     value = total_elems * args.steps / dt
+    rccl_ranks = 0
+    if (world > 1 or args.force_exchange) and backend == 'nccl':
+        from cnn_quantization_amd import rccl
+        rccl_ranks = rccl.comm_ranks(group)          # what ncclCommCount says about the communicator actually used
 
     verified = verify_outputs(ops, layers, group, world)
     if world > 1:
@@ -493,7 +516,8 @@ def main():
     out = {
         'metric': 'activation elements/sec (and % HBM peak) for per-channel int4 Q/DQ, ResNet-50 b512',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+        'ms_per_step': ms_per_step, 'ms_per_step_by_rank': per_rank_ms, 'rccl_ranks': rccl_ranks,
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'ResNet-50 b%d conv activations (53 tensors, %.2f G elements in the job, %.2f G per GPU), '
                                'per-channel int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (

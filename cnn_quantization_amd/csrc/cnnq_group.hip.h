@@ -55,6 +55,17 @@ constexpr int GRP_SUB = 16;                        // members per arrival counte
 #define GRP_K32_WAVES 3   // waves per SIMD the K = 32 tile is compiled for (168 VGPRs)
 #endif
 
+#ifdef GRP_TRACE
+// development build only (tools/trace_group.py): lane 0 of every workgroup stamps its phases with the 100 MHz clock
+__device__ unsigned long long* g_grp_trace = nullptr;   // [workgroup][8]
+#define GRP_STAMP(i)                                                                                     \
+    do {                                                                                                 \
+        if (g_grp_trace && threadIdx.x == 0) g_grp_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define GRP_STAMP(i)
+#endif
+
 __device__ __forceinline__ unsigned long long pack_pair(float mn, float mx) {
     return (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
 }
@@ -231,14 +242,21 @@ __device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsig
     if (!timed_out && !ready) {
         const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals
         const unsigned want = (nsub > 1) ? 1u : m_i;
-        const long long t0 = wall_clock64();
+        long long t0 = 0;
         for (int spins = 0;; ++spins) {
             // back-off in units of 64 clocks (swept 4/8/16 ... 32/64/127: +-1.5 %, the schedule hardly matters)
             if (spins < 2) __builtin_amdgcn_s_sleep(8);
             else if (spins < 6) __builtin_amdgcn_s_sleep(32);
             else __builtin_amdgcn_s_sleep(64);
             if (__hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-            if (wall_clock64() - t0 > GRP_TIMEOUT_TICKS || spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
+            // the clock is a scalar-memory round trip of its own (microseconds under a streaming load): consult it
+            // every 32 polls (~50 us apart) - the bound stays 20 ms, the common case pays for the poll alone
+            if ((spins & 31) == 31) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > GRP_TIMEOUT_TICKS) { timed_out = 1; break; }
+            }
+            if (spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
         }
     }
 #if GRP_ACQUIRE
@@ -284,11 +302,26 @@ struct GWs {
 template <int A, int K>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_group(
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
-    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags) {
+    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const int wave0) {
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
     __shared__ int sh_timed_out;
+    GRP_STAMP(0);
     const RBlk rb = rblk_of(g, Gs);
+    if ((int)blockIdx.x < wave0) {
+        // The workgroups of the FIRST dispatch wave all start within a microsecond and would stay in lockstep for the
+        // whole launch (every group loads, meets and stores at the same moments: HBM idles during the meetings and the
+        // next wave inherits the phase).  Groups of the first wave therefore start in P phases, D apart.
+        const unsigned P = (flags >> 4) & 15u, D = ((flags >> 8) & 255u) * 50u;   // D in units of 0.5 us
+        const unsigned ph = P ? (unsigned)rb.group % P : 0u;
+        if (ph) {
+            if (threadIdx.x == 0) {
+                const long long t0 = wall_clock64();
+                while (wall_clock64() - t0 < (long long)(ph * D)) __builtin_amdgcn_s_sleep(32);
+            }
+            __syncthreads();
+        }
+    }
     const Blk& b = rb.b;
     const int tid = threadIdx.x;
     const int col = b.col0 + tid;
@@ -304,6 +337,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         const int r = j < nrows ? j : nrows - 1;
         ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
     }
+    GRP_STAMP(1);
     float mn[A], mx[A];
     bool nan = false;
 #pragma unroll
@@ -313,6 +347,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     if (A == 1 && nan) { mn[0] = NAN; mx[0] = NAN; }
     wg_channel_minmax<A>(g, b, ok, mn, mx, l_mn, l_mx, sh_mn, sh_mx);
     const int nch = b.c1 - b.c0;
+    GRP_STAMP(2);
 
     // ---- publish this workgroup's pairs (write-through), arrive, wait for the group
     unsigned long long* blk = ws.part + (size_t)rb.group * ws.gstride;
@@ -322,10 +357,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
                            __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
     __syncthreads();
+    GRP_STAMP(3);
     if (tid == 0) {
         const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {});
         if (timed_out) atomicOr(ws.status, 1u);
         sh_timed_out = timed_out;
+        GRP_STAMP(4);
     }
     __syncthreads();
     if (sh_timed_out) {
@@ -376,6 +413,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         }
     }
     __syncthreads();
+    GRP_STAMP(5);
     float sc[A], zp[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -401,7 +439,13 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     }
     // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
     //      counter line re-arms it for the next launch
+    GRP_STAMP(6);
     if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
+#ifdef GRP_TRACE
+    if (g_grp_trace && tid == 0)
+        g_grp_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
 }
 
 // The rank-local extrema out[2][C] of a batch shard in ONE launch (the multi-GPU form of config 2 exchanges them

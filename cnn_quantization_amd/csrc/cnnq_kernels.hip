@@ -184,6 +184,9 @@ int cnnq_pc_params(const float* stats, int64_t C, const cnnq_params_cfg* cfg, fl
                    void* stream) {
     if (!stats || !cfg || !qp || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
     if (cfg->num_bits < 1 || cfg->num_bits > 32 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
+    // the ACIQ factor tables have entries for 0..8 bits only (iq.py:14-41: the reference's alpha_laplace / alpha_gaus
+    // dictionaries raise KeyError beyond 8); wider codes are accepted for min/max and the '<p>std' clip alone
+    if ((cfg->clip == 1 || cfg->clip == 2) && cfg->num_bits > 8) return CNNQ_EINVAL;
     if (cfg->bit_alloc && cfg->num_bits <= 4 && !diag) return CNNQ_EINVAL;  // bit table lives in diag
     float* bits_ws = diag ? diag + (size_t)CNNQ_DIAG_BITS * C : nullptr;
     const int threads = (int)(C >= PTPB ? PTPB : ((C + 63) / 64) * 64);
@@ -427,6 +430,14 @@ int cnnq_group_ws_status(const void* ws, uint32_t* status_host) {
     return (int)hipMemcpy(status_host, ws, sizeof(uint32_t), hipMemcpyDeviceToHost);
 }
 
+#ifdef GRP_TRACE
+// development build only (tools/trace_group.py; not declared in include/cnnq_hip.h, absent from the product library)
+int cnnq_debug_group_trace(void* buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grp_trace), &p, sizeof(p));
+}
+#endif
+
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
     if (!out) return CNNQ_EINVAL;
     GPlan p;
@@ -536,6 +547,8 @@ size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16) {
 int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
                      float* qp, float* diag, void* stream) {
     if (!x || !y || !cfg || !ws || !qp || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
+    if (cfg->num_bits < 1 || cfg->num_bits > 32 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
+    if ((cfg->clip == 1 || cfg->clip == 2) && cfg->num_bits > 8) return CNNQ_EINVAL;   // as cnnq_pc_params, before any launch
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
     double* part = reinterpret_cast<double*>(ws);

@@ -1,6 +1,7 @@
 // cnnq_plan.hip.h - host side: load-shape choice, launch geometry, template dispatch.
 // Part of the single translation unit cnnq_kernels.hip (see its header for the design).
 #pragma once
+#include <stdio.h>
 #include "cnnq_common.hip.h"
 #include "cnnq_resident.hip.h"
 #include "cnnq_group.hip.h"
@@ -294,8 +295,23 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
+    // development knob: CNNQ_GRP_STAGGER="P,D" - P start phases D half-microseconds apart for the first dispatch wave
+    static const int stag = [] {
+        const char* e = getenv("CNNQ_GRP_STAGGER");
+        int P = 0, D = 0;
+        if (e && sscanf(e, "%d,%d", &P, &D) == 2 && P > 1 && P < 16 && D > 0 && D < 256) return (P << 4) | (D << 8);
+        return 0;
+    }();
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    const int occ = p.K == 32 ? 3 : p.K == 16 ? 5 : 8;      // workgroups per CU (register-bound)
+    const int wave0 = stag ? cus * occ : 0;
+    flags |= (unsigned)stag;
 #define LAUNCH_G(A, K) \
-    hipLaunchKernelGGL((k_mmq_group<A, K>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags)
+    hipLaunchKernelGGL((k_mmq_group<A, K>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, wave0)
     if (p.v.A == 4) {
         if (p.K == 32) LAUNCH_G(4, 32); else if (p.K == 16) LAUNCH_G(4, 16); else if (p.K == 8) LAUNCH_G(4, 8); else LAUNCH_G(4, 4);
     } else {

@@ -162,6 +162,9 @@ def _params_cfg(num_bits, positive, clip, bit_alloc, prior_is_b, target, round_m
     cfg.num_bits = int(num_bits)
     cfg.positive = int(bool(positive))
     if clip in CLIP_CODES:
+        if clip != 'no' and int(num_bits) > 8:
+            # iq.py:14-41: alpha_laplace / alpha_gaus have keys 0..8 only (the reference raises KeyError)
+            raise L.CnnqError('%s clipping is tabulated for at most 8 bits, got %d' % (clip, int(num_bits)))
         cfg.clip, cfg.pstd = CLIP_CODES[clip], 0.
     elif 'std' in clip:
         cfg.clip, cfg.pstd = 3, float(clip.replace('std', ''))

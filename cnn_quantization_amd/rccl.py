@@ -32,8 +32,11 @@ def _load():
     lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_void_p]
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    lib.ncclCommCuDevice.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
     lib.ncclGetErrorString.restype = ctypes.c_char_p
-    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllGather, lib.ncclCommDestroy):
+    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllGather, lib.ncclCommDestroy, lib.ncclCommCuDevice,
+              lib.ncclCommCount):
         f.restype = ctypes.c_int
     return lib
 
@@ -63,14 +66,27 @@ class DirectComm:
         if self._all_agree(local_ok):                # nobody enters the blocking set-up unless everybody can
             ctypes.memmove(ctypes.byref(uid), box[0], 128)
             err = []
+            # the HIP current device is a property of the HOST THREAD and a new thread starts on device 0:
+            # without this every rank >= 1 of a one-process-per-GPU job would create its communicator on GPU 0
+            dev_index = torch.cuda.current_device()
+            self.device_index = dev_index
 
             def init():
+                torch.cuda.set_device(dev_index)
                 err.append(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank))
             th = threading.Thread(target=init, daemon=True)
             th.start()
             th.join(SETUP_TIMEOUT_S)
             if th.is_alive() or not err or err[0] != 0:
                 local_ok, self.why = False, 'ncclCommInitRank %s' % ('timed out' if th.is_alive() else err)
+            if local_ok:
+                # the communicator must live on THIS rank's device and span the whole group
+                d, n = ctypes.c_int(-1), ctypes.c_int(-1)
+                rc1 = self.lib.ncclCommCuDevice(self.comm, ctypes.byref(d))
+                rc2 = self.lib.ncclCommCount(self.comm, ctypes.byref(n))
+                if rc1 != 0 or rc2 != 0 or d.value != dev_index or n.value != self.world:
+                    local_ok, self.why = False, 'communicator on device %d with %d ranks, expected device %d with %d ranks' % (
+                        d.value, n.value, dev_index, self.world)
         else:
             local_ok = False
         self.ok = self._all_agree(local_ok) and self._verify()
@@ -139,8 +155,24 @@ def direct_comm(group=None):
     return _COMMS[key]
 
 
+def comm_ranks(group=None):
+    """Ranks of the direct communicator of `group` as RCCL itself reports them (ncclCommCount), 0 when the direct
+    path is not in use - reported by bench.py as `rccl_ranks`."""
+    c = direct_comm(group)
+    if c is None:
+        return 0
+    n = ctypes.c_int(0)
+    return n.value if c.lib.ncclCommCount(c.comm, ctypes.byref(n)) == 0 else 0
+
+
 def close_all():
+    """Destroy every direct communicator; cached exchange plans that hold one are dropped with it."""
     for c in _COMMS.values():
         if c is not None:
             c.close()
     _COMMS.clear()
+    try:
+        from . import ops
+        ops.release_plans()
+    except ImportError:
+        pass

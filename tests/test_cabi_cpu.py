@@ -55,6 +55,21 @@ def test_argument_validation_needs_no_device():
     assert lib.cnnq_kld_search(None, 1, None, None, None, None) == -1
     with pytest.raises(L.CnnqError):
         L.check(-2, 'x')
+    # ACIQ factor tables end at 8 bits (iq.py:14-41: the reference's dictionaries raise KeyError): wider codes with
+    # laplace / gaus clipping are refused before anything is launched (the dummy pointers are never dereferenced)
+    import ctypes
+    cfg = L.ParamsCfg(num_bits=16, positive=0, clip=1, pstd=0., bit_alloc=0, prior_is_b=0, target=16., round_mode=1,
+                      direct_range=0)
+    assert lib.cnnq_pc_params(64, 4, ctypes.byref(cfg), 64, 64, None) == -1
+    assert lib.cnnq_pc_aciq_qdq(64, 64, 2, 4, 16, ctypes.byref(cfg), 64, 64, 64, None) == -1
+    cfg.clip = 2
+    assert lib.cnnq_pc_params(64, 4, ctypes.byref(cfg), 64, 64, None) == -1
+    from cnn_quantization_amd import ops
+    for clip in ('laplace', 'gaus'):
+        with pytest.raises(L.CnnqError):
+            ops._params_cfg(16, False, clip, False, False, None, True, False)
+    assert ops._params_cfg(16, False, '2std', False, False, None, True, False).clip == 3
+    assert ops._params_cfg(16, False, 'no', False, False, None, True, False).clip == 0
 
 
 def test_geometry_plan_covers_resnet50_shapes():
