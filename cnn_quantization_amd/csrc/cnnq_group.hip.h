@@ -30,7 +30,7 @@
 //     plain loads; its own departure is counted after its stores are issued;
 //   * forward progress does not depend on dispatch order: the wait is bounded twice (20 ms of the 100 MHz clock,
 //     2^20 polls); a workgroup that gives up recomputes its channels' extrema from x itself (exact, hence the
-//     same bits) and raises bit 0 of the status word.
+//     same bits) and raises bit 0 of the status word (bit 1: the recompute was forced by the test hook, flags & 1).
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"
@@ -214,7 +214,7 @@ __device__ __forceinline__ unsigned* grp_lines(unsigned* cnt, int group, int Gs,
     return cnt + ((size_t)group * nex + ex) * grp_lines_per_group(Gs) * GRP_CNT_STRIDE;
 }
 
-// arrive and wait; returns 1 when the wait was given up (timeout, or flags & 1).  `on_sub_last()` runs in the LAST
+// arrive and wait; returns 1 when the wait expired, 2 when the test hook (flags & 1) skipped it, else 0.  `on_sub_last()` runs in the LAST
 // arriver of a sub-group, before it reports to the top line (two-level groups only): the place to fold the
 // sub-group's records.
 template <typename F>
@@ -238,7 +238,7 @@ __device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsig
             ready = true;
         }
     }
-    int timed_out = (flags & 1u) ? 1 : 0;
+    int timed_out = (flags & 1u) ? 2 : 0;      // 2: the test hook, 1: a wait that really expired (status bits 1 / 0)
     if (!timed_out && !ready) {
         const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals
         const unsigned want = (nsub > 1) ? 1u : m_i;
@@ -302,26 +302,12 @@ struct GWs {
 template <int A, int K>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_group(
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
-    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const int wave0) {
+    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags) {
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
     __shared__ int sh_timed_out;
     GRP_STAMP(0);
     const RBlk rb = rblk_of(g, Gs);
-    if ((int)blockIdx.x < wave0) {
-        // The workgroups of the FIRST dispatch wave all start within a microsecond and would stay in lockstep for the
-        // whole launch (every group loads, meets and stores at the same moments: HBM idles during the meetings and the
-        // next wave inherits the phase).  Groups of the first wave therefore start in P phases, D apart.
-        const unsigned P = (flags >> 4) & 15u, D = ((flags >> 8) & 255u) * 50u;   // D in units of 0.5 us
-        const unsigned ph = P ? (unsigned)rb.group % P : 0u;
-        if (ph) {
-            if (threadIdx.x == 0) {
-                const long long t0 = wall_clock64();
-                while (wall_clock64() - t0 < (long long)(ph * D)) __builtin_amdgcn_s_sleep(32);
-            }
-            __syncthreads();
-        }
-    }
     const Blk& b = rb.b;
     const int tid = threadIdx.x;
     const int col = b.col0 + tid;
@@ -360,7 +346,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     GRP_STAMP(3);
     if (tid == 0) {
         const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {});
-        if (timed_out) atomicOr(ws.status, 1u);
+        if (timed_out) atomicOr(ws.status, (unsigned)timed_out);   // bit 0: a wait expired, bit 1: the test hook
         sh_timed_out = timed_out;
         GRP_STAMP(4);
     }
@@ -441,6 +427,162 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     //      counter line re-arms it for the next launch
     GRP_STAMP(6);
     if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
+#ifdef GRP_TRACE
+    if (g_grp_trace && tid == 0)
+        g_grp_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+}
+
+// ---- flat tiles: every lane busy when a channel row is not a multiple of the workgroup --------------------------------
+// k_mmq_group cuts a channel row of H*W/4 float4 into nb pieces of <= 256 lanes: 56x56 (784 float4) gives 4 pieces of
+// 196, 28x28 one piece of 196 - a quarter of the lanes (registers, VALU slots, load slots) idles on 70 % of ResNet-50's
+// bytes.  Here a group is ONE channel and a member's tile is 256*K CONSECUTIVE float4 of the channel's flattened
+// [N][H*W/4] space: lane t's j-th load is element f0 + 256 j + t, which lives in sample (f / cpc) at column (f % cpc).
+// The walk is incremental and branch-free (a conditional around a load makes the compiler wait for the previous load):
+// byte offsets relative to the tile's first sample, 32 bits (the plan bounds a tile's rows * plane size below 4 GB).
+struct FGeo {
+    int N, C, HW, P;
+    unsigned cpc;         // float4 per channel row
+    unsigned total;       // N * cpc: float4 per channel (< 2^31)
+    int Gs;               // members (tiles) per channel
+    unsigned q256, r16;   // 256 / cpc and (256 % cpc) * 16: one step of 256 float4 in rows and in bytes
+    unsigned rs;          // bytes between two samples of the tensor (P * 4)
+};
+
+struct FWalk {
+    unsigned ro, co;      // row offset and column offset, bytes
+    __device__ __forceinline__ void step(const FGeo& g) {
+        co += g.r16;
+        ro += g.q256 * g.rs;
+        const bool wrap = co >= g.cpc * 16u;
+        co -= wrap ? g.cpc * 16u : 0u;
+        ro += wrap ? g.rs : 0u;
+    }
+};
+
+// one channel's extrema over the workgroup: wave shuffles, then the four wave results through LDS
+__device__ __forceinline__ void wg_minmax1(float tn, float tx, float* l_mn, float* l_mx, float& cmn, float& cmx) {
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
+    __syncthreads();                     // l_mn / l_mx may still be read from a previous call
+    if (lane == 0) { l_mn[wv] = tn; l_mx[wv] = tx; }
+    __syncthreads();
+    cmn = pmin(pmin(l_mn[0], l_mn[1]), pmin(l_mn[2], l_mn[3]));
+    cmx = pmax(pmax(l_mx[0], l_mx[1]), pmax(l_mx[2], l_mx[3]));
+}
+
+template <int K>
+__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat(
+    const float* __restrict__ x, float* __restrict__ y, const FGeo g, const int num_bits, const int positive, const GWs ws,
+    float* __restrict__ qp, float* __restrict__ mm, const unsigned flags) {
+    static_assert(TPB == 256, "wg_minmax1 folds four waves");
+    __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
+    __shared__ int sh_timed_out;
+    GRP_STAMP(0);
+    const int tid = threadIdx.x;
+    const int c = (int)blockIdx.x / g.Gs, member = (int)blockIdx.x - c * g.Gs;
+    const unsigned f0 = (unsigned)member * (256u * K);          // < total
+    const unsigned n_first = f0 / g.cpc;
+    const unsigned u = f0 + (unsigned)tid;
+    const unsigned n = u / g.cpc;
+    FWalk w0;
+    w0.ro = (n - n_first) * g.rs;
+    w0.co = (u - n * g.cpc) * 16u;
+    const unsigned long long lim64 = (unsigned long long)((unsigned)g.N - n_first) * g.rs;
+    const unsigned lim = lim64 > 0xffffffffull ? 0xffffffffu : (unsigned)lim64;   // row offsets below it are inside the batch
+    const size_t base = ((size_t)n_first * (size_t)g.P + (size_t)c * (size_t)g.HW) * 4;
+    const char* xb = reinterpret_cast<const char*>(x) + base;
+    char* yb = reinterpret_cast<char*>(y) + base;
+
+    // ---- the tile: K 16-byte loads per lane, back to back; past the end of the channel a lane re-reads the tile
+    //      base's row start (an element of the same channel: harmless for the extrema, never stored)
+    float v[K][4];
+    FWalk w = w0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+        ldv_nt<4>(reinterpret_cast<const float*>(xb + off), v[j]);
+        w.step(g);
+    }
+    // nothing that consumes a loaded value may be scheduled in between the loads (the scheduler otherwise folds the
+    // first rows into the extrema while it still has loads to issue, and waits for them first)
+    __builtin_amdgcn_sched_barrier(0);
+    GRP_STAMP(1);
+    float mn[1] = {INFINITY}, mx[1] = {-INFINITY};
+    bool nan = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j) lane_acc<1>(v[j], mn, mx, nan);
+    if (nan) { mn[0] = NAN; mx[0] = NAN; }
+    float cmn, cmx;
+    wg_minmax1(mn[0], mx[0], l_mn, l_mx, cmn, cmx);
+    GRP_STAMP(2);
+
+    // ---- publish, arrive, wait (the protocol of k_mmq_group; one pair per member)
+    unsigned long long* blk = ws.part + (size_t)c * ws.gstride;
+    if (tid == 0) {
+        __hip_atomic_store(blk + member, pack_pair(cmn, cmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair has left the CU
+        GRP_STAMP(3);
+        const int timed_out = grp_meet(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs, flags, [] {});
+        if (timed_out) atomicOr(ws.status, (unsigned)timed_out);
+        sh_timed_out = timed_out;
+        GRP_STAMP(4);
+    }
+    __syncthreads();
+    float tn = INFINITY, tx = -INFINITY;
+    if (sh_timed_out) {
+        // cold path: the channel's extrema straight from x, all samples
+        bool nn = false;
+        for (int s = 0; s < g.N; ++s)
+            for (unsigned col = (unsigned)tid; col < g.cpc; col += TPB) {
+                float t[4], a[1] = {tn}, b[1] = {tx};
+                ldv<4>(x + (size_t)s * (size_t)g.P + (size_t)c * (size_t)g.HW + (size_t)col * 4, t);
+                lane_acc<1>(t, a, b, nn);
+                tn = a[0];
+                tx = b[0];
+            }
+        if (nn) { tn = NAN; tx = NAN; }
+    } else {
+        for (int m = tid; m < g.Gs; m += TPB) {
+            float a, b;
+            unpack_pair(blk[m], a, b);
+            tn = pmin(tn, a);
+            tx = pmax(tx, b);
+        }
+    }
+    wg_minmax1(tn, tx, l_mn, l_mx, cmn, cmx);
+
+    // ---- scale / zero point (iq.py:559-572): every lane derives the same values from the same extrema
+    const float qm = qmax_of(num_bits);
+    const float offset = positive ? 0.f : cmn;
+    const float delta = cmx - offset;
+    float sc = delta / qm;
+    sc = (sc < 1e-8f) ? 1e-8f : sc;
+    const float zp = rintf(0.f - offset / sc);
+    if (member == 0 && tid == 0) {
+        qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
+        qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
+        qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
+        if (mm) { mm[c] = cmn; mm[g.C + c] = cmx; }
+    }
+    GRP_STAMP(5);
+
+    // ---- Q/DQ out of the registers.  The walk is repeated, and hidden from the optimiser: it would otherwise keep the
+    //      K offsets of the load phase alive across the meeting (K more registers than the tile leaves: spills)
+    w = w0;
+    asm volatile("" : "+v"(w.ro), "+v"(w.co));
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float o[4], cd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd);
+        if (w.ro < lim) stv_nt<4>(reinterpret_cast<float*>(yb + (w.ro + w.co)), o);
+        w.step(g);
+    }
+    GRP_STAMP(6);
+    if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);
 #ifdef GRP_TRACE
     if (g_grp_trace && tid == 0)
         g_grp_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |

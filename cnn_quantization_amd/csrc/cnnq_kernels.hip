@@ -406,8 +406,12 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
 
 // Config 2 in one launch and one read of x for tensors whose channels span several workgroups (cnnq_group.hip.h)
 size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW) {
-    GPlan p;
-    return plan_group(N, C, HW, true, &p) ? 0 : p.ws_bytes;
+    // the larger of the two tilings a caller may end up with (flat tiles for the single launch, row pieces for
+    // k_minmax_group's half of the multi-GPU path)
+    GPlan p, q;
+    const size_t a = plan_group(N, C, HW, true, &p) ? 0 : p.ws_bytes;
+    const size_t b = plan_group(N, C, HW, true, &q, /*allow_flat=*/false) ? 0 : q.ws_bytes;
+    return a > b ? a : b;
 }
 
 // The exchange workspace lives in fine-grained (uncached) device memory: the pairs one XCD writes must be what
@@ -428,6 +432,12 @@ int cnnq_group_ws_free(void* ws) { return ws ? (int)hipFree(ws) : CNNQ_EINVAL; }
 int cnnq_group_ws_status(const void* ws, uint32_t* status_host) {
     if (!ws || !status_host) return CNNQ_EINVAL;
     return (int)hipMemcpy(status_host, ws, sizeof(uint32_t), hipMemcpyDeviceToHost);
+}
+
+int cnnq_group_ws_status_clear(void* ws) {
+    if (!ws) return CNNQ_EINVAL;
+    const uint32_t zero = 0;
+    return (int)hipMemcpy(ws, &zero, sizeof(uint32_t), hipMemcpyHostToDevice);   // synchronises, like the read
 }
 
 #ifdef GRP_TRACE
@@ -479,7 +489,7 @@ int cnnq_pc_minmax_local_auto(const float* x, int64_t N, int64_t C, int64_t HW, 
     static const int64_t max_bytes = env_int("CNNQ_LOCAL_GROUP_MAX_MB", 384) * ((int64_t)1 << 20);   // development knob
     if (gws && !((uintptr_t)gws & 127) && N * C * HW * 4 <= max_bytes) {
         GPlan p;
-        if (plan_group(N, C, HW, al16(x), &p) == 0 && p.ws_bytes <= gws_bytes)
+        if (plan_group(N, C, HW, al16(x), &p, /*allow_flat=*/false) == 0 && p.ws_bytes <= gws_bytes)
             return launch_minmax_group(x, p, gws, local, (hipStream_t)stream);
     }
     return cnnq_pc_minmax_local(x, N, C, HW, pmm, local, stream);

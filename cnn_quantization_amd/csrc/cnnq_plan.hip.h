@@ -235,6 +235,8 @@ struct GPlan {
     int ngroups;   // groups = arrival counters
     int gstride;   // 8-byte pairs per group block (a multiple of 16 = 128 bytes)
     size_t ws_bytes;
+    int flat;      // 1: k_mmq_flat (a group = one channel, members = flat tiles of 256*K float4), geometry in fg
+    FGeo fg;
 };
 
 // ws layout, the SAME for every geometry (the counters must never alias another launch's pairs: they are only
@@ -244,9 +246,77 @@ constexpr size_t GRP_WS_HDR = 256;
 constexpr int GRP_MAX_LINES = 16384;   // counter lines (4 MB)
 constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_LINES * GRP_CNT_STRIDE * 4;
 
-int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p) {
+// flat tiles (k_mmq_flat) when a channel row is long enough that the row-piece tiling of k_mmq_group would idle lanes
+int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p) {
+    static const int allow = env_int("CNNQ_GRP_FLAT", 1);       // development knob
+    static const int forceK = env_int("CNNQ_GRP_K", 0);
+    static const int target = env_int("CNNQ_GRP_WGS", 1024);
+    if (!allow || HW % 4 != 0) return CNNQ_ENOTSUP;
+    const int64_t cpc = HW / 4;
+    if (cpc < 128 || C * HW >= (int64_t)1 << 31 || N * cpc >= (int64_t)1 << 31) return CNNQ_ENOTSUP;
+    if (cpc % TPB == 0) return CNNQ_ENOTSUP;     // the row pieces already fill every lane
+    const int64_t total = N * cpc;
+    int K = 8;
+    if (forceK == 8 || forceK == 16 || forceK == 32) {
+        K = forceK;
+    } else {
+        for (K = 32; K > 8; K >>= 1)
+            if (C * ((total + TPB * K - 1) / (TPB * K)) >= target) break;
+    }
+    while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
+    const int64_t Gs = (total + TPB * K - 1) / (TPB * K);
+    if (Gs > GRP_GS_MAX || Gs < 2) return CNNQ_ENOTSUP;
+    const int64_t rows = (TPB * K) / cpc + 3;                    // samples a tile can touch, with slack
+    if (rows * C * HW * 4 >= (int64_t)1 << 32) return CNNQ_ENOTSUP;
+    const int64_t nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    if (C * (nsub > 1 ? nsub + 1 : 1) > GRP_MAX_LINES) return CNNQ_ENOTSUP;
+    p->flat = 1;
+    p->v = {4, 1, 1};
+    p->K = K;
+    p->Gs = (int)Gs;
+    p->ngroups = (int)C;
+    p->gstride = (int)(((Gs + 15) / 16) * 16);
+    p->ws_bytes = GRP_WS_PAIRS + (size_t)C * p->gstride * 8;
+    FGeo& f = p->fg;
+    f.N = (int)N; f.C = (int)C; f.HW = (int)HW; f.P = (int)(C * HW);
+    f.cpc = (unsigned)cpc; f.total = (unsigned)total; f.Gs = (int)Gs;
+    f.q256 = (unsigned)(TPB / cpc); f.r16 = (unsigned)(TPB % cpc) * 16u; f.rs = (unsigned)(C * HW * 4);
+    // describe(): a Geo that tells the same story
+    p->g = Geo{};
+    p->g.N = (int)N; p->g.C = (int)C; p->g.HW = (int)HW; p->g.P = (int)(C * HW);
+    p->g.mode = 3; p->g.S = (int)Gs; p->g.ncb = (int)C; p->g.Cn = (int)C; p->g.nb = 1; p->g.k = 1;
+    return 0;
+}
+
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat);
+
+// plans are pure functions of their arguments (the development knobs are read once): the hot call asks for the same
+// handful of geometries over and over, so each host thread remembers the last 64
+int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true) {
+    struct Entry { int64_t N, C, HW; int key, rc; GPlan plan; };
+    constexpr int SLOTS = 64;
+    thread_local Entry cache[SLOTS];
+    thread_local int used = 0, next = 0;
+    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0);
+    for (int i = 0; i < used; ++i)
+        if (cache[i].N == N && cache[i].C == C && cache[i].HW == HW && cache[i].key == key) {
+            *p = cache[i].plan;
+            return cache[i].rc;
+        }
+    const int rc = plan_group_compute(N, C, HW, aligned16, p, allow_flat);
+    Entry& e = cache[next];
+    e.N = N; e.C = C; e.HW = HW; e.key = key; e.rc = rc; e.plan = *p;
+    next = (next + 1) % SLOTS;
+    if (used < SLOTS) ++used;
+    return rc;
+}
+
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat) {
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (!aligned16) return CNNQ_ENOTSUP;
+    p->flat = 0;
+    if (allow_flat && plan_flat(N, C, HW, p) == 0) return 0;
+    p->flat = 0;
     if (HW % 4 == 0) {
         p->v = {4, 1, 1};
     } else if ((C * HW) % 4 == 0) {
@@ -295,23 +365,15 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
-    // development knob: CNNQ_GRP_STAGGER="P,D" - P start phases D half-microseconds apart for the first dispatch wave
-    static const int stag = [] {
-        const char* e = getenv("CNNQ_GRP_STAGGER");
-        int P = 0, D = 0;
-        if (e && sscanf(e, "%d,%d", &P, &D) == 2 && P > 1 && P < 16 && D > 0 && D < 256) return (P << 4) | (D << 8);
-        return 0;
-    }();
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        return n;
-    }();
-    const int occ = p.K == 32 ? 3 : p.K == 16 ? 5 : 8;      // workgroups per CU (register-bound)
-    const int wave0 = stag ? cus * occ : 0;
-    flags |= (unsigned)stag;
+    if (p.flat) {
+        const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
+#define LAUNCH_F(K) hipLaunchKernelGGL((k_mmq_flat<K>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags)
+        if (p.K == 32) LAUNCH_F(32); else if (p.K == 16) LAUNCH_F(16); else LAUNCH_F(8);
+#undef LAUNCH_F
+        return launch_status();
+    }
 #define LAUNCH_G(A, K) \
-    hipLaunchKernelGGL((k_mmq_group<A, K>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, wave0)
+    hipLaunchKernelGGL((k_mmq_group<A, K>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags)
     if (p.v.A == 4) {
         if (p.K == 32) LAUNCH_G(4, 32); else if (p.K == 16) LAUNCH_G(4, 16); else if (p.K == 8) LAUNCH_G(4, 8); else LAUNCH_G(4, 4);
     } else {

@@ -250,14 +250,22 @@ def _group_workspace(x, st=None):
     return ws
 
 
-def group_status(x):
-    """Status word of this stream's group workspace (synchronises): bit 0 = some wait timed out and its workgroup
-    recomputed the extrema from x (results are unaffected)."""
+GROUP_WAIT_EXPIRED, GROUP_TEST_HOOK = 1, 2
+
+
+def group_status(x, clear=False):
+    """Status word of this stream's group workspace (synchronises).  Bit 0 (GROUP_WAIT_EXPIRED): a bounded wait of the
+    in-launch exchange ran out and its workgroup recomputed the extrema from x - results are unaffected, but the
+    launch was slow (a group's members were not co-resident: another kernel held the CUs).  Bit 1 (GROUP_TEST_HOOK):
+    the recompute path was forced by the test flag.  The word is sticky; clear=True zeroes it after the read."""
     ws = _GROUP_WS.get((x.device.index, _raw_stream(x.device.index)))
     if ws is None:
         return 0
     v = ctypes.c_uint32()
-    L.check(L.load().cnnq_group_ws_status(ws, ctypes.byref(v)), 'cnnq_group_ws_status')
+    lib = L.load()
+    L.check(lib.cnnq_group_ws_status(ws, ctypes.byref(v)), 'cnnq_group_ws_status')
+    if clear:
+        L.check(lib.cnnq_group_ws_status_clear(ws), 'cnnq_group_ws_status_clear')
     return int(v.value)
 
 

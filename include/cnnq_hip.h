@@ -271,6 +271,7 @@ size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW);
 int cnnq_group_ws_alloc(size_t bytes, void** ws);   /* allocates + zeroes, synchronises the device */
 int cnnq_group_ws_free(void* ws);
 int cnnq_group_ws_status(const void* ws, uint32_t* status_host);
+int cnnq_group_ws_status_clear(void* ws);
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              void* ws, float* qp, float* mm, unsigned flags, void* stream);

@@ -56,7 +56,7 @@ def test_local_extrema_one_launch(env, shape):
         out = local_auto(env, x)
         assert bits_equal(out.cpu(), ref.cpu()), (shape, rep)
     assert bits_equal(local_auto(env, x, use_gws=False).cpu(), ref.cpu())      # the two-launch form
-    assert ops.group_status(x) & ~1 == 0
+    assert ops.group_status(x) & ops.GROUP_WAIT_EXPIRED == 0
 
 
 def test_local_extrema_nan_and_shared_workspace(env):

@@ -42,6 +42,7 @@ def test_group_golden_bit_exact(ops, golden):
     from cnn_quantization_amd import _lib as L
     g = golden('act_pc')
     n = 0
+    ops.group_status(torch.empty(1, device='cuda'), clear=True)
     for key in g.np('names'):
         key = str(key)
         name, si = key.rsplit('_s', 1)
@@ -60,9 +61,15 @@ def test_group_golden_bit_exact(ops, golden):
             assert bits_equal(parts['stats'][L.STAT_MIN].cpu(), g.np('s%s_stat_min' % si)), key
         n += 1
     assert n == 12
+    # the forced recompute reported itself (bit 1), no wait expired (bit 0)
+    assert ops.group_status(x, clear=True) == ops.GROUP_TEST_HOOK
 
 
 SHAPES = [
+    # flat tiles (k_mmq_flat: a channel row that is not a multiple of 256 float4): ragged last tiles, rows shorter and
+    # longer than a workgroup, one- and two-level arrival
+    (40, 6, 56, 56), (300, 3, 56, 56), (130, 4, 28, 28), (512, 2, 28, 28), (20, 3, 112, 112), (33, 5, 24, 24),
+    (17, 3, 40, 52),
     (3, 8, 7, 7), (70, 40, 7, 7), (300, 24, 7, 7),          # straddling float4s; several column blocks and batch splits
     (2, 8, 14, 14), (37, 24, 14, 14), (64, 256, 14, 14), (200, 12, 14, 14),
     (5, 3, 28, 28), (33, 16, 28, 28), (130, 20, 28, 28),
@@ -80,6 +87,7 @@ def test_group_equals_chain_and_oracle(ops, shape, half):
     rc, d = describe(N, C, H * W)
     assert rc == 0
     yc = None
+    ops.group_status(torch.empty(1, device='cuda'), clear=True)
     for rnd in range(3):          # a different tensor every launch, the same (never re-zeroed) workspace
         x = torch.randn(shape, generator=gen) * (torch.rand(1, C, 1, 1, generator=gen) * 4 + 0.05) + \
             torch.randn(1, C, 1, 1, generator=gen)
@@ -89,18 +97,25 @@ def test_group_equals_chain_and_oracle(ops, shape, half):
         yc, pc = classic(ops, xd, 4, half)
         assert torch.equal(yc, y) and torch.equal(pc['qp'], parts['qp']), (shape, d, rnd)
     assert bits_equal(y.cpu(), O.act_per_channel_qdq(x, 4, half_range=half)), (shape, d)
-    assert ops.group_status(xd) in (0, 1)        # 1: the forced recompute of round 1 reported itself
+    # the forced recompute of round 1 reported itself (bit 1); no wait ever expired (bit 0)
+    assert ops.group_status(xd, clear=True) == ops.GROUP_TEST_HOOK
 
 
 def test_group_plans_cover_one_and_two_level_arrival():
+    """mode 3 = flat tiles (k_mmq_flat: 56x56 / 28x28 / 112x112), 1 / 2 = row pieces / whole channels (k_mmq_group)"""
     levels = set()
     for shape in SHAPES + [(512, 64, 112, 112), (512, 256, 56, 56), (512, 2048, 7, 7)]:
         rc, d = describe(shape[0], shape[1], shape[2] * shape[3])
         assert rc == 0
-        levels.add(1 if d['Gs'] <= 16 else 2)
-        assert d['S'] * d['K'] >= shape[0] and d['Gs'] <= 512
-    assert levels == {1, 2}
-    assert describe(512, 64, 112 * 112)[1]['Gs'] == 208
+        levels.add((d['mode'], 1 if d['Gs'] <= 16 else 2))
+        if d['mode'] == 3:
+            assert (d['Gs'] - 1) * 256 * d['K'] < shape[0] * shape[2] * shape[3] // 4 <= d['Gs'] * 256 * d['K']
+        else:
+            assert d['S'] * d['K'] >= shape[0]
+        assert d['Gs'] <= 512
+    assert levels >= {(3, 1), (3, 2), (2, 1), (2, 2)}, levels
+    assert describe(512, 256, 3136)[1]['mode'] == 3 and describe(512, 1024, 196)[1]['mode'] == 2
+    assert describe(512, 64, 112 * 112)[1]['Gs'] == 196          # 512 * 3136 float4 / (256 * 32)
 
 
 def test_group_nan_inf_follow_torch(ops):
@@ -152,7 +167,7 @@ def test_group_rearms_and_replays_from_a_graph(ops):
     torch.cuda.synchronize()
     ref, _ = classic(ops, x, 4, False)
     assert torch.equal(y, ref)
-    assert st == 0 and ops.group_status(x) in (0, 1)
+    assert st == 0 and ops.group_status(x) == 0
 
 
 @pytest.mark.parametrize('shape,half', [((512, 64, 112, 112), True), ((512, 256, 56, 56), False),
@@ -166,6 +181,7 @@ def test_group_full_size_properties(ops, shape, half):
     N, C, H, W = shape
     torch.manual_seed(12345)
     x = torch.empty(shape, device='cuda').normal_()
+    ops.group_status(x, clear=True)
     for rnd in range(2):
         x.mul_(torch.rand(1, C, 1, 1, device='cuda') * 3 + 0.1)
         y, parts = ops.minmax_qdq_group(x, N, C, H * W, 4, half, want_parts=True)
@@ -181,4 +197,4 @@ def test_group_full_size_properties(ops, shape, half):
         assert torch.equal(pc['qp'], qp)
         assert torch.equal(yc, y)
         del yc, y
-    assert ops.group_status(x) in (0, 1)
+    assert ops.group_status(x) == 0          # no wait expired on an idle GPU
