@@ -73,6 +73,9 @@ SIGNATURES = {
     'cnnq_pc_gathered_qdq': (_I, [_P, _P, _L, _L, _L, _P, _I, _I, _I, _P, _P]),
     'cnnq_pc_minmax_qdq_workspace': (ctypes.c_size_t, [_L, _L, _L]),
     'cnnq_pc_minmax_qdq_auto': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, ctypes.c_size_t, _I, _P]),
+    'cnnq_hist_replica_bytes': (ctypes.c_size_t, []),
+    'cnnq_pc_minmax_qdq_single': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P]),
+    'cnnq_entropy_replicas': (_I, [_P, _P, _P]),
     'cnnq_pc_aciq_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_aciq_qdq': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),

@@ -299,11 +299,15 @@ struct GWs {
     int gstride;   // pairs per group block
 };
 
-template <int A, int K>
+template <int A, int K, int OUT = 0>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_group(
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
-    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags) {
+    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}) {
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
+    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_zero(sh_hist);      // ordered before the first count by the barriers of the exchange
+    }
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
     __shared__ int sh_timed_out;
     GRP_STAMP(0);
@@ -410,18 +414,22 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     }
 
     // ---- Q/DQ out of the registers
+    unsigned nzp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) nzp[a] = 0u;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         if (j < nrows) {
-            float o[4], cd;
+            float o[4], cd[4];
 #pragma unroll
-#ifdef GRP_EXPERIMENT_CHEAP_ALU
-            for (int e = 0; e < 4; ++e) { cd = 0.f; o[e] = (v[j][e] + zp[A == 1 ? 0 : e]) * sc[A == 1 ? 0 : e]; }
-#else
-            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
-#endif
-            if (ok) stv_nt<4>(y + base + (size_t)j * (size_t)g.P, o);
+            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
+            if (ok)
+                xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o, cd,
+                               sh_hist, zp, nzp);
         }
+    }
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, zp, nzp);
     }
     // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
     //      counter line re-arms it for the next launch
@@ -473,12 +481,16 @@ __device__ __forceinline__ void wg_minmax1(float tn, float tx, float* l_mn, floa
     cmx = pmax(pmax(l_mx[0], l_mx[1]), pmax(l_mx[2], l_mx[3]));
 }
 
-template <int K>
+template <int K, int OUT = 0>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat(
     const float* __restrict__ x, float* __restrict__ y, const FGeo g, const int num_bits, const int positive, const GWs ws,
-    float* __restrict__ qp, float* __restrict__ mm, const unsigned flags) {
+    float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}) {
     static_assert(TPB == 256, "wg_minmax1 folds four waves");
     __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
+    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_zero(sh_hist);      // ordered before the first count by the barriers of the exchange
+    }
     __shared__ int sh_timed_out;
     GRP_STAMP(0);
     const int tid = threadIdx.x;
@@ -495,6 +507,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     const size_t base = ((size_t)n_first * (size_t)g.P + (size_t)c * (size_t)g.HW) * 4;
     const char* xb = reinterpret_cast<const char*>(x) + base;
     char* yb = reinterpret_cast<char*>(y) + base;
+    uint8_t* cbb = (OUT == 1 && xo.codes) ? xo.codes + base / 4 : nullptr;     // the tile's bases of the other outputs
+    uint8_t* pbb = (OUT == 2) ? xo.packed + base / 8 : nullptr;
 
     // ---- the tile: K 16-byte loads per lane, back to back; past the end of the channel a lane re-reads the tile
     //      base's row start (an element of the same channel: harmless for the extrema, never stored)
@@ -573,13 +587,18 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     //      K offsets of the load phase alive across the meeting (K more registers than the tile leaves: spills)
     w = w0;
     asm volatile("" : "+v"(w.ro), "+v"(w.co));
+    const float zpa[1] = {zp};
+    unsigned nzp[1] = {0u};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        float o[4], cd;
+        float o[4], cd[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd);
-        if (w.ro < lim) stv_nt<4>(reinterpret_cast<float*>(yb + (w.ro + w.co)), o);
+        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
+        if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
         w.step(g);
+    }
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, zpa, nzp);
     }
     GRP_STAMP(6);
     if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);

@@ -543,6 +543,44 @@ int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int6
     return cnnq_pc_minmax_qdq(x, y, N, C, HW, num_bits, positive, pmm, qp, nullptr, nullptr, stream);
 }
 
+// Config 2 in ONE launch with the outputs the chain form used to be needed for: the uint8 codes, the code histogram
+// (-me: iq.py:586-587) and / or the packed 4-bit codes INSTEAD of y (4.5 bytes per element straight from
+// x).  Routing as cnnq_pc_minmax_qdq_auto, without the chain: CNNQ_ENOTSUP when the shape has no single-launch kernel.
+size_t cnnq_hist_replica_bytes(void) { return (size_t)XHIST_REPLICAS * 256 * sizeof(unsigned long long); }
+
+int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                              void* gws, size_t gws_bytes, float* qp, float* mm, uint8_t* codes, uint64_t* hist_rep,
+                              uint8_t* packed, void* stream) {
+    if (!x || !qp || num_bits < 1 || num_bits > 32 || C <= 0) return CNNQ_EINVAL;
+    if (packed ? (y || codes || hist_rep || num_bits > 4 || ((uintptr_t)packed & 1)) : !y) return CNNQ_EINVAL;
+    if ((codes || hist_rep) && num_bits > 8) return CNNQ_EINVAL;
+    if (((uintptr_t)codes & 3) || ((uintptr_t)hist_rep & 7) || (gws && ((uintptr_t)gws & 127))) return CNNQ_EINVAL;
+    const int out = packed ? 2 : (codes || hist_rep) ? 1 : 0;
+    XOut xo;
+    xo.codes = codes;
+    xo.hist = reinterpret_cast<unsigned long long*>(hist_rep);
+    xo.packed = packed;
+    const bool al = al16(x) && (packed ? true : al16(y));
+    GPlan gp;
+    const bool group_ok = gws && plan_group(N, C, HW, al, &gp) == 0 && gp.ws_bytes <= gws_bytes;
+    WPlan wp;
+    const bool whole_ok = plan_whole(N, C, HW, al, &wp) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (whole_ok && !(group_ok && wp.wgs < RES_MIN_WGS))
+        return launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, out, xo);
+    if (group_ok) return launch_group(x, y, gp, num_bits, positive ? 1 : 0, gws, qp, mm, 0u, st, out, xo);
+    if (whole_ok) return launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, out, xo);
+    return CNNQ_ENOTSUP;
+}
+
+// entropy (bits) of the replica histogram the call above filled; the tables are zero again afterwards
+int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream) {
+    if (!hist_rep || !out) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_entropy_replicas, dim3(1), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned long long*>(hist_rep), out);
+    return launch_status();
+}
+
 // The whole dynamic ACIQ pipeline (iq.py:327-352 + 409-451) behind ONE call: statistics pass A, merge, pass B
 // when b is needed, merge, parameters (ACIQ clipping, bit allocation, scale / zero point), fused Q/DQ - six
 // launches (five since round 2: the first merge runs inside pass B), one host call, one caller workspace.  ws layout (doubles first): part[G][NMOM][C], mom[NMOM][C],

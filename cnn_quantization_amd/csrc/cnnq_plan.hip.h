@@ -207,11 +207,16 @@ int plan_whole(int64_t N, int64_t C, int64_t HW, bool aligned16, WPlan* p) {
     return CNNQ_ENOTSUP;
 }
 
+// out = 0: y; 1: y + codes / histogram; 2: packed 4-bit codes instead of y (the XOut of cnnq_qdq.hip.h)
 int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int positive, float* qp, float* mm,
-                 hipStream_t st) {
+                 hipStream_t st, int out = 0, const XOut& xo = XOut{}) {
     const dim3 grid((unsigned)p.wgs);
-#define LAUNCH_W(A, T, K) \
-    hipLaunchKernelGGL((k_mmq_whole<A, T, K>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm)
+#define LAUNCH_W(A, T, K)                                                                                                     \
+    do {                                                                                                                      \
+        if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, xo);      \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, xo); \
+        else hipLaunchKernelGGL((k_mmq_whole<A, T, K, 2>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, xo);               \
+    } while (0)
     if (p.A == 1) {
         if (p.T == 256) { if (p.K == 8) LAUNCH_W(1, 256, 8); else if (p.K == 16) LAUNCH_W(1, 256, 16); else LAUNCH_W(1, 256, 32); }
         else if (p.T == 512) { if (p.K == 16) LAUNCH_W(1, 512, 16); else LAUNCH_W(1, 512, 32); }
@@ -358,7 +363,7 @@ int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* 
 }
 
 int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
-                 unsigned flags, hipStream_t st) {
+                 unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}) {
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
@@ -367,13 +372,22 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
     if (p.flat) {
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
-#define LAUNCH_F(K) hipLaunchKernelGGL((k_mmq_flat<K>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags)
+#define LAUNCH_F(K)                                                                                                                  \
+    do {                                                                                                                             \
+        if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);      \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo); \
+        else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);               \
+    } while (0)
         if (p.K == 32) LAUNCH_F(32); else if (p.K == 16) LAUNCH_F(16); else LAUNCH_F(8);
 #undef LAUNCH_F
         return launch_status();
     }
-#define LAUNCH_G(A, K) \
-    hipLaunchKernelGGL((k_mmq_group<A, K>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags)
+#define LAUNCH_G(A, K)                                                                                                                     \
+    do {                                                                                                                                   \
+        if (out == 0) hipLaunchKernelGGL((k_mmq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);      \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo); \
+        else hipLaunchKernelGGL((k_mmq_group<A, K, 2>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);               \
+    } while (0)
     if (p.v.A == 4) {
         if (p.K == 32) LAUNCH_G(4, 32); else if (p.K == 16) LAUNCH_G(4, 16); else if (p.K == 8) LAUNCH_G(4, 8); else LAUNCH_G(4, 4);
     } else {

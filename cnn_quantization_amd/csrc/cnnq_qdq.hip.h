@@ -155,6 +155,69 @@ __global__ void __launch_bounds__(TPB) k_minmax_reduce(const float* __restrict__
 // group always hit 32 different banks however skewed the codes are (measured with 8 replicas: 90 %
 // of the LDS cycles were bank conflicts, ~18 cycles per atomic); flushed once per workgroup.
 constexpr int HREP = 32;
+
+// ---- extra outputs of the single-launch kernels (k_mmq_whole / k_mmq_group / k_mmq_flat) --------------------------
+// OUT = 0: y only.  OUT = 1: y, plus the uint8 codes and / or the code histogram (iq.py:586-587: the codes exist in the
+// reference only as the argument of shannon_entropy).  OUT = 2: the packed 4-bit codes INSTEAD of y (two per byte, the
+// layout of k_q_pack4): 4.5 bytes per element in one launch - the stored format of SURVEY 8 f3 straight from x.
+struct XOut {
+    uint8_t* codes;               // OUT 1, may be null
+    unsigned long long* hist;     // OUT 1, may be null: XHIST_REPLICAS tables of 256 bins; the workgroup flushes its LDS
+                                  // table into table (blockIdx & 63) - same-address chains of a few hundred atomics
+                                  // where one shared table would see 10^5; k_entropy_replicas sums and re-zeroes them
+    uint8_t* packed;              // OUT 2
+};
+constexpr int XHIST_REPLICAS = 64;
+
+__device__ __forceinline__ void xhist_zero(unsigned* sh_hist) {
+    for (int i = threadIdx.x; i < 256 * HREP; i += blockDim.x) sh_hist[i] = 0u;
+}
+// the zero point (the code of x == 0, about half of a post-ReLU layer) is counted in a register
+__device__ __forceinline__ void xhist_add(unsigned* sh_hist, float cd, float zp, unsigned& nzp) {
+    if (cd == zp) ++nzp;
+    else atomicAdd(&sh_hist[((unsigned)(int)cd & 255u) * HREP + (threadIdx.x & (HREP - 1))], 1u);
+}
+template <int A>
+__device__ __forceinline__ void xhist_flush(unsigned* sh_hist, unsigned long long* hist, const float (&zp)[A],
+                                            const unsigned (&nzp)[A]) {
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+        if (nzp[a]) atomicAdd(&sh_hist[((unsigned)(int)zp[a] & 255u) * HREP + (threadIdx.x & (HREP - 1))], nzp[a]);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int tid = threadIdx.x;
+        unsigned tot = 0;
+#pragma unroll 8
+        for (int r = 0; r < HREP; ++r) tot += sh_hist[tid * HREP + ((r + tid) & (HREP - 1))];
+        if (tot) atomicAdd(&hist[(size_t)(blockIdx.x & (XHIST_REPLICAS - 1)) * 256 + tid], (unsigned long long)tot);
+    }
+}
+// one float4 of results at byte offset `boff` (of the fp32 tensor) from the three bases: y, the codes (one byte per
+// element: boff / 4) and the packed nibbles (boff / 8).  OFF is size_t, or unsigned when the bases are per-workgroup
+// (uniform base + 32-bit lane offset is the addressing form the flat tiles load with)
+template <int OUT, int A, typename OFF>
+__device__ __forceinline__ void xstore(const XOut& xo, char* __restrict__ yb, uint8_t* __restrict__ cb, uint8_t* __restrict__ pb,
+                                       OFF boff, const float (&o)[4], const float (&cd)[4], unsigned* sh_hist,
+                                       const float (&zp)[A], unsigned (&nzp)[A]) {
+    if constexpr (OUT != 2) stv_nt<4>(reinterpret_cast<float*>(yb + boff), o);
+    if constexpr (OUT == 1) {
+        if (xo.codes) {
+            const uint32_t pk = ((uint32_t)cd[0] & 255u) | (((uint32_t)cd[1] & 255u) << 8) | (((uint32_t)cd[2] & 255u) << 16) |
+                                (((uint32_t)cd[3] & 255u) << 24);
+            __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(cb + boff / 4));
+        }
+        if (xo.hist) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xhist_add(sh_hist, cd[e], zp[A == 1 ? 0 : e], nzp[A == 1 ? 0 : e]);
+        }
+    }
+    if constexpr (OUT == 2) {
+        const unsigned pk = ((unsigned)cd[0] & 15u) | (((unsigned)cd[1] & 15u) << 4) | (((unsigned)cd[2] & 15u) << 8) |
+                            (((unsigned)cd[3] & 15u) << 12);
+        *reinterpret_cast<uint16_t*>(pb + boff / 8) = (uint16_t)pk;
+    }
+}
+
 #ifndef QDQ_NT
 #define QDQ_NT 3  // bit 0: non-temporal loads of x, bit 1: non-temporal stores of y
 #endif
@@ -361,6 +424,40 @@ __global__ void __launch_bounds__(TPB) k_entropy(const unsigned long long* __res
             const float pr = (float)c / total;
             e += (double)(-pr * log2f(pr));
         }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) e += shfl_xor_d(e, m);
+    __syncthreads();
+    if (lane == 0) sh[wv] = e;
+    __syncthreads();
+    if (tid == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// entropy of XHIST_REPLICAS replica tables (the histogram output of the single-launch kernels): fold them, hand the
+// folded table to the same arithmetic as k_entropy, and leave the tables zero for the next launch
+__global__ void __launch_bounds__(TPB) k_entropy_replicas(unsigned long long* __restrict__ rep, float* __restrict__ out) {
+    __shared__ unsigned long long bins[256];
+    __shared__ double sh[TPB / 64];
+    __shared__ double sh_total;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    unsigned long long c = 0;
+    for (int r = 0; r < XHIST_REPLICAS; ++r) {
+        c += rep[(size_t)r * 256 + tid];
+        rep[(size_t)r * 256 + tid] = 0ull;
+    }
+    bins[tid] = c;
+    double t = (double)c;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += shfl_xor_d(t, m);
+    if (lane == 0) sh[wv] = t;
+    __syncthreads();
+    if (tid == 0) sh_total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    const float total = (float)sh_total;
+    double e = 0.;
+    if (c) {
+        const float pr = (float)c / total;
+        e = (double)(-pr * log2f(pr));
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) e += shfl_xor_d(e, m);

@@ -50,11 +50,15 @@ struct WGeo {
     int RL;   // row lanes (<= N)
 };
 
-template <int A, int T, int K>
+template <int A, int T, int K, int OUT = 0>
 __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, float* __restrict__ y, const WGeo g,
                                                  const int num_bits, const int positive, float* __restrict__ qp,
-                                                 float* __restrict__ mm) {
+                                                 float* __restrict__ mm, const XOut xo = XOut{}) {
     __shared__ float l_mn[T * A], l_mx[T * A];
+    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_zero(sh_hist);      // the barriers of the reductions below order it before the first count
+    }
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH];   // per channel: extrema, then scale / zero point
     const int tid = threadIdx.x;
     const int c0 = (int)blockIdx.x * g.k;
@@ -155,13 +159,21 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     }
 
     // ---- Q/DQ out of the registers, sample by sample
+    unsigned nzp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) nzp[a] = 0u;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int n = rlc + j * g.RL;
-        float o[4], cd;
+        float o[4], cd[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd);
-        if (active && n < g.N) stv_nt<4>(y + (size_t)n * (size_t)g.P + colbase, o);
+        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
+        if (active && n < g.N)
+            xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, ((size_t)n * (size_t)g.P + colbase) * 4, o, cd,
+                           sh_hist, zp, nzp);
+    }
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, zp, nzp);
     }
 }
 

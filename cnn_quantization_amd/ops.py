@@ -41,9 +41,43 @@ def _dev_f32(x, what='tensor'):
     return x if x.is_contiguous() else x.contiguous()
 
 
+# switches, read ONCE at import (the hot call used to look three of them up per tensor: weak #10 of the round-2
+# review); reload_switches() re-reads them for callers that change the environment afterwards (tests, tools)
+def reload_switches():
+    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL
+    _RESIDENT = os.environ.get('CNNQ_RESIDENT', '1') != '0'            # 0: never take a single-launch kernel
+    _SINGLE_CODES = os.environ.get('CNNQ_SINGLE_CODES', '1') != '0'    # 0: codes / entropy requests take the chain
+    _EXCHANGE_OVERLAP = os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') == '1'
+    _P2P_EXCHANGE = os.environ.get('CNNQ_P2P_EXCHANGE', '0')
+    _DIRECT_RCCL = os.environ.get('CNNQ_DIRECT_RCCL', '1')
+    _XPLAN.clear()
+
+
+_XPLAN = {}     # per (group, device, stream, geometry): what the multi-GPU hot call needs, looked up once
+reload_switches()
+
 _SCRATCH = {}
 _WS_BYTES = {}
-_XPLAN = {}     # per (group, device, stream, geometry): what the multi-GPU hot call needs, looked up once
+
+
+def release_plans():
+    """Drop the cached multi-GPU exchange plans (they hold process groups and direct RCCL communicators): called by
+    rccl.close_all(), so that no plan outlives its communicator."""
+    _XPLAN.clear()
+
+
+def release_workspaces():
+    """Give back every cached buffer: scratch tensors, the replica histograms and the fine-grained exchange
+    workspaces of all streams (cnnq_group_ws_free).  Synchronises the device first; later calls re-allocate."""
+    torch.cuda.synchronize()
+    release_plans()
+    _SCRATCH.clear()
+    _HIST_REP.clear()
+    lib = L.load()
+    for ws in list(_GROUP_WS.values()) + [w for pool in _GROUP_POOL.values() for w in pool]:
+        lib.cnnq_group_ws_free(ws)
+    _GROUP_WS.clear()
+    _GROUP_POOL.clear()
 
 
 def _scratch(x, tag, nbytes, st=None):
@@ -215,7 +249,6 @@ GROUP_WS_BYTES = 16 << 20
 
 
 _GROUP_POOL = {}
-_GROUP_KEEP = []
 GROUP_POOL_SIZE = 4
 
 
@@ -230,12 +263,6 @@ def _group_workspace(x, st=None):
     key = (dev, _raw_stream(dev) if st is None else st)
     ws = _GROUP_WS.get(key)
     if ws is not None:
-        return ws
-    if os.environ.get('CNNQ_GROUP_WS_CACHED', '0') == '1':
-        # experiment switch: ordinary (L2-cached) device memory instead of the fine-grained allocation
-        t = torch.zeros(GROUP_WS_BYTES, dtype=torch.uint8, device=x.device)
-        _GROUP_KEEP.append(t)
-        ws = _GROUP_WS[key] = ctypes.c_void_p(t.data_ptr())
         return ws
     pool = _GROUP_POOL.setdefault(dev, [])
     if not pool:
@@ -318,20 +345,96 @@ def minmax_qdq_resident(x, N, C, HW, num_bits, positive=False, out=None, want_pa
     return y
 
 
+_HIST_REP = {}
+
+
+def _hist_replicas(x, st):
+    """The replica histogram of the single-launch kernels (cnnq_hist_replica_bytes), one per (device, stream), zeroed
+    ONCE: cnnq_entropy_replicas leaves it zero."""
+    key = (x.device.index, st)
+    t = _HIST_REP.get(key)
+    if t is None:
+        t = _HIST_REP[key] = torch.zeros(L.load().cnnq_hist_replica_bytes() // 8, dtype=torch.int64, device=x.device)
+    return t
+
+
+def minmax_qdq_single(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
+                      want_parts=False):
+    """Config 2 in ONE launch also when the codes and / or the entropy of the codes are wanted
+    (cnnq_pc_minmax_qdq_single; the entropy is one more tiny launch).  Returns None when the shape has no
+    single-launch kernel or the codes do not fit a byte (the caller takes the chain)."""
+    if num_bits > 8 and (want_codes or want_entropy):
+        return None
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    st = _raw_stream(x.device.index)
+    gws = _group_workspace(x, st)
+    y = _out_like(x, out)
+    qp = torch.empty((L.NQP + 2, C), dtype=torch.float32, device=x.device)
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+    hist = _hist_replicas(x, st) if want_entropy else None
+    rc = lib.cnnq_pc_minmax_qdq_single(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), gws,
+                                       GROUP_WS_BYTES if gws is not None else 0, _ptr(qp), _ptr(qp[L.NQP:]), _ptr(codes),
+                                       _ptr(hist), None, st)
+    if rc == L.ENOTSUP:
+        return None
+    L.check(rc, 'cnnq_pc_minmax_qdq_single')
+    res = [y]
+    if want_codes:
+        res.append(codes)
+    if want_entropy:
+        ent = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_entropy_replicas(_ptr(hist), _ptr(ent), st), 'cnnq_entropy_replicas')
+        res.append(ent[0])
+    if want_parts:
+        stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
+        stats[L.STAT_MIN] = qp[L.NQP]
+        stats[L.STAT_MAX] = qp[L.NQP + 1]
+        res.append(dict(stats=stats, qp=qp[:L.NQP], diag=None))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def minmax_quantize_pack4(x, num_bits=4, positive=False, out=None):
+    """Dynamic per-channel min/max quantization of x [N, C, H, W] straight to the STORED format: two 4-bit codes per
+    byte instead of the dequantized floats, in one launch and one read of x (4.5 bytes per element).
+    Returns (packed uint8 [numel / 2], qp [NQP, C]); dequantize_pack4(packed, x.shape, qp) gives back exactly what
+    act_qdq_per_channel(x, num_bits) returns.  None when the shape has no single-launch kernel."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    if num_bits > 4 or x.numel() % 2:
+        raise L.CnnqError('packed 4-bit storage needs num_bits <= 4 and an even number of elements')
+    N, C, HW = geometry(x)
+    st = _raw_stream(x.device.index)
+    gws = _group_workspace(x, st)
+    packed = torch.empty(x.numel() // 2, dtype=torch.uint8, device=x.device) if out is None else out
+    if out is not None and not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= x.numel() // 2):
+        raise L.CnnqError('out must be a contiguous uint8 device buffer of numel / 2 bytes')
+    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device)
+    rc = lib.cnnq_pc_minmax_qdq_single(_ptr(x), None, N, C, HW, int(num_bits), int(bool(positive)), gws,
+                                       GROUP_WS_BYTES if gws is not None else 0, _ptr(qp), None, None, None, _ptr(packed), st)
+    if rc == L.ENOTSUP:
+        return None
+    L.check(rc, 'cnnq_pc_minmax_qdq_single')
+    return packed, qp
+
+
 def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
-                     want_parts=False, group=None, _checked=False):
+                     want_parts=False, group=None, _checked=False, chain=False):
     """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials -> parameter table (one tiny
     launch) -> fused Q/DQ in descending address order; no host sync.
 
     World size > 1 (x is this rank's batch shard): the local extrema [2, C] are all-gathered and the
     parameter kernel reduces the W gathered pairs instead - exact, so the result is bit-identical to
-    a single GPU holding the whole batch."""
+    a single GPU holding the whole batch.
+
+    chain=True forces the three-launch chain (k_minmax -> k_minmax_params -> k_qdq) where a single-launch kernel
+    would otherwise run: the reference form the single-launch kernels are tested against."""
     lib = L.load()
     if not _checked:
         x = _dev_f32(x, 'x')
     world = D.world_size(group)
     exchanging = world > 1 or D.forced_exchange()
-    resident = os.environ.get('CNNQ_RESIDENT', '1') != '0'
+    resident = _RESIDENT and not chain
     if not exchanging and not (want_codes or want_entropy or want_parts):
         # the hot call: one C entry point, one cached workspace, no torch allocation besides the result
         key = (N, C, HW)
@@ -358,12 +461,11 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
             L.check(rc, 'cnnq_pc_minmax_qdq_auto')
         return y
     if (exchanging and not (want_codes or want_entropy or want_parts)
-            and os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') != '1'):
+            and not _EXCHANGE_OVERLAP):
         # the multi-GPU hot call: local extrema (one C call) -> all_gather of [2, C] -> parameters + Q/DQ (one C
         # call), all in cached workspaces; the collective is the only torch.distributed call
         st = _raw_stream(x.device.index)
-        p2p = os.environ.get('CNNQ_P2P_EXCHANGE', '0')
-        direct = os.environ.get('CNNQ_DIRECT_RCCL', '1')
+        p2p, direct = _P2P_EXCHANGE, _DIRECT_RCCL
         key = (id(group), x.device.index, st, N, C, HW, world, p2p, direct)
         plan = _XPLAN.get(key)
         if plan is None:
@@ -408,6 +510,11 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
             res = minmax_qdq_group(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
         if res is not None:
             return res
+    if not exchanging and resident and _SINGLE_CODES:
+        # codes / entropy out of the single launch too (round 3): no chain, no memset
+        res = minmax_qdq_single(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out, want_parts=want_parts)
+        if res is not None:
+            return res
     y = _out_like(x, out)
     G = max(lib.cnnq_pc_groups(N, C, HW, 1), lib.cnnq_pc_groups(N, C, HW, 0))
     if G <= 0:
@@ -419,7 +526,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     if not exchanging:
         L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
                                        _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
-    elif (os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') == '1' and C >= 8 and not want_codes and not want_entropy
+    elif (_EXCHANGE_OVERLAP and C >= 8 and not want_codes and not want_entropy
           and not want_parts):
         _minmax_qdq_pipelined(x, y, N, C, HW, num_bits, positive, group)
     else:

@@ -299,6 +299,21 @@ size_t cnnq_pc_minmax_qdq_workspace(int64_t N, int64_t C, int64_t HW);
 int cnnq_pc_minmax_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                             float* ws, void* gws, size_t gws_bytes, int allow_single_launch, void* stream);
 
+/* Config 2 in ONE launch with the outputs that otherwise need the three-launch chain (round 3): y, plus optionally
+ * `codes` (uint8, one per element, <= 8 bits; 4-byte aligned) and / or the code histogram `hist_rep`
+ * (cnnq_hist_replica_bytes() bytes, zeroed ONCE by the caller: cnnq_entropy_replicas folds the replica tables into the
+ * Shannon entropy of utils/entropy.py:6-17 - iq.py:586-587 - and leaves them zero) - or, with y == codes == hist_rep ==
+ * NULL, `packed`: the 4-bit codes two per byte INSTEAD of y (<= 4 bits; the layout of cnnq_pc_quantize_pack4, decoded by
+ * cnnq_pc_dequantize_pack4 with the qp this call writes): 4.5 bytes per element straight from x.
+ * gws / gws_bytes: the exchange workspace of cnnq_pc_minmax_qdq_group (may be NULL: whole-channel shapes only).
+ * qp[CNNQ_NQP][C] is written; mm[2][C] (may be NULL) receives the extrema.  CNNQ_ENOTSUP: the shape has no
+ * single-launch kernel (use cnnq_pc_minmax_qdq and friends). */
+size_t cnnq_hist_replica_bytes(void);
+int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                              void* gws, size_t gws_bytes, float* qp, float* mm, uint8_t* codes, uint64_t* hist_rep,
+                              uint8_t* packed, void* stream);
+int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
+
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace
  * prior) -> merge -> cnnq_pc_params(cfg) -> fused Q/DQ.  `ws`: caller workspace of cnnq_pc_aciq_workspace(...)

@@ -37,10 +37,12 @@ def _worker(rank, world, port, tmp):
     y = ops.act_qdq_per_channel(xs, 4, clip='laplace', bit_alloc=True)
     out['cfg3_y'] = y.cpu()
     os.environ['CNNQ_EXCHANGE_OVERLAP'] = '1'          # pipelined exchange: two channel halves in flight
+    ops.reload_switches()
     for half in (False, True):
         out['cfg2_overlap_y_%d' % half] = ops.act_qdq_per_channel(xs, 4, positive=half).cpu()
     os.environ['CNNQ_EXCHANGE_OVERLAP'] = '0'
     os.environ['CNNQ_P2P_EXCHANGE'] = '1'              # peer-to-peer exchange through hipIpc-mapped windows
+    ops.reload_switches()
     ex = D.p2p_exchange(None)
     out['p2p_ok'] = ex is not None
     for half in (False, True):
@@ -49,6 +51,7 @@ def _worker(rank, world, port, tmp):
     out['stats_p2p'] = st_p2p.cpu()                     # fp64 moment records travel as 32-bit words
     out['p2p_healthy'] = ex.healthy() if ex is not None else None
     os.environ['CNNQ_P2P_EXCHANGE'] = '0'
+    ops.reload_switches()
     st, mom = ops.pc_stats(xs, xs.shape[0], xs.shape[1], 14 * 14, need_b=True, need_kurt=True, need_relu=True)
     out['stats'] = st.cpu()
     # per-tensor calibration statistics (-sm collect without -pcq_a): global on every rank, one writer

@@ -30,9 +30,9 @@ def describe(N, C, HW):
 
 
 def classic(ops, x, bits, half):
-    """The three-launch chain: want_codes keeps it off the single-launch paths."""
+    """The three-launch chain: chain=True keeps it off the single-launch paths."""
     N, C = x.shape[:2]
-    y, codes, parts = ops.minmax_qdq_fused(x, N, C, x[0, 0].numel(), bits, half, want_codes=True, want_parts=True)
+    y, codes, parts = ops.minmax_qdq_fused(x, N, C, x[0, 0].numel(), bits, half, want_codes=True, want_parts=True, chain=True)
     return y, parts
 
 

@@ -45,7 +45,7 @@ for shape in ((6, 5, 28, 28), (3, 70, 7, 7), (4, 9, 3, 5), (2, 3, 70, 66), (7, 1
     st2, _ = ops.pc_stats(xd, N, C, HW, need_b=True)                                          # <.., false, true> instances
     assert torch.equal(st2.cpu()[:5], st[:5])
     for half in (False, True):                                                               # k_minmax<.., true> + k_qdq (the chain)
-        y, codes, parts = ops.minmax_qdq_fused(xd, N, C, HW, 4, half, want_codes=True, want_parts=True)
+        y, codes, parts = ops.minmax_qdq_fused(xd, N, C, HW, 4, half, want_codes=True, want_parts=True, chain=True)
         refy, rp = O.act_per_channel_qdq(x, 4, half_range=half, return_parts=True)
         assert np.array_equal(y.cpu().numpy().view(np.uint32), refy.numpy().view(np.uint32))
         assert torch.equal(codes.cpu().float(), rp['codes'])
@@ -110,7 +110,7 @@ def test_statistics_above_the_nt_threshold(ops, shape):
     np.testing.assert_allclose(st[L.STAT_KURT].cpu(), (z4 / n - 3).float().cpu(), rtol=1e-3, atol=1e-3)
     rv = (rss - rs * rs / n) / (n - 1)
     np.testing.assert_allclose(st[L.STAT_STD_POS].cpu(), rv.sqrt().float().cpu(), rtol=2e-6)
-    y1, codes, parts = ops.minmax_qdq_fused(x, N, C, H * W, 4, False, want_codes=True, want_parts=True)   # the chain
+    y1, codes, parts = ops.minmax_qdq_fused(x, N, C, H * W, 4, False, want_codes=True, want_parts=True, chain=True)
     assert int(codes.max()) <= 15
     qp = parts['qp']
     assert torch.equal((codes.float() - qp[1].view(1, C, 1, 1)) * qp[0].view(1, C, 1, 1), y1)
@@ -243,7 +243,7 @@ def test_nan_golden_case(ops, golden):
         N, C = x.shape[:2]
         HW = x[0, 0].numel()
         outs = {'auto': ops.act_qdq_per_channel(x.cuda(), 4, positive=half),
-                'chain': ops.minmax_qdq_fused(x.cuda(), N, C, HW, 4, half, want_codes=True)[0]}
+                'chain': ops.minmax_qdq_fused(x.cuda(), N, C, HW, 4, half, want_codes=True, chain=True)[0]}
         r = ops.minmax_qdq_resident(x.cuda(), N, C, HW, 4, half)
         if r is not None:
             outs['resident'] = r
@@ -338,7 +338,9 @@ def test_wide_per_channel_bits(ops, bits):
             assert bits_equal(ops.act_qdq_per_channel(x.cuda(), bits, positive=half).cpu(), ref), (shape, half)
             N, C = shape[:2]
             os.environ['CNNQ_RESIDENT'] = '0'
+            ops.reload_switches()
             try:
                 assert bits_equal(ops.act_qdq_per_channel(x.cuda(), bits, positive=half).cpu(), ref), (shape, half)
             finally:
                 os.environ['CNNQ_RESIDENT'] = '1'
+                ops.reload_switches()
