@@ -242,8 +242,14 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
     if constexpr (HIST) {
         if (nzero) {
             const int kk = -wstart;
-            if (kk >= 0 && kk < MT_W) atomicAdd(&sh_hist[hidx((unsigned)kk, tid)], nzero);
-            else atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
+            if (kk >= 0 && kk < MT_W) {
+                atomicAdd(&sh_hist[hidx((unsigned)kk, tid)], nzero);
+            } else {
+                // code 0 lies outside the window (a symmetric range with more than 2 * MT_W bins): its count goes to the
+                // global bins, and the flag word must say so - k_mt_entropy reads those bins only when it is raised
+                atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
+                atomicAdd(&hist[mt_flag_word(g.C)], 1ull);
+            }
         }
         __syncthreads();
         unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)g.C + (size_t)(blockIdx.x & (MT_GR - 1)) * MT_W;

@@ -15,12 +15,10 @@
 // (stores of sample j overlap the arithmetic of sample j+1).
 //
 // It applies when a channel block of the whole batch fits the register tile: RL*K >= N with K <= 32 (T <= 512) or
-// K <= 16 (T = 1024) - at batch 64 every ResNet-50 layer with H*W <= 28*28; larger per-channel populations
-// (56x56 and 112x112 at batch 64, everything at batch 512) stay on the two-pass chain, which already streams
-// them at 6+ TB/s.
-//
-// (A variant in which several workgroups share a channel and exchange {min, max} partials inside the launch -
-// arrival counters, bounded waits - was built and measured first: see DESIGN.md "tried and rejected".)
+// K <= 16 (T = 1024) - at batch 64 every ResNet-50 layer with H*W <= 28*28.  Larger per-channel populations (56x56 and
+// 112x112 at batch 64, everything at batch 512) take the kernels of cnnq_group.hip.h, in which the workgroups that
+// share a channel exchange their {min, max} partials inside the launch (k_mmq_flat / k_mmq_group): also one launch and
+// one read of x.  OUT selects the extra outputs shared by all three kernels (XOut in cnnq_qdq.hip.h).
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"

@@ -1,0 +1,64 @@
+"""The driver's bench.py contract on a small batch: exactly ONE JSON line on stdout with the agreed keys, the roofline
+and cpu_baseline objects, internally consistent numbers, every other_configs entry verified - and `--gpus 2` started as
+a PLAIN process (the form of the driver's N = 1 command) starts its own two ranks (VERDICT r2 missing #4; here both
+ranks share the one GPU over gloo).  Needs an MI355X: `pytest -m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = ((64, 112, 1), (256, 56, 4), (128, 56, 1), (512, 28, 5), (64, 56, 6), (256, 28, 1), (1024, 14, 7), (128, 28, 7),
+          (512, 14, 1), (2048, 7, 4), (256, 14, 11), (512, 7, 5))
+
+
+def run_bench(*extra, env=None):
+    e = dict(os.environ)
+    e.pop('WORLD_SIZE', None), e.pop('RANK', None), e.pop('LOCAL_RANK', None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(extra), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_json_line_contract():
+    d = run_bench('--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '8')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'verified', 'group_status',
+              'other_configs', 'ms_per_step_by_rank', 'rccl_ranks'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['verified'] is True
+    assert d['group_status'] == 0 and d['rccl_ranks'] == 0
+    assert d['unit'] == 'elements/s' and d['dtype'] == 'f32' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    elems = sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 8
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - elems) / elems < 1e-6       # value = elements / step time
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+    assert abs(r['achieved'] - r['bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9) / r['achieved'] < 1e-6
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'elements/s' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    oc = d['other_configs']
+    for k in ('config1', 'config2_entropy', 'config2_packed_single_launch', 'config3', 'config3_packed_storage',
+              'config3_packed_load', 'config4', 'config5'):
+        assert oc[k]['verified'] is True, k
+        assert oc[k]['roofline']['bound'] == 'hbm' and oc[k]['value'] > 0
+
+
+def test_plain_process_starts_its_own_ranks():
+    d = run_bench('--gpus', '2', '--batch', '64', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                  env={'CNNQ_BENCH_BACKEND': 'gloo'})
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['verified'] is True
+    assert d['config']['per_gpu_batch'] == 32 and d['config']['global_batch'] == 64
+    assert len(d['ms_per_step_by_rank']) == 2 and all(t > 0 for t in d['ms_per_step_by_rank'])
+    assert abs(max(d['ms_per_step_by_rank']) - d['ms_per_step']) / d['ms_per_step'] < 0.5
+    elems = sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 64
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - elems) / elems < 1e-6       # whole-job elements over the max time

@@ -71,3 +71,20 @@ def test_entropy_unclipped_weights(ops):
     ref = entropy_of(codes)
     assert abs(float(ent) - ref) < 2e-4 * max(1.0, ref)
     assert math.isfinite(float(ent))
+
+
+def test_entropy_zero_code_outside_the_window(ops):
+    """A symmetric clip with ~512 bins per channel puts code 0 beyond the 128-code window (it starts at the smallest
+    clamp bound, about -256): the register-counted zeros go to the global bins and must raise the flag word, or the
+    mode of the distribution is missing from the entropy.  Mostly-zero tensor: nothing else raises it."""
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.zeros(8, 16, 14, 14, device='cuda')
+    mask = torch.rand(x.shape, device='cuda', generator=g) < 0.02
+    x[mask] = torch.randn(int(mask.sum()), device='cuda', generator=g) * 0.01
+    y, ent, codes, parts = ops.mid_tread_qdq(x, 9.0, clip=True, sym=True, want_entropy=True, want_codes=True, want_parts=True)
+    from cnn_quantization_amd import _lib as L
+    assert int(parts['mt'][L.MT_WSTART][0]) + L.MT_HIST_WINDOW <= 0          # code 0 really is outside the window
+    ref = entropy_of(codes)
+    assert ref > 0.05
+    assert abs(float(ent) - ref) < 2e-4 * max(1.0, ref), (float(ent), ref)
+    assert int(parts['hist'][:-1].sum()) == x.numel()
