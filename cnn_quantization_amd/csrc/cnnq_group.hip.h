@@ -206,6 +206,10 @@ __device__ __forceinline__ void grp_leave(unsigned* ln, unsigned actors) {
 // launch leaves the workspace zero under any interleaving.
 // A group owns lines_per_group(Gs) consecutive lines per exchange (`nex` line sets per group for a kernel with
 // several exchanges per launch, `ex` selects one).
+inline int grp_lines_per_group_host(int Gs) {
+    const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    return nsub > 1 ? nsub + 1 : 1;
+}
 __device__ __forceinline__ int grp_lines_per_group(int Gs) {
     const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
     return nsub > 1 ? nsub + 1 : 1;

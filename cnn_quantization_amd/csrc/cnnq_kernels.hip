@@ -779,6 +779,54 @@ int cnnq_pt_setup(const float* range_offset_host, const float* stats, int64_t st
     return launch_status();
 }
 
+// config 1 behind one call AND one launch (k_pt_fused): x viewed as [rows][n / rows]; rows_mode 0: batch mean of the
+// per-row extrema (conv activations, iq.py:515-526), 1: the tensor's extrema.  gws: the exchange workspace of
+// cnnq_group_ws_alloc (its header region; zero between launches).  ptp_out (may be NULL): the eight parameters
+// cnnq_pt_setup would have written.  CNNQ_ENOTSUP: shapes the kernel does not take (rows not whole float4s, more than
+// 1024 rows, unaligned pointers, more 16 KB tiles than the workspace has records for) - use cnnq_pc_minmax + cnnq_pc_minmax_reduce + cnnq_pt_setup + cnnq_pt_qdq.
+int cnnq_pt_minmax_qdq_fused(const float* x, float* y, int64_t n, int rows, int rows_mode, int zero_min, int num_bits,
+                             int int_exp, int enforce_true_zero, void* gws, size_t gws_bytes, float* ptp_out, void* stream) {
+    if (!x || !y || !gws || gws_bytes < GRP_WS_PAIRS || n <= 0 || rows <= 0 || num_bits < 1 || num_bits > 31 || ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
+    if (n % rows) return CNNQ_EINVAL;
+    const int64_t L = n / rows;
+    if (L % 4 || rows > PTF_MAX_ROWS || !al16(x) || !al16(y) || L / 4 >= ((int64_t)1 << 31)) return CNNQ_ENOTSUP;
+    const int64_t L4 = L / 4;
+    const int64_t tpr = (L4 + PTF_TILE4 - 1) / PTF_TILE4;
+    if (tpr * rows >= ((int64_t)1 << 31) - 64) return CNNQ_ENOTSUP;
+    if ((size_t)(tpr * rows) * sizeof(uint4) > gws_bytes - GRP_WS_PAIRS) return CNNQ_ENOTSUP;     // one record per tile
+    char* base = reinterpret_cast<char*>(gws) + PTF_OFF;
+    PtfWs w;
+    w.status = reinterpret_cast<unsigned*>(gws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(gws) + GRP_WS_HDR);
+    w.epoch = reinterpret_cast<unsigned*>(base);
+    w.rows = reinterpret_cast<unsigned*>(base + 256);
+    w.recs = reinterpret_cast<uint4*>(reinterpret_cast<char*>(gws) + GRP_WS_PAIRS);   // write-before-read: garbage-tolerant
+    static_assert(PTF_OFF + 256 + (size_t)PTF_MAX_ROWS * 16 <= GRP_WS_HDR, "the fused per-tensor region must fit the header");
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+        return c;
+    }();
+    // a co-resident grid: 4 workgroups per CU of the 5 that fit (83 VGPRs, 13 KB of LDS), fewer when the tensor is small
+    const int64_t ntiles = tpr * rows;
+    int64_t G = (int64_t)cus * 4;
+    if (G > GRP_GS_MAX * 2) G = GRP_GS_MAX * 2;
+    if (G > ntiles) G = ntiles;
+    const int64_t per = (ntiles + G - 1) / G;
+    G = (ntiles + per - 1) / per;
+    if (grp_lines_per_group_host((int)G) > GRP_MAX_LINES) return CNNQ_ENOTSUP;
+    const dim3 grid((unsigned)G), block(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    // beyond the Infinity Cache the first sweep leaves nothing behind for the second: stream it
+    if (n * 4 > ((int64_t)192 << 20))
+        hipLaunchKernelGGL(k_pt_fused<true>, grid, block, 0, st, x, y, rows, (unsigned)L4, (unsigned)tpr, (unsigned)per, w,
+                           rows_mode, zero_min, num_bits, int_exp, enforce_true_zero, ptp_out);
+    else
+        hipLaunchKernelGGL(k_pt_fused<false>, grid, block, 0, st, x, y, rows, (unsigned)L4, (unsigned)tpr, (unsigned)per, w,
+                           rows_mode, zero_min, num_bits, int_exp, enforce_true_zero, ptp_out);
+    return launch_status();
+}
+
 int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const float* noise, void* stream) {
     if (!x || !y || !ptp || n <= 0) return CNNQ_EINVAL;
     const bool vec = al16(x) && al16(y) && (!noise || al16(noise));

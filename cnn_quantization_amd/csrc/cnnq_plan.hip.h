@@ -247,7 +247,9 @@ struct GPlan {
 // ws layout, the SAME for every geometry (the counters must never alias another launch's pairs: they are only
 // ever zero or mid-count; counters of different geometries may alias each other, every launch leaves them zero):
 // status word, GRP_MAX_LINES counter lines, then the pair blocks
-constexpr size_t GRP_WS_HDR = 256;
+// header: [0] the status word; [PTF_OFF ..) the region of the fused per-tensor kernel (cnnq_pertensor.hip.h: four
+// counter lines and one {max key, inverted min key} record per row), zero whenever no launch is in flight
+constexpr size_t GRP_WS_HDR = 65536;
 constexpr int GRP_MAX_LINES = 16384;   // counter lines (4 MB)
 constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_LINES * GRP_CNT_STRIDE * 4;
 

@@ -44,7 +44,8 @@ def _dev_f32(x, what='tensor'):
 # switches, read ONCE at import (the hot call used to look three of them up per tensor: weak #10 of the round-2
 # review); reload_switches() re-reads them for callers that change the environment afterwards (tests, tools)
 def reload_switches():
-    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL
+    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED
+    _PT_FUSED = os.environ.get('CNNQ_PT_FUSED', '0') == '1'           # 1: config 1 in one launch (slower: see ops.minmax_qdq_per_tensor)
     _RESIDENT = os.environ.get('CNNQ_RESIDENT', '1') != '0'            # 0: never take a single-launch kernel
     _SINGLE_CODES = os.environ.get('CNNQ_SINGLE_CODES', '1') != '0'    # 0: codes / entropy requests take the chain
     _EXCHANGE_OVERLAP = os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') == '1'
@@ -939,11 +940,28 @@ def tensor_row_stats(x, rows):
 
 
 def minmax_qdq_per_tensor(x, num_bits, avg_over_batch, zero_min=False, int_exp=False, enforce_true_zero=True,
-                          group=None):
+                          group=None, fused=None):
     """iq.py:361-379 + 605-614 with dynamic statistics: per-sample min/max, their batch mean
-    (or the whole-tensor min/max), then the GEMMLOWP kernel - all on the device."""
+    (or the whole-tensor min/max), then the GEMMLOWP kernel - all on the device, four launches.
+    fused=True (default: CNNQ_PT_FUSED=1) takes the ONE-launch form on a single GPU (cnnq_pt_minmax_qdq_fused): the same
+    bits, but measured SLOWER than the chain - 70 against 54 us on the [32,64,112,112] tensor of BASELINE config 1: its
+    second sweep is not served by the Infinity Cache once 103 MB of y are written next to it - so
+    it is opt-in."""
     x = _dev_f32(x, 'x')
     rows = x.shape[0] if x.dim() > 1 else 1
+    if (_PT_FUSED if fused is None else fused) and D.world_size(group) == 1 and x.numel() > 0:
+        # one launch (k_pt_fused): two sweeps with a tile count in between, the second served by the Infinity Cache
+        st = _raw_stream(x.device.index)
+        gws = _group_workspace(x, st)
+        if gws is not None:
+            y = torch.empty_like(x)
+            rc = L.load().cnnq_pt_minmax_qdq_fused(x.data_ptr(), y.data_ptr(), x.numel(), rows, 0 if avg_over_batch else 1,
+                                                   int(bool(zero_min)), int(num_bits), int(bool(int_exp)),
+                                                   int(bool(enforce_true_zero)), gws, GROUP_WS_BYTES, None, st)
+            if rc == 0:
+                return y
+            if rc != L.ENOTSUP:
+                L.check(rc, 'cnnq_pt_minmax_qdq_fused')
     stats = tensor_row_stats(x, rows)
     if D.world_size(group) > 1:
         stats = D.merge_row_minmax(stats, rows, avg_over_batch, group)

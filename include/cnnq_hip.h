@@ -383,6 +383,14 @@ int cnnq_pt_setup(const float* range_offset_host, const float* stats, int64_t st
                   int rows_mode, int zero_min, int num_bits, int int_exp, int enforce_true_zero, float* ptp,
                   void* stream);
 int cnnq_pt_qdq(const float* x, float* y, int64_t n, const float* ptp, const float* noise, void* stream);
+/* Config 1 in ONE launch (round 3): dynamic min / max of x viewed as [rows][n / rows] (rows_mode 0: batch mean of the
+ * per-row extrema, iq.py:515-526; 1: the tensor's extrema) -> range / offset -> the GEMMLOWP kernel above, the same
+ * bits as cnnq_pc_minmax + cnnq_pc_minmax_reduce + cnnq_pt_setup + cnnq_pt_qdq.  gws: an exchange workspace of
+ * cnnq_group_ws_alloc of gws_bytes bytes.  ptp_out[8] (may be NULL) receives the parameters.  CNNQ_ENOTSUP: rows that
+ * are not whole float4s, more than 1024 rows, unaligned pointers, a tensor of more 16 KB tiles than the workspace
+ * holds 16-byte records for (use the four calls). */
+int cnnq_pt_minmax_qdq_fused(const float* x, float* y, int64_t n, int rows, int rows_mode, int zero_min, int num_bits,
+                             int int_exp, int enforce_true_zero, void* gws, size_t gws_bytes, float* ptp_out, void* stream);
 
 /* KLD calibration (`-kld` with `-sm collect`): replaces the host loops of
  * inference/kld_threshold.py:6-84 (`get_kld_threshold_15bins`, one call per sample at
