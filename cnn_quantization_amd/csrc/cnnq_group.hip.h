@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
     __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_zero(sh_hist);      // ordered before the first count by the barriers of the exchange
+        if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
     __shared__ int sh_timed_out;
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         }
     }
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, zp, nzp);
+        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zp, nzp);
     }
     // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
     //      counter line re-arms it for the next launch
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
     __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_zero(sh_hist);      // ordered before the first count by the barriers of the exchange
+        if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }
     __shared__ int sh_timed_out;
     GRP_STAMP(0);
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         w.step(g);
     }
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, zpa, nzp);
+        if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zpa, nzp);
     }
     GRP_STAMP(6);
     if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);

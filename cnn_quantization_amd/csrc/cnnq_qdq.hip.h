@@ -169,8 +169,10 @@ struct XOut {
 };
 constexpr int XHIST_REPLICAS = 64;
 
-__device__ __forceinline__ void xhist_zero(unsigned* sh_hist) {
-    for (int i = threadIdx.x; i < 256 * HREP; i += blockDim.x) sh_hist[i] = 0u;
+// nbins = 2^num_bits (<= 256): only the bins the codes can reach are zeroed and flushed - 16 instead of 256 for int4,
+// i.e. 2 KB of LDS traffic per workgroup instead of 64
+__device__ __forceinline__ void xhist_zero(unsigned* sh_hist, int nbins) {
+    for (int i = threadIdx.x; i < nbins * HREP; i += blockDim.x) sh_hist[i] = 0u;
 }
 // the zero point (the code of x == 0, about half of a post-ReLU layer) is counted in a register
 __device__ __forceinline__ void xhist_add(unsigned* sh_hist, float cd, float zp, unsigned& nzp) {
@@ -178,13 +180,13 @@ __device__ __forceinline__ void xhist_add(unsigned* sh_hist, float cd, float zp,
     else atomicAdd(&sh_hist[((unsigned)(int)cd & 255u) * HREP + (threadIdx.x & (HREP - 1))], 1u);
 }
 template <int A>
-__device__ __forceinline__ void xhist_flush(unsigned* sh_hist, unsigned long long* hist, const float (&zp)[A],
+__device__ __forceinline__ void xhist_flush(unsigned* sh_hist, unsigned long long* hist, int nbins, const float (&zp)[A],
                                             const unsigned (&nzp)[A]) {
 #pragma unroll
     for (int a = 0; a < A; ++a)
         if (nzp[a]) atomicAdd(&sh_hist[((unsigned)(int)zp[a] & 255u) * HREP + (threadIdx.x & (HREP - 1))], nzp[a]);
     __syncthreads();
-    if (threadIdx.x < 256) {
+    if ((int)threadIdx.x < nbins) {
         const int tid = threadIdx.x;
         unsigned tot = 0;
 #pragma unroll 8

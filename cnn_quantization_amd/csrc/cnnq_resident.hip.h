@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     __shared__ float l_mn[T * A], l_mx[T * A];
     __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_zero(sh_hist);      // the barriers of the reductions below order it before the first count
+        if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // the barriers of the reductions below order it before the first count
     }
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH];   // per channel: extrema, then scale / zero point
     const int tid = threadIdx.x;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
                            sh_hist, zp, nzp);
     }
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, zp, nzp);
+        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zp, nzp);
     }
 }
 
