@@ -27,7 +27,8 @@
 //     than GRP_SUB members arrive in sub-groups whose last arrivers meet on a top counter; the very last raises one
 //     flag per sub-group (208 members on one word cost the 112x112 layer 60 % of its time);
 //   * lane 0 polls (relaxed sc1 load, s_sleep back-off 0.2 -> 1.7 us), every member then reads the group's block with
-//     plain loads; its own departure is counted after its stores are issued;
+//     relaxed agent-scope loads (sc1: they bypass the L1 like the poll; round 3 - the block is uncached memory either
+//     way, this only says so to the memory model); its own departure is counted after its stores are issued;
 //   * forward progress does not depend on dispatch order: the wait is bounded twice (20 ms of the 100 MHz clock,
 //     2^20 polls); a workgroup that gives up recomputes its channels' extrema from x itself (exact, hence the
 //     same bits) and raises bit 0 of the status word (bit 1: the recompute was forced by the test hook, flags & 1).
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         float tn = INFINITY, tx = -INFINITY;
         for (int m = tid; m < Gs; m += TPB) {
             float a, c;
-            unpack_pair(blk[m], a, c);
+            unpack_pair(__hip_atomic_load(blk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, c);
             tn = pmin(tn, a);
             tx = pmax(tx, c);
         }
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
 #pragma unroll 8
             for (int s = 0; s < Gs; ++s) {
                 float a, c;
-                unpack_pair(blk[(size_t)s * kk + ch], a, c);
+                unpack_pair(__hip_atomic_load(blk + ((size_t)s * kk + ch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, c);
                 tn = pmin(tn, a);
                 tx = pmax(tx, c);
             }
@@ -565,7 +566,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     } else {
         for (int m = tid; m < g.Gs; m += TPB) {
             float a, b;
-            unpack_pair(blk[m], a, b);
+            unpack_pair(__hip_atomic_load(blk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, b);
             tn = pmin(tn, a);
             tx = pmax(tx, b);
         }
@@ -661,7 +662,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_group(const float* __restrict__ 
         float tn = INFINITY, tx = -INFINITY;
         for (int m = tid; m < Gs; m += TPB) {
             float a, c;
-            unpack_pair(blk[m], a, c);
+            unpack_pair(__hip_atomic_load(blk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, c);
             tn = pmin(tn, a);
             tx = pmax(tx, c);
         }
@@ -674,7 +675,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_group(const float* __restrict__ 
 #pragma unroll 8
             for (int s = 0; s < Gs; ++s) {
                 float a, c;
-                unpack_pair(blk[(size_t)s * kk + ch], a, c);
+                unpack_pair(__hip_atomic_load(blk + ((size_t)s * kk + ch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, c);
                 tn = pmin(tn, a);
                 tx = pmax(tx, c);
             }
