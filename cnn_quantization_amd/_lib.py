@@ -52,6 +52,7 @@ SIGNATURES = {
     'cnnq_pc_dequantize_u8': (_I, [_P, _P, _L, _L, _L, _P, _P]),
     'cnnq_pc_packed_layout': (_I, [_P, _L, _L, _P, _P]),
     'cnnq_pc_quantize_packed': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
+    'cnnq_pc_quantize_packed_form': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _P]),
     'cnnq_pc_dequantize_packed': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
     'cnnq_pc_minmax': (_I, [_P, _L, _L, _L, _P, _P]),
     'cnnq_pc_minmax_strided': (_I, [_P, _L, _L, _L, _L, _P, _P]),

@@ -284,7 +284,7 @@ int cnnq_pc_dequantize_u8(const uint8_t* codes, float* y, int64_t N, int64_t C, 
 
 // variable-width packed codes (bit allocation as the stored format)
 static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, int64_t N, int64_t C, int64_t HW,
-                         const float* qp, const float* bits, const uint32_t* rowoff, void* stream) {
+                         const float* qp, const float* bits, const uint32_t* rowoff, void* stream, int form = 0) {
     if (!packed || !qp || !bits || !rowoff || N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (C * HW >= (int64_t)1 << 31 || N >= (int64_t)1 << 31 || C > 65535) return CNNQ_ERANGE;
     // k adjacent channels per workgroup: >= 512 eight-element groups per sample (16 KB contiguous) when the layer has
@@ -300,6 +300,27 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
     int64_t S = (N + rows - 1) / rows;
     if (S * ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
     if (k * ngroups >= (int64_t)1 << 24) return CNNQ_ERANGE;   // the in-loop index arithmetic is exact in fp32 below that
+    // round 3: the lean form (one channel per wave, scalar parameters) for whole-float4 rows; form 1 forces the general
+    // kernel, 2 the lean one (CNNQ_ENOTSUP when the geometry does not allow it)
+    if (quant && form != 1) {
+        const int64_t nsl = 2 * ngroups;
+        const int64_t rpc = nsl <= 128 ? 128 / nsl : 1;
+        const bool lean_ok = HW % 4 == 0 && al16(x) && rpc * C * HW * 4 < ((int64_t)1 << 32);
+        if (lean_ok) {
+            // ~8 KB of x per wave (32 KB per workgroup of four adjacent channels), whole chunks of rows
+            int64_t rpw = (8192 + HW * 2) / (HW * 4);
+            if (rpw < 1) rpw = 1;
+            rpw = ((rpw + rpc - 1) / rpc) * rpc;
+            const int64_t Sl = (N + rpw - 1) / rpw, ncb4 = (C + 3) / 4;
+            if (Sl * ncb4 >= (int64_t)1 << 31) return CNNQ_ERANGE;
+            const dim3 lgrid((unsigned)(Sl * ncb4)), lblock(TPB);
+            hipStream_t lst = (hipStream_t)stream;
+            if (nsl <= 128) hipLaunchKernelGGL(k_pack_lean<true>, lgrid, lblock, 0, lst, x, packed, (int)N, (int)C, (int)HW, (int)rpw, qp, bits, rowoff);
+            else hipLaunchKernelGGL(k_pack_lean<false>, lgrid, lblock, 0, lst, x, packed, (int)N, (int)C, (int)HW, (int)rpw, qp, bits, rowoff);
+            return launch_status();
+        }
+        if (form == 2) return CNNQ_ENOTSUP;
+    }
     const dim3 grid((unsigned)(ncb * S)), block(TPB);
     static const int64_t rows_min = env_int("CNNQ_PACK_ROWS_MIN", 256);   // development knob (slots per row)
     const bool rows_form = 2 * ngroups >= rows_min;
@@ -322,6 +343,14 @@ int cnnq_pc_quantize_packed(const float* x, uint8_t* packed, int64_t N, int64_t 
                             const float* bits, const uint32_t* rowoff, void* stream) {
     if (!x) return CNNQ_EINVAL;
     return packed_launch(true, x, nullptr, packed, N, C, HW, qp, bits, rowoff, stream);
+}
+
+// the same with the kernel form spelled out: 0 = the library's choice, 1 = the general kernel (any geometry), 2 = the
+// lean kernel (one channel per wave; CNNQ_ENOTSUP unless H*W % 4 == 0 and x is 16-byte aligned).  Same bytes.
+int cnnq_pc_quantize_packed_form(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
+                                 const float* bits, const uint32_t* rowoff, int form, void* stream) {
+    if (!x || form < 0 || form > 2) return CNNQ_EINVAL;
+    return packed_launch(true, x, nullptr, packed, N, C, HW, qp, bits, rowoff, stream, form);
 }
 
 int cnnq_pc_dequantize_packed(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,

@@ -371,4 +371,128 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_pack_lean (round 3): the quantize + pack pass for the common geometry - whole float4 slots (H*W % 4 == 0), aligned x.
+// k_packed<QUANT> is VALU-bound: ~350 vector instructions per 8 elements per lane, of which 8 IEEE divides + clamps +
+// roundings are 130; the rest is bookkeeping - every lane splits a flat slot index into (channel, slot) twice per chunk,
+// fetches three parameters per slot from LDS, tests widths per lane.  Here ONE WAVE owns one channel for a run of
+// samples, so scale / zero point / qmax / width / row offset are scalars (s_load, no LDS, no barrier: the four waves of
+// a workgroup take four ADJACENT channels of the same samples and never talk), and the lane -> (row, slot) map of a
+// chunk is computed once per wave lifetime:
+//   SHORT rows (<= 128 slots: 28x28 and smaller): a chunk = RPC whole rows of consecutive samples (lane q of the 128
+//          slot positions = slot q % nsl of row q / nsl; nsl = slots per row rounded up to even);
+//   long rows: a chunk = 128 consecutive slots of one row.
+// Both views as in k_packed: lane L loads slots L and 64 + L (two coalesced 16-byte accesses), quantizes them to 4 * b
+// code bits each, four wave shuffles hand lane G the two halves of group G (8 codes = b whole bytes), which it stores
+// with straight-line code selected by the scalar width.  The next chunk's loads are issued before the current chunk is
+// encoded.  Same bytes as k_packed<true, *> (tests compare the two forms).
+template <bool SHORT>
+__global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, uint8_t* __restrict__ packed, const int N,
+                                                   const int C, const int HW, const int rpw, const float* __restrict__ qp,
+                                                   const float* __restrict__ bits, const uint32_t* __restrict__ rowoff) {
+    const int lane = threadIdx.x & 63;
+    const int ncb = (C + 3) / 4;
+    const int s = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - s * ncb;
+    const int c = __builtin_amdgcn_readfirstlane(cb * 4 + (int)(threadIdx.x >> 6));      // the wave's channel: a scalar
+    if (c >= C) return;
+    const int b = (int)bits[c];
+    if (b == 0) return;                                                                   // a 0-bit channel stores nothing
+    const float sc = qp[(size_t)CNNQ_QP_SCALE * C + c], zp = qp[(size_t)CNNQ_QP_ZP * C + c], qm = qp[(size_t)CNNQ_QP_QMAX * C + c];
+    const uint32_t off_c = rowoff[c], plane = rowoff[C];
+    const int n0 = s * rpw, n1 = min(N, n0 + rpw);
+    const int nslots = HW / 4, ngroups = (HW + 7) / 8, nsl = 2 * ngroups;
+    const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
+    const size_t P = (size_t)C * (size_t)HW;
+    const int src = (2 * lane) & 63;
+    // the lane's two slots and its group inside a chunk
+    int ra = 0, rb = 0, rg = 0, sa, sb, gi;
+    int rpc = 1, cpr = 1;
+    if constexpr (SHORT) {
+        rpc = 128 / nsl;
+        ra = lane / nsl; sa = lane - ra * nsl;
+        rb = (64 + lane) / nsl; sb = 64 + lane - rb * nsl;
+        rg = lane / ngroups; gi = lane - rg * ngroups;
+    } else {
+        cpr = (nsl + 127) / 128;
+        sa = lane; sb = 64 + lane; gi = lane;
+    }
+    const int nchunks = SHORT ? (n1 - n0 + rpc - 1) / rpc : (n1 - n0) * cpr;
+    if (nchunks <= 0) return;
+    // chunk i -> its first sample, the lane's slots / group in it
+    auto chunk = [&](int i, int& nb, int& j) {
+        if constexpr (SHORT) { nb = n0 + i * rpc; j = 0; }
+        else { nb = n0 + i / cpr; j = i - (i / cpr) * cpr; }
+    };
+    auto load2 = [&](int i, float (&va)[4], float (&vb)[4], bool& oka, bool& okb) {
+        int nb, j;
+        chunk(i, nb, j);
+        const float* xs = x + ((size_t)nb * P + (size_t)c * (size_t)HW);     // uniform: the chunk's first row
+        const int qa = sa + j * 128, qb = sb + j * 128;                      // slot within the row
+        oka = qa < nslots && (SHORT ? (ra < rpc && nb + ra < n1) : true);
+        okb = qb < nslots && (SHORT ? (rb < rpc && nb + rb < n1) : true);
+        // unconditional loads (a branch around a load serialises the loads): dead lanes read the chunk's first slot
+        const unsigned oa = oka ? (unsigned)ra * (unsigned)P + (unsigned)qa * 4u : 0u;
+        const unsigned ob = okb ? (unsigned)rb * (unsigned)P + (unsigned)qb * 4u : 0u;
+        ldv_nt<4>(xs + oa, va);
+        ldv_nt<4>(xs + ob, vb);
+    };
+    auto half_of = [&](const float (&v)[4], bool ok) -> unsigned {
+        unsigned cds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float cd;
+            (void)qdq1(v[e], sc, zp, qm, cd);
+            cds[e] = (unsigned)cd;
+        }
+        const unsigned h = cds[0] | (cds[1] << b) | (cds[2] << (2 * b)) | (cds[3] << (3 * b));
+        return ok ? h : 0u;
+    };
+    float va[4], vb[4];
+    bool oka, okb;
+    load2(0, va, vb, oka, okb);
+    for (int i = 0; i < nchunks; ++i) {
+        float na[4], nbv[4];
+        bool noka, nokb;
+        load2(i + 1 < nchunks ? i + 1 : i, na, nbv, noka, nokb);             // unconditional prefetch (the last one repeats)
+        const unsigned ha = half_of(va, oka), hb = half_of(vb, okb);
+        const unsigned a0 = (unsigned)__shfl((int)ha, src, 64), b0 = (unsigned)__shfl((int)hb, src, 64);
+        const unsigned a1 = (unsigned)__shfl((int)ha, src + 1, 64), b1 = (unsigned)__shfl((int)hb, src + 1, 64);
+        const unsigned lo = lane < 32 ? a0 : b0, hi = lane < 32 ? a1 : b1;
+        const unsigned long long ww = (unsigned long long)lo | ((unsigned long long)hi << (4 * b));
+        int nb, j;
+        chunk(i, nb, j);
+        const int g_i = gi + j * 64;                                           // group within the row
+        const bool ghere = g_i < ngroups && (SHORT ? (rg < rpc && nb + rg < n1) : true);
+        if (ghere) {
+            uint8_t* g = packed + (size_t)(nb + rg) * plane + off_c + (uint32_t)g_i * (uint32_t)b;
+            if (g_i != ngroups - 1) {
+                const unsigned wl = (unsigned)ww, wh = (unsigned)(ww >> 32);
+                switch (b) {   // scalar
+                    case 8: *reinterpret_cast<unsigned long long*>(g) = ww; break;
+                    case 4: *reinterpret_cast<uint32_t*>(g) = wl; break;
+                    case 2: *reinterpret_cast<uint16_t*>(g) = (uint16_t)wl; break;
+                    case 6:
+                        *reinterpret_cast<uint16_t*>(g) = (uint16_t)wl;
+                        *reinterpret_cast<uint16_t*>(g + 2) = (uint16_t)(wl >> 16);
+                        *reinterpret_cast<uint16_t*>(g + 4) = (uint16_t)wh;
+                        break;
+                    case 7: g[6] = (uint8_t)(wh >> 16); [[fallthrough]];
+                    case 5: g[4] = (uint8_t)wh; if (b == 7) g[5] = (uint8_t)(wh >> 8); g[3] = (uint8_t)(wl >> 24); [[fallthrough]];
+                    case 3: g[2] = (uint8_t)(wl >> 16); g[1] = (uint8_t)(wl >> 8); [[fallthrough]];
+                    case 1: g[0] = (uint8_t)wl; break;
+                    default: break;
+                }
+            } else {
+                // the row's last group: everything up to the padded row end (<= b + 3 bytes), zeros beyond the codes
+                const uint32_t nbytes = rowbytes - (uint32_t)g_i * (uint32_t)b;
+                for (uint32_t kk = 0; kk < nbytes; ++kk) g[kk] = (uint8_t)(kk < 8 ? (ww >> (8 * kk)) : 0ull);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { va[e] = na[e]; vb[e] = nbv[e]; }
+        oka = noka;
+        okb = nokb;
+    }
+}
+
 }  // namespace

@@ -674,12 +674,13 @@ def packed_capacity(shape):
     return N * C * ((HW * 8 + 31) // 32 * 4)
 
 
-def quantize_packed(x, qp, bits, out=None):
+def quantize_packed(x, qp, bits, out=None, form=0):
     """x [N, C, H, W] + parameter table + per-channel bit widths (diag[DIAG_BITS] of pc_params with bit
     allocation) -> (packed uint8 [N * bytes_per_sample], rowoff int32 [C + 1]): bits[c] bits per code, i.e.
     sum(bits)/8 bytes per spatial position (cnnq_pc_quantize_packed).  Sizing the buffer exactly takes one host
     read of rowoff[C]; with `out` (a uint8 buffer of at least packed_capacity(x.shape) bytes) nothing synchronises
-    and the whole buffer is returned (the used prefix is N * rowoff[C] bytes)."""
+    and the whole buffer is returned (the used prefix is N * rowoff[C] bytes).  form: 0 = the library's choice, 1 = the
+    general kernel, 2 = the lean kernel (cnnq_pc_quantize_packed_form); every form writes the same bytes."""
     lib = L.load()
     x = _dev_f32(x, 'x')
     N, C, HW = geometry(x)
@@ -693,8 +694,8 @@ def quantize_packed(x, qp, bits, out=None):
     else:
         plane = int(rowoff[C].item())
         packed = torch.empty(max(N * plane, 4), dtype=torch.uint8, device=x.device)
-    L.check(lib.cnnq_pc_quantize_packed(_ptr(x), _ptr(packed), N, C, HW, _ptr(qp), _ptr(bits), _ptr(rowoff), _stream(x)),
-            'cnnq_pc_quantize_packed')
+    L.check(lib.cnnq_pc_quantize_packed_form(_ptr(x), _ptr(packed), N, C, HW, _ptr(qp), _ptr(bits), _ptr(rowoff), int(form),
+                                             _stream(x)), 'cnnq_pc_quantize_packed')
     return (packed if plane is None else packed[:N * plane]), rowoff
 
 

@@ -344,3 +344,24 @@ def test_wide_per_channel_bits(ops, bits):
             finally:
                 os.environ['CNNQ_RESIDENT'] = '1'
                 ops.reload_switches()
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 56, 56), (5, 20, 14, 14), (6, 12, 28, 28), (3, 7, 112, 112), (40, 8, 8, 8), (2, 5, 2, 2),
+                                   (9, 5, 6, 6), (33, 3, 40, 52), (64, 4, 224, 224)])
+def test_packed_forms_write_the_same_bytes(ops, shape):
+    """The lean quantize+pack kernel of round 3 (k_pack_lean: one channel per wave, scalar parameters; short rows take
+    several samples per chunk, long rows several chunks per row) against the general kernel: the same bytes, padding
+    included, for every width 0..8, rows of 4 (mod 8) elements, ragged sample ranges."""
+    from cnn_quantization_amd import _lib as L
+    gen = torch.Generator().manual_seed(sum(shape))
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=gen) * torch.exp(torch.randn(1, C, 1, 1, generator=gen) * 1.5) + 0.1).cuda()
+    y, parts = ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True, want_parts=True)
+    for bits in (parts['diag'][L.DIAG_BITS], torch.arange(C, device='cuda', dtype=torch.float32) % 9):
+        qp = parts['qp'].clone()
+        qp[L.QP_QMAX] = 2. ** bits - 1.                 # keep the codes inside the widths under test
+        a, ro_a = ops.quantize_packed(x, qp, bits, form=1)
+        b, ro_b = ops.quantize_packed(x, qp, bits, form=2)
+        c, _ = ops.quantize_packed(x, qp, bits)
+        assert torch.equal(ro_a, ro_b) and torch.equal(a, b) and torch.equal(a, c), shape
+        assert torch.equal(ops.dequantize_packed(b, shape, qp, bits, ro_b), ops.pc_qdq(x, N, C, H * W, qp))
