@@ -88,6 +88,10 @@ def _scratch(x, tag, nbytes, st=None):
     key = (x.device.index, _raw_stream(x.device.index) if st is None else st, tag)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # a buffer allocated now would live in the graph's private pool and yet stay cached here for eager use
+            raise L.CnnqError('scratch workspace %r (%d bytes) would be allocated inside a stream capture: run the call '
+                              'once on this stream before capturing' % (tag, nbytes))
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=x.device)
         _SCRATCH[key] = buf
     return buf
