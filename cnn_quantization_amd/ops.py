@@ -89,9 +89,10 @@ def _scratch(x, tag, nbytes, st=None):
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
-            # a buffer allocated now would live in the graph's private pool and yet stay cached here for eager use
-            raise L.CnnqError('scratch workspace %r (%d bytes) would be allocated inside a stream capture: run the call '
-                              'once on this stream before capturing' % (tag, nbytes))
+            # inside a stream capture the buffer comes from the graph's private pool: hand it out WITHOUT caching it
+            # (a cached one would later serve eager calls from memory that belongs to the graph); the pool keeps the
+            # block for the graph's replays and reuses it in capture order
+            return torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=x.device)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=x.device)
         _SCRATCH[key] = buf
     return buf
