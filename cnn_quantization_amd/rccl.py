@@ -52,7 +52,7 @@ class DirectComm:
         local_ok = True
         try:
             self.lib = _load()
-        except OSError as e:
+        except (OSError, AttributeError) as e:        # library not found, or a symbol this module binds is missing
             local_ok, self.why = False, 'librccl.so: %s' % e
         uid = _UniqueId()
         if local_ok and self.rank == 0:
