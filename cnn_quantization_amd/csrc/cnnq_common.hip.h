@@ -145,6 +145,15 @@ __device__ __forceinline__ double pmaxd(double a, double b) { return (a > b || a
 
 // qmax = 2.**num_bits - 1. (iq.py:559: a Python float, i.e. fp64, rounded to fp32 when it meets the tensor): exact up
 // to 24 bits, 2^32 for 'int32' - any width the reference's __gemmlowpQuantize1__ accepts
+// zero_point = round(qmin - offset / scale) with qmin = 0 (iq.py:570-572): +0 when the quotient is +-0.  The compiler
+// otherwise folds rint(0 - q) into rint(-q), which is -0 for q = +0 (seen in k_minmax_params' ISA: `v_rndne_f32 -v`);
+// the values agree, the bits of the parameter table would not.
+__device__ __forceinline__ float zero_point_of(float offset, float scale) {
+    float t = 0.f - offset / scale;
+    asm volatile("" : "+v"(t));
+    return rintf(t);
+}
+
 __device__ __host__ __forceinline__ float qmax_of(int num_bits) { return (float)(exp2((double)num_bits) - 1.0); }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }

@@ -243,7 +243,7 @@ __device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsig
             ready = true;
         }
     }
-    int timed_out = (flags & 1u) ? 2 : 0;      // 2: the test hook, 1: a wait that really expired (status bits 1 / 0)
+    int timed_out = (flags & MMQ_FLAG_TEST_HOOK) ? 2 : 0;      // 2: the test hook, 1: a wait that really expired (status bits 1 / 0)
     if (!timed_out && !ready) {
         const unsigned* pw = (nsub > 1) ? line + 2 : line;     // two levels: the flag; one level: the arrivals
         const unsigned want = (nsub > 1) ? 1u : m_i;
@@ -313,8 +313,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }
-    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH];
-    __shared__ int sh_timed_out;
+    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH], sh_rs[MAXCH];
+    __shared__ int sh_timed_out, sh_slow;
+    if (threadIdx.x == 0) sh_slow = 0;      // the barriers of the reduction and of the exchange come before its writers
     GRP_STAMP(0);
     const RBlk rb = rblk_of(g, Gs);
     const Blk& b = rb.b;
@@ -396,9 +397,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         const float delta = cmx - offset;
         float sc = delta / qm;
         sc = (sc < 1e-8f) ? 1e-8f : sc;
-        const float zp = rintf(0.f - offset / sc);
+        const float zp = zero_point_of(offset, sc);
         sh_sc[ch] = sc;
         sh_zp[ch] = zp;
+        sh_rs[ch] = 1.0f / sc;
+        if (!qdq_fast_domain(cmn, cmx, sc) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
         if (rb.member == 0) {
             const int c = b.c0 + ch;
             qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
@@ -422,15 +425,37 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     unsigned nzp[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) nzp[a] = 0u;
+    if (!__builtin_amdgcn_readfirstlane(sh_slow)) {
+        // every channel of the block inside qdq_fast_domain: the exact quotient without the divide
+        float rs[A];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < nrows) {
-            float o[4], cd[4];
+        for (int a = 0; a < A; ++a) {
+            const unsigned e = (unsigned)colc * 4u + (unsigned)a;
+            rs[a] = sh_rs[(int)(e / (unsigned)g.HW) - b.c0];
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
-            if (ok)
-                xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o, cd,
-                               sh_hist, zp, nzp);
+        for (int j = 0; j < K; ++j) {
+            if (j < nrows) {
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = qdq1_fast(v[j][e], sc[A == 1 ? 0 : e], rs[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
+                if (ok)
+                    xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o,
+                                   cd, sh_hist, zp, nzp);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < nrows) {
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
+                if (ok)
+                    xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o,
+                                   cd, sh_hist, zp, nzp);
+            }
         }
     }
     if constexpr (OUT == 1) {
@@ -579,7 +604,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     const float delta = cmx - offset;
     float sc = delta / qm;
     sc = (sc < 1e-8f) ? 1e-8f : sc;
-    const float zp = rintf(0.f - offset / sc);
+    const float zp = zero_point_of(offset, sc);
+    const bool fast = qdq_fast_domain(cmn, cmx, sc) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
     if (member == 0 && tid == 0) {
         qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
         qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
@@ -594,13 +620,27 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     asm volatile("" : "+v"(w.ro), "+v"(w.co));
     const float zpa[1] = {zp};
     unsigned nzp[1] = {0u};
+    if (__builtin_amdgcn_readfirstlane((int)fast)) {
+        // the channel's values are inside qdq_fast_domain: the exact quotient without the divide, parameters in
+        // scalar registers (one channel per workgroup)
+        const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp);
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        float o[4], cd[4];
+        for (int j = 0; j < K; ++j) {
+            float o[4], cd[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
-        if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-        w.step(g);
+            for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], s_sc, s_rs, s_zp, qm, cd[e]);
+            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            w.step(g);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float o[4], cd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
+            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            w.step(g);
+        }
     }
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zpa, nzp);

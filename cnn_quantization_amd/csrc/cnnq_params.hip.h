@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats
             scale = delta / qmax;
         }
         scale = (scale < 1e-8f) ? 1e-8f : scale;  // NaN stays NaN, as torch.max does
-        const float zp = rintf(0.f - offset / scale);
+        const float zp = zero_point_of(offset, scale);
         qp[(size_t)CNNQ_QP_SCALE * C + c] = scale;
         qp[(size_t)CNNQ_QP_ZP * C + c] = zp;
         qp[(size_t)CNNQ_QP_QMAX * C + c] = qmax;

@@ -208,14 +208,21 @@ int plan_whole(int64_t N, int64_t C, int64_t HW, bool aligned16, WPlan* p) {
 }
 
 // out = 0: y; 1: y + codes / histogram; 2: packed 4-bit codes instead of y (the XOut of cnnq_qdq.hip.h)
+// CNNQ_IEEE_DIVIDE=1: the single-launch kernels take the hardware divide for every channel (A/B against qdq1_fast)
+inline unsigned mmq_env_flags() {
+    static const unsigned f = env_int("CNNQ_IEEE_DIVIDE", 0) ? MMQ_FLAG_IEEE_DIVIDE : 0u;
+    return f;
+}
+
 int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int positive, float* qp, float* mm,
-                 hipStream_t st, int out = 0, const XOut& xo = XOut{}) {
+                 hipStream_t st, int out = 0, const XOut& xo = XOut{}, unsigned flags = 0u) {
     const dim3 grid((unsigned)p.wgs);
+    flags |= mmq_env_flags();
 #define LAUNCH_W(A, T, K)                                                                                                     \
     do {                                                                                                                      \
-        if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, xo);      \
-        else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, xo); \
-        else hipLaunchKernelGGL((k_mmq_whole<A, T, K, 2>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, xo);               \
+        if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);      \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo); \
+        else hipLaunchKernelGGL((k_mmq_whole<A, T, K, 2>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);               \
     } while (0)
     if (p.A == 1) {
         if (p.T == 256) { if (p.K == 8) LAUNCH_W(1, 256, 8); else if (p.K == 16) LAUNCH_W(1, 256, 16); else LAUNCH_W(1, 256, 32); }
@@ -366,6 +373,7 @@ int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* 
 
 int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
                  unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}) {
+    flags |= mmq_env_flags();
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);

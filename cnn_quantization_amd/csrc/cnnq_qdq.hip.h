@@ -19,6 +19,45 @@ __device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax
     return (q - zp) * scale;
 }
 
+// The same function without the hardware divide, for callers that KNOW the channel's value range (the single-launch
+// kernels hold the channel's exact extrema before they quantize).  IEEE x / s on gfx950 is v_div_scale x2, v_rcp (quarter
+// rate), five fma, v_div_fmas, v_div_fixup; with rs = RN(1 / s) computed once per channel by the real divide, the quotient
+// is the same two-correction sequence the hardware macro runs (q0 = x rs; r0 = x - s q0; q1 = q0 + r0 rs; r1 = x - s q1;
+// q = q1 + r1 rs - every step one rounding, the remainders exact), minus the range scaling and the fix-up, which are what
+// the domain below makes unnecessary:
+//   * s in [1e-8, 2^30] and every |x| of the channel <= 2^70, no NaN (qdq_fast_domain on the channel's extrema);
+//   * for 2^-70 <= |x| every intermediate is a normal number (|q| in [2^-100, 2^100], remainders multiples of
+//     2^(ex-46) >= 2^-116), so q1 is a faithful and q the correctly rounded quotient (Markstein's theorem: rs is the
+//     correctly rounded reciprocal) - bit-identical to x / s;
+//   * for |x| < 2^-70 (zeros, denormals) the exact quotient and this one are both below 2^-39 in magnitude: q + zp rounds
+//     to zp when zp != 0, and for zp == 0 (zp is never -0) both clamp / round to +0 - the same code and the same y.
+// No NaN can occur inside the domain, so the clamp is one v_med3_f32 instead of two compare+select pairs.
+// 10 VALU operations per element against 19 (of which one quarter-rate).  tests/test_fastdiv_cpu.py brute-forces the
+// quotient against the C divide; the -m gpu parity tests compare whole tensors with the oracle bit for bit.
+constexpr unsigned MMQ_FLAG_TEST_HOOK = 1u;     // group kernels: skip the wait, recompute (tests)
+constexpr unsigned MMQ_FLAG_IEEE_DIVIDE = 2u;   // every channel through the hardware divide (tests, A/B: CNNQ_IEEE_DIVIDE=1)
+
+__device__ __forceinline__ bool qdq_fast_domain(float cmn, float cmx, float scale) {
+    return fabsf(cmn) <= 0x1p70f && fabsf(cmx) <= 0x1p70f && scale <= 0x1p30f;   // false for NaN / Inf extrema
+}
+
+__device__ __forceinline__ float qdq1_fast(float x, float scale, float rs, float zp, float qmax, float& code) {
+    float q = x * rs;
+    float r = __builtin_fmaf(-scale, q, x);
+    q = __builtin_fmaf(r, rs, q);
+    r = __builtin_fmaf(-scale, q, x);
+    q = __builtin_fmaf(r, rs, q);
+    q = q + zp;
+    q = __builtin_amdgcn_fmed3f(q, 0.f, qmax);
+    q = rintf(q);
+    code = q;
+    return (q - zp) * scale;
+}
+
+__device__ __forceinline__ float uniform_f(float v) {   // a value every lane of the wave holds: into a scalar register
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 // Exact per-channel min / max for config 2 and the per-tensor paths.  Each workgroup writes ONE
 // {min, max} pair per channel it owns into pmm[G][2][C] (plain stores, every (group, channel) entry
 // written exactly once: no atomics, no initialisation, deterministic); k_minmax_params /
@@ -240,7 +279,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_params(const float* __restrict__
     float sc = delta / qm;
     sc = (sc < 1e-8f) ? 1e-8f : sc;
     qp[(size_t)CNNQ_QP_SCALE * C + c] = sc;
-    qp[(size_t)CNNQ_QP_ZP * C + c] = rintf(0.f - offset / sc);
+    qp[(size_t)CNNQ_QP_ZP * C + c] = zero_point_of(offset, sc);
     qp[(size_t)CNNQ_QP_QMAX * C + c] = qm;
 }
 
@@ -268,7 +307,7 @@ __device__ __forceinline__ void gathered_params(const float* __restrict__ rec, c
     qm = qmax_of(ga.num_bits);
     sc = delta / qm;
     sc = (sc < 1e-8f) ? 1e-8f : sc;
-    zp = rintf(0.f - offset / sc);
+    zp = zero_point_of(offset, sc);
 }
 
 template <int VEC, int A, int J, bool CODES, bool HIST, bool GATH = false>

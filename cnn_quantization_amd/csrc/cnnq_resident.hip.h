@@ -51,8 +51,11 @@ struct WGeo {
 template <int A, int T, int K, int OUT = 0>
 __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, float* __restrict__ y, const WGeo g,
                                                  const int num_bits, const int positive, float* __restrict__ qp,
-                                                 float* __restrict__ mm, const XOut xo = XOut{}) {
+                                                 float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}) {
     __shared__ float l_mn[T * A], l_mx[T * A];
+    __shared__ float sh_rs[MAXCH];
+    __shared__ int sh_slow;
+    if (threadIdx.x == 0) sh_slow = 0;      // the barriers of the reductions come before its writers
     __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // the barriers of the reductions below order it before the first count
@@ -139,36 +142,62 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
         const float delta = cmx - offset;
         p_sc = delta / qm;
         p_sc = (p_sc < 1e-8f) ? 1e-8f : p_sc;
-        p_zp = rintf(0.f - offset / p_sc);
+        p_zp = zero_point_of(offset, p_sc);
         const int c = c0 + tid;
         qp[(size_t)CNNQ_QP_SCALE * g.C + c] = p_sc;
         qp[(size_t)CNNQ_QP_ZP * g.C + c] = p_zp;
         qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
         if (mm) { mm[c] = cmn; mm[g.C + c] = cmx; }
     }
-    if (tid < nch) { sh_mn[tid] = p_sc; sh_mx[tid] = p_zp; }   // own entry only: no hazard with the reads above
+    if (tid < nch) {
+        if (!qdq_fast_domain(sh_mn[tid], sh_mx[tid], p_sc) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
+        sh_mn[tid] = p_sc;   // own entry only: no hazard with the reads above
+        sh_mx[tid] = p_zp;
+        sh_rs[tid] = 1.0f / p_sc;
+    }
     __syncthreads();
-    float sc[A], zp[A];
+    float sc[A], zp[A], rs[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         const int ch = (int)(((unsigned)clc * 4u + (unsigned)a) / (unsigned)g.HW);
         sc[a] = sh_mn[ch];
         zp[a] = sh_mx[ch];
+        rs[a] = sh_rs[ch];
     }
+    const bool fast = !__builtin_amdgcn_readfirstlane(sh_slow);   // every channel of the workgroup inside qdq_fast_domain
 
     // ---- Q/DQ out of the registers, sample by sample
     unsigned nzp[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) nzp[a] = 0u;
+    if (fast) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const int n = rlc + j * g.RL;
-        float o[4], cd[4];
+        for (int j = 0; j < K; ++j) {
+            const int n = rlc + j * g.RL;
+            float o[4], cd[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
-        if (active && n < g.N)
-            xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, ((size_t)n * (size_t)g.P + colbase) * 4, o, cd,
-                           sh_hist, zp, nzp);
+            for (int e = 0; e < 4; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                o[e] = qdq1_fast(v[j][e], sc[a], rs[a], zp[a], qm, cd[e]);
+            }
+            if (active && n < g.N)
+                xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, ((size_t)n * (size_t)g.P + colbase) * 4, o, cd,
+                               sh_hist, zp, nzp);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int n = rlc + j * g.RL;
+            float o[4], cd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = (A == 1 ? 0 : e);
+                o[e] = qdq1(v[j][e], sc[a], zp[a], qm, cd[e]);
+            }
+            if (active && n < g.N)
+                xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, ((size_t)n * (size_t)g.P + colbase) * 4, o, cd,
+                               sh_hist, zp, nzp);
+        }
     }
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zp, nzp);

@@ -270,6 +270,10 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
  *        a wait timed out (diagnostic only, results are unaffected).
  *   qp   out: qp[CNNQ_NQP][C].   mm: optional out [2][C] = the per-channel min and max.
  *   flags  bit 0: take the recompute path unconditionally (tests).
+ *          bit 1: quantize every channel through the hardware divide (tests; CNNQ_IEEE_DIVIDE=1 sets it for every
+ *          single-launch kernel of the process).  By default a channel whose extrema are finite, at most 2^70 in
+ *          magnitude, with a scale of at most 2^30, takes the correctly rounded quotient from the channel's reciprocal
+ *          (two fma corrections, csrc/cnnq_qdq.hip.h qdq1_fast): the same bits, half the arithmetic.
  * Same shape / alignment conditions and CNNQ_ENOTSUP convention as cnnq_pc_minmax_qdq_resident.
  * cnnq_pc_group_describe: out[8] = {A, K, mode, S, column blocks, workgroups per group, groups, workgroups}. */
 size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW);
