@@ -120,6 +120,12 @@ __device__ __forceinline__ void ldv_nt(const float* __restrict__ p, float (&v)[V
         v[0] = __builtin_nontemporal_load(p);
     }
 }
+// four floats from an address that is only 4-byte aligned (rows of H*W % 4 != 0 elements): still one global_load_dwordx4
+typedef f4_t f4a4_t __attribute__((aligned(4)));
+__device__ __forceinline__ void ldv4_nt_a4(const float* __restrict__ p, float (&v)[4]) {
+    const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4a4_t*>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
 template <int VEC>
 __device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {
@@ -143,8 +149,6 @@ __device__ __forceinline__ float pmax(float a, float b) { return (a > b || a != 
 __device__ __forceinline__ double pmind(double a, double b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ double pmaxd(double a, double b) { return (a > b || a != a) ? a : b; }
 
-// qmax = 2.**num_bits - 1. (iq.py:559: a Python float, i.e. fp64, rounded to fp32 when it meets the tensor): exact up
-// to 24 bits, 2^32 for 'int32' - any width the reference's __gemmlowpQuantize1__ accepts
 // zero_point = round(qmin - offset / scale) with qmin = 0 (iq.py:570-572): +0 when the quotient is +-0.  The compiler
 // otherwise folds rint(0 - q) into rint(-q), which is -0 for q = +0 (seen in k_minmax_params' ISA: `v_rndne_f32 -v`);
 // the values agree, the bits of the parameter table would not.
@@ -154,6 +158,8 @@ __device__ __forceinline__ float zero_point_of(float offset, float scale) {
     return rintf(t);
 }
 
+// qmax = 2.**num_bits - 1. (iq.py:559: a Python float, i.e. fp64, rounded to fp32 when it meets the tensor): exact up
+// to 24 bits, 2^32 for 'int32' - any width the reference's __gemmlowpQuantize1__ accepts
 __device__ __host__ __forceinline__ float qmax_of(int num_bits) { return (float)(exp2((double)num_bits) - 1.0); }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }

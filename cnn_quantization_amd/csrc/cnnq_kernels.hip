@@ -305,18 +305,23 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
     if (quant && form != 1) {
         const int64_t nsl = 2 * ngroups;
         const int64_t rpc = nsl <= 128 ? 128 / nsl : 1;
-        const bool lean_ok = HW % 4 == 0 && al16(x) && rpc * C * HW * 4 < ((int64_t)1 << 32);
+        // whole-float4 rows of an aligned x, or (RAG) any row of at least 8 elements: its slots are 4-byte aligned
+        const bool rag = HW % 4 != 0;
+        const bool lean_ok = (rag ? HW >= 8 && ((uintptr_t)x & 3) == 0 : al16(x)) && rpc * C * HW * 4 < ((int64_t)1 << 32);
         if (lean_ok) {
             // ~8 KB of x per wave (32 KB per workgroup of four adjacent channels), whole chunks of rows
-            int64_t rpw = (8192 + HW * 2) / (HW * 4);
+            static const int64_t wave_bytes = env_int("CNNQ_PACK_WAVE_BYTES", 8192);   // development knob
+            int64_t rpw = (wave_bytes + HW * 2) / (HW * 4);
             if (rpw < 1) rpw = 1;
             rpw = ((rpw + rpc - 1) / rpc) * rpc;
             const int64_t Sl = (N + rpw - 1) / rpw, ncb4 = (C + 3) / 4;
             if (Sl * ncb4 >= (int64_t)1 << 31) return CNNQ_ERANGE;
             const dim3 lgrid((unsigned)(Sl * ncb4)), lblock(TPB);
             hipStream_t lst = (hipStream_t)stream;
-            if (nsl <= 128) hipLaunchKernelGGL(k_pack_lean<true>, lgrid, lblock, 0, lst, x, packed, (int)N, (int)C, (int)HW, (int)rpw, qp, bits, rowoff);
-            else hipLaunchKernelGGL(k_pack_lean<false>, lgrid, lblock, 0, lst, x, packed, (int)N, (int)C, (int)HW, (int)rpw, qp, bits, rowoff);
+#define LAUNCH_LEAN(S, R) hipLaunchKernelGGL((k_pack_lean<S, R>), lgrid, lblock, 0, lst, x, packed, (int)N, (int)C, (int)HW, (int)rpw, qp, bits, rowoff)
+            if (nsl <= 128) { if (rag) LAUNCH_LEAN(true, true); else LAUNCH_LEAN(true, false); }
+            else { if (rag) LAUNCH_LEAN(false, true); else LAUNCH_LEAN(false, false); }
+#undef LAUNCH_LEAN
             return launch_status();
         }
         if (form == 2) return CNNQ_ENOTSUP;
@@ -346,7 +351,7 @@ int cnnq_pc_quantize_packed(const float* x, uint8_t* packed, int64_t N, int64_t 
 }
 
 // the same with the kernel form spelled out: 0 = the library's choice, 1 = the general kernel (any geometry), 2 = the
-// lean kernel (one channel per wave; CNNQ_ENOTSUP unless H*W % 4 == 0 and x is 16-byte aligned).  Same bytes.
+// lean kernel (one channel per wave; CNNQ_ENOTSUP for rows of fewer than 8 elements, or whole-float4 rows of an x that is not 16-byte aligned).  Same bytes.
 int cnnq_pc_quantize_packed_form(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
                                  const float* bits, const uint32_t* rowoff, int form, void* stream) {
     if (!x || form < 0 || form > 2) return CNNQ_EINVAL;

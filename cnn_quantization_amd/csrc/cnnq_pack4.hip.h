@@ -386,7 +386,10 @@ __global__ void __launch_bounds__(TPB) k_packed(const float* __restrict__ x, flo
 // code bits each, four wave shuffles hand lane G the two halves of group G (8 codes = b whole bytes), which it stores
 // with straight-line code selected by the scalar width.  The next chunk's loads are issued before the current chunk is
 // encoded.  Same bytes as k_packed<true, *> (tests compare the two forms).
-template <bool SHORT>
+#ifndef PACK_AHEAD
+#define PACK_AHEAD 1
+#endif
+template <bool SHORT, bool RAG = false>
 __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, uint8_t* __restrict__ packed, const int N,
                                                    const int C, const int HW, const int rpw, const float* __restrict__ qp,
                                                    const float* __restrict__ bits, const uint32_t* __restrict__ rowoff) {
@@ -395,13 +398,11 @@ __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, 
     const int s = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - s * ncb;
     const int c = __builtin_amdgcn_readfirstlane(cb * 4 + (int)(threadIdx.x >> 6));      // the wave's channel: a scalar
     if (c >= C) return;
-    const int b = (int)bits[c];
-    if (b == 0) return;                                                                   // a 0-bit channel stores nothing
-    const float sc = qp[(size_t)CNNQ_QP_SCALE * C + c], zp = qp[(size_t)CNNQ_QP_ZP * C + c], qm = qp[(size_t)CNNQ_QP_QMAX * C + c];
-    const uint32_t off_c = rowoff[c], plane = rowoff[C];
     const int n0 = s * rpw, n1 = min(N, n0 + rpw);
-    const int nslots = HW / 4, ngroups = (HW + 7) / 8, nsl = 2 * ngroups;
-    const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
+    // RAG: rows of H*W % 4 != 0 elements (7x7): the row's last slot holds `tail` < 4 elements; it is loaded from the
+    // row's last four elements (in bounds, 4-byte aligned like every slot of such a row) and its codes are shifted down
+    const int nslots = RAG ? (HW + 3) / 4 : HW / 4, ngroups = (HW + 7) / 8, nsl = 2 * ngroups;
+    const int tail = HW - 4 * (nslots - 1);
     const size_t P = (size_t)C * (size_t)HW;
     const int src = (2 * lane) & 63;
     // the lane's two slots and its group inside a chunk
@@ -425,36 +426,79 @@ __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, 
     };
     auto load2 = [&](int i, float (&va)[4], float (&vb)[4], bool& oka, bool& okb) {
         int nb, j;
-        chunk(i, nb, j);
+        const bool live = i < nchunks;                                       // the prefetch behind the last chunk: every lane
+        chunk(live ? i : nchunks - 1, nb, j);                                // re-reads one 16-byte piece (a single request)
         const float* xs = x + ((size_t)nb * P + (size_t)c * (size_t)HW);     // uniform: the chunk's first row
         const int qa = sa + j * 128, qb = sb + j * 128;                      // slot within the row
-        oka = qa < nslots && (SHORT ? (ra < rpc && nb + ra < n1) : true);
-        okb = qb < nslots && (SHORT ? (rb < rpc && nb + rb < n1) : true);
+        oka = live && qa < nslots && (SHORT ? (ra < rpc && nb + ra < n1) : true);
+        okb = live && qb < nslots && (SHORT ? (rb < rpc && nb + rb < n1) : true);
         // unconditional loads (a branch around a load serialises the loads): dead lanes read the chunk's first slot
-        const unsigned oa = oka ? (unsigned)ra * (unsigned)P + (unsigned)qa * 4u : 0u;
-        const unsigned ob = okb ? (unsigned)rb * (unsigned)P + (unsigned)qb * 4u : 0u;
-        ldv_nt<4>(xs + oa, va);
-        ldv_nt<4>(xs + ob, vb);
-    };
-    auto half_of = [&](const float (&v)[4], bool ok) -> unsigned {
-        unsigned cds[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float cd;
-            (void)qdq1(v[e], sc, zp, qm, cd);
-            cds[e] = (unsigned)cd;
+        if constexpr (RAG) {
+            const unsigned ea = qa == nslots - 1 ? (unsigned)(HW - 4) : (unsigned)qa * 4u;
+            const unsigned eb = qb == nslots - 1 ? (unsigned)(HW - 4) : (unsigned)qb * 4u;
+            ldv4_nt_a4(xs + (oka ? (unsigned)ra * (unsigned)P + ea : 0u), va);
+            ldv4_nt_a4(xs + (okb ? (unsigned)rb * (unsigned)P + eb : 0u), vb);
+        } else {
+            const unsigned oa = oka ? (unsigned)ra * (unsigned)P + (unsigned)qa * 4u : 0u;
+            const unsigned ob = okb ? (unsigned)rb * (unsigned)P + (unsigned)qb * 4u : 0u;
+            ldv_nt<4>(xs + oa, va);
+            ldv_nt<4>(xs + ob, vb);
         }
-        const unsigned h = cds[0] | (cds[1] << b) | (cds[2] << (2 * b)) | (cds[3] << (3 * b));
-        return ok ? h : 0u;
     };
     float va[4], vb[4];
     bool oka, okb;
     load2(0, va, vb, oka, okb);
+#if PACK_AHEAD == 2
+    float ma[4], mb[4];                     // the chunk after it (the loads run two chunks ahead of the encoder)
+    bool moka, mokb;
+    load2(1, ma, mb, moka, mokb);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // the channel's parameters only now: the first chunk of x is already on its way while they arrive
+    const int b = (int)bits[c];
+    if (b == 0) return;                                                                   // a 0-bit channel stores nothing
+    const float sc = qp[(size_t)CNNQ_QP_SCALE * C + c], zp = qp[(size_t)CNNQ_QP_ZP * C + c], qm = qp[(size_t)CNNQ_QP_QMAX * C + c];
+    const uint32_t off_c = rowoff[c], plane = rowoff[C];
+    const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
+    const bool fastc = sc >= 0x1p-30f && sc <= 0x1p30f && fabsf(zp) <= 0x1p30f && qm >= 0.f && qm <= 255.f;
+    const float rs = uniform_f(1.0f / sc);
+    // The codes without the hardware divide (qdq1_fast, cnnq_qdq.hip.h) when the channel's parameters are inside its
+    // domain (a scalar test) AND the chunk's eight values per lane are (a wave-uniform test per chunk: the sum of their
+    // squares is at most 2^120 - every |x| <= 2^60, no NaN, no inf; one fma per element); otherwise qdq1.
+    auto half_of = [&](const float (&v)[4], bool ok, bool fast, bool last) -> unsigned {
+        unsigned cds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float cd;
+            if (fast) (void)qdq1_fast(v[e], sc, rs, zp, qm, cd);
+            else (void)qdq1(v[e], sc, zp, qm, cd);
+            cds[e] = (unsigned)cd;
+        }
+        unsigned h = cds[0] | (cds[1] << b) | (cds[2] << (2 * b)) | (cds[3] << (3 * b));
+        if constexpr (RAG) h = last ? h >> ((4 - tail) * b) : h;     // the row's last slot: its `tail` elements sit on top
+        return ok ? h : 0u;
+    };
+    auto chunk_in_domain = [&](const float (&p)[4], const float (&q)[4]) -> bool {
+        float t0 = p[0] * p[0], t1 = p[1] * p[1];
+        t0 = __builtin_fmaf(p[2], p[2], t0); t1 = __builtin_fmaf(p[3], p[3], t1);
+        t0 = __builtin_fmaf(q[0], q[0], t0); t1 = __builtin_fmaf(q[1], q[1], t1);
+        t0 = __builtin_fmaf(q[2], q[2], t0); t1 = __builtin_fmaf(q[3], q[3], t1);
+        return fastc && __builtin_amdgcn_ballot_w64(!(t0 + t1 <= 0x1p120f)) == 0ull;
+    };
     for (int i = 0; i < nchunks; ++i) {
         float na[4], nbv[4];
         bool noka, nokb;
-        load2(i + 1 < nchunks ? i + 1 : i, na, nbv, noka, nokb);             // unconditional prefetch (the last one repeats)
-        const unsigned ha = half_of(va, oka), hb = half_of(vb, okb);
+        load2(i + PACK_AHEAD, na, nbv, noka, nokb);                          // unconditional prefetch (past the end: one broadcast line)
+        unsigned ha, hb;
+        bool lasta = false, lastb = false;
+        if constexpr (RAG) {
+            int nbq, jq;
+            chunk(i, nbq, jq);
+            lasta = sa + jq * 128 == nslots - 1;
+            lastb = sb + jq * 128 == nslots - 1;
+        }
+        if (chunk_in_domain(va, vb)) { ha = half_of(va, oka, true, lasta); hb = half_of(vb, okb, true, lastb); }
+        else { ha = half_of(va, oka, false, lasta); hb = half_of(vb, okb, false, lastb); }
         const unsigned a0 = (unsigned)__shfl((int)ha, src, 64), b0 = (unsigned)__shfl((int)hb, src, 64);
         const unsigned a1 = (unsigned)__shfl((int)ha, src + 1, 64), b1 = (unsigned)__shfl((int)hb, src + 1, 64);
         const unsigned lo = lane < 32 ? a0 : b0, hi = lane < 32 ? a1 : b1;
@@ -489,9 +533,15 @@ __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, 
             }
         }
 #pragma unroll
+#if PACK_AHEAD == 2
+        for (int e = 0; e < 4; ++e) { va[e] = ma[e]; vb[e] = mb[e]; ma[e] = na[e]; mb[e] = nbv[e]; }
+        oka = moka; okb = mokb;
+        moka = noka; mokb = nokb;
+#else
         for (int e = 0; e < 4; ++e) { va[e] = na[e]; vb[e] = nbv[e]; }
         oka = noka;
         okb = nokb;
+#endif
     }
 }
 

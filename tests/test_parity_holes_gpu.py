@@ -347,7 +347,9 @@ def test_wide_per_channel_bits(ops, bits):
 
 
 @pytest.mark.parametrize('shape', [(8, 64, 56, 56), (5, 20, 14, 14), (6, 12, 28, 28), (3, 7, 112, 112), (40, 8, 8, 8), (2, 5, 2, 2),
-                                   (9, 5, 6, 6), (33, 3, 40, 52), (64, 4, 224, 224)])
+                                   (9, 5, 6, 6), (33, 3, 40, 52), (64, 4, 224, 224),
+                                   # rows that are not whole float4s (the lean kernel's ragged form): 7x7, short and long rows
+                                   (64, 40, 7, 7), (33, 6, 5, 5), (20, 3, 9, 11), (6, 3, 23, 23), (5, 4, 3, 3), (3, 2, 1, 1023)])
 def test_packed_forms_write_the_same_bytes(ops, shape):
     """The lean quantize+pack kernel of round 3 (k_pack_lean: one channel per wave, scalar parameters; short rows take
     several samples per chunk, long rows several chunks per row) against the general kernel: the same bytes, padding
@@ -365,3 +367,43 @@ def test_packed_forms_write_the_same_bytes(ops, shape):
         c, _ = ops.quantize_packed(x, qp, bits)
         assert torch.equal(ro_a, ro_b) and torch.equal(a, b) and torch.equal(a, c), shape
         assert torch.equal(ops.dequantize_packed(b, shape, qp, bits, ro_b), ops.pc_qdq(x, N, C, H * W, qp))
+
+
+@pytest.mark.parametrize('shape', [(8, 16, 56, 56), (10, 12, 14, 14), (6, 12, 28, 28), (3, 8, 112, 112)])
+def test_packed_lean_edges_equal_the_divide(ops, shape):
+    """k_pack_lean computes its codes without the hardware divide when the channel's parameters and the chunk's values
+    are inside qdq1_fast's domain, and with it otherwise: values a few ulps around the rounding ties of the code, zeros,
+    denormals, 1e30, inf and NaN scattered over the tensor, scales at and beyond the domain's ends - the same bytes as
+    the general kernel, which always divides."""
+    from cnn_quantization_amd import _lib as L
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=gen) * torch.exp(torch.randn(1, C, 1, 1, generator=gen))
+    qp = torch.zeros((L.NQP, C))
+    sc = torch.rand(C, generator=gen) * 0.5 + 0.01
+    sc[1], sc[2], sc[3] = 2.0 ** -31, 2.0 ** 31, 1e-8          # outside, outside, the floor (inside)
+    zp = torch.randint(0, 16, (C,), generator=gen).float()
+    zp[4] = -3.0e9                                              # outside
+    zp[5] = 0.0
+    qp[L.QP_SCALE], qp[L.QP_ZP], qp[L.QP_QMAX] = sc, zp, 15.0
+    # ties of the code: (k + 1/2 - zp) * scale, a few ulps either way
+    k = torch.randint(0, 16, shape, generator=gen).float() + 0.5
+    t = ((k - zp.view(1, C, 1, 1)).double() * sc.view(1, C, 1, 1).double()).float()
+    t = (t.view(torch.int32) + torch.randint(-3, 4, shape, generator=gen, dtype=torch.int32)).view(torch.float32)
+    pick = torch.rand(shape, generator=gen)
+    x = torch.where(pick < 0.4, t, x)
+    x = torch.where((pick >= 0.4) & (pick < 0.45), torch.zeros(()), x)
+    x = torch.where((pick >= 0.45) & (pick < 0.5), torch.full((), 1e-41), x)
+    x = torch.where(torch.isfinite(x), x, torch.zeros(()))
+    xe = x.clone()
+    flat = xe.view(-1)
+    idx = torch.randint(0, flat.numel(), (40,), generator=gen)
+    vals = torch.tensor([1e30, -1e30, float('inf'), -float('inf'), float('nan'), 3e20, -2e19, 1e18])
+    flat[idx] = vals[torch.arange(40) % 8]
+    for xx in (x, xe):
+        xd, qd = xx.cuda(), qp.cuda()
+        bits = torch.full((C,), 4.0, device='cuda')
+        a, ro_a = ops.quantize_packed(xd, qd, bits, form=1)
+        b, ro_b = ops.quantize_packed(xd, qd, bits, form=2)
+        assert torch.equal(ro_a, ro_b) and torch.equal(a, b), shape
+
