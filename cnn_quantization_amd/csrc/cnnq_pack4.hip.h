@@ -462,6 +462,34 @@ __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, 
     const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
     const bool fastc = sc >= 0x1p-30f && sc <= 0x1p30f && fabsf(zp) <= 0x1p30f && qm >= 0.f && qm <= 255.f;
     const float rs = uniform_f(1.0f / sc);
+    // Widths 3, 5, 6, 7: a group's b bytes are neither a power of two nor aligned, and storing them byte by byte costs
+    // 3-5 store instructions of 1-byte pieces at a stride of b (PMC: 21 bytes per write request).  The chunk's groups
+    // form one byte stream per row (long rows: 64 b bytes of one row; short rows: `rowbytes` per row, rpc rows), whose
+    // start is 4-byte aligned: lane L stores DWORD L (and 64 + L) of it - fully coalesced 256-byte stores - after
+    // fetching the two groups the dword straddles from the lanes that own them (ds_bpermute; the lane -> (row, dword,
+    // source lane, shifts) map is fixed for the wave's lifetime).
+    const bool xch = b == 3 || b == 5 || b == 6 || b == 7;                                // scalar
+    int xsrc[2], xrow[2];
+    unsigned xshA[2], xshB[2], xoff[2];
+    bool xokA[2], xokB[2], xlive[2];
+    if (xch) {
+        const int dpr = (int)(rowbytes / 4u);                                             // dwords per row
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int d = lane + 64 * r;
+            int rd = 0, dd = d;
+            if constexpr (SHORT) { rd = d / dpr; dd = d - rd * dpr; }
+            const int g0 = (4 * dd) / b, o = 4 * dd - g0 * b;
+            xsrc[r] = (SHORT ? rd * ngroups : 0) + g0;
+            xshA[r] = 8u * (unsigned)o;
+            xshB[r] = 8u * (unsigned)(b - o);
+            xokA[r] = SHORT ? g0 < ngroups : true;                                       // long rows: codes past the row are 0 already
+            xokB[r] = (SHORT ? g0 + 1 < ngroups : g0 + 1 < 64) && b - o < 4;
+            xlive[r] = SHORT ? rd < rpc : d < 16 * b;
+            xrow[r] = rd;
+            xoff[r] = 4u * (unsigned)dd;
+        }
+    }
     // The codes without the hardware divide (qdq1_fast, cnnq_qdq.hip.h) when the channel's parameters are inside its
     // domain (a scalar test) AND the chunk's eight values per lane are (a wave-uniform test per chunk: the sum of their
     // squares is at most 2^120 - every |x| <= 2^60, no NaN, no inf; one fma per element); otherwise qdq1.
@@ -507,7 +535,21 @@ __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, 
         chunk(i, nb, j);
         const int g_i = gi + j * 64;                                           // group within the row
         const bool ghere = g_i < ngroups && (SHORT ? (rg < rpc && nb + rg < n1) : true);
-        if (ghere) {
+        if (xch) {
+            const unsigned wl = (unsigned)ww, wh = (unsigned)(ww >> 32);
+            const uint32_t cbase = SHORT ? 0u : (uint32_t)j * 64u * (uint32_t)b;                // the chunk's first byte in its row
+            const uint32_t cbytes = SHORT ? rowbytes : min(64u * (uint32_t)b, rowbytes - cbase);   // bytes of the row from there
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && (SHORT ? rpc * (int)(rowbytes / 4u) : 16 * b) <= 64) break;          // uniform: one round is enough
+                const unsigned al = (unsigned)__shfl((int)wl, xsrc[r], 64), ah = (unsigned)__shfl((int)wh, xsrc[r], 64);
+                const unsigned bl = (unsigned)__shfl((int)wl, xsrc[r] + 1, 64);
+                const unsigned long long A = xokA[r] ? ((unsigned long long)al | ((unsigned long long)ah << 32)) : 0ull;
+                const unsigned dw = (unsigned)(A >> xshA[r]) | (xokB[r] ? bl << xshB[r] : 0u);
+                if (xlive[r] && xoff[r] < cbytes && (SHORT ? nb + xrow[r] < n1 : true))
+                    *reinterpret_cast<uint32_t*>(packed + (size_t)(nb + xrow[r]) * plane + off_c + cbase + xoff[r]) = dw;
+            }
+        } else if (ghere) {
             uint8_t* g = packed + (size_t)(nb + rg) * plane + off_c + (uint32_t)g_i * (uint32_t)b;
             if (g_i != ngroups - 1) {
                 const unsigned wl = (unsigned)ww, wh = (unsigned)(ww >> 32);
