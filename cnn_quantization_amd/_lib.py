@@ -54,6 +54,7 @@ SIGNATURES = {
     'cnnq_pc_quantize_packed': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
     'cnnq_pc_quantize_packed_form': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _P]),
     'cnnq_pc_dequantize_packed': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P]),
+    'cnnq_pc_dequantize_packed_form': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _P]),
     'cnnq_pc_minmax': (_I, [_P, _L, _L, _L, _P, _P]),
     'cnnq_pc_minmax_strided': (_I, [_P, _L, _L, _L, _L, _P, _P]),
     'cnnq_pc_qdq_strided': (_I, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _I, _P]),

@@ -126,6 +126,11 @@ __device__ __forceinline__ void ldv4_nt_a4(const float* __restrict__ p, float (&
     const f4_t t = __builtin_nontemporal_load(reinterpret_cast<const f4a4_t*>(p));
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
+__device__ __forceinline__ void stv4_nt_a4(float* __restrict__ p, const float (&v)[4]) {
+    f4_t t;
+    t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    __builtin_nontemporal_store(t, reinterpret_cast<f4a4_t*>(p));
+}
 template <int VEC>
 __device__ __forceinline__ void stv_nt(float* __restrict__ p, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {

@@ -326,6 +326,30 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
         }
         if (form == 2) return CNNQ_ENOTSUP;
     }
+    if (!quant && form != 1) {
+        // the load direction's lean form (k_unpack_lean): the same geometry; the packed stream is read as dwords
+        const int64_t nsl = 2 * ngroups;
+        const int64_t rpc = nsl <= 128 ? 128 / nsl : 1;
+        const bool rag = HW % 4 != 0;
+        const bool lean_ok = (rag ? HW >= 8 && ((uintptr_t)y & 3) == 0 : al16(y)) && ((uintptr_t)packed & 3) == 0 &&
+                             rpc * C * HW * 4 < ((int64_t)1 << 32);
+        if (lean_ok) {
+            static const int64_t wave_bytes = env_int("CNNQ_UNPACK_WAVE_BYTES", 8192);   // development knob
+            int64_t rpw = (wave_bytes + HW * 2) / (HW * 4);
+            if (rpw < 1) rpw = 1;
+            rpw = ((rpw + rpc - 1) / rpc) * rpc;
+            const int64_t Sl = (N + rpw - 1) / rpw, ncb4 = (C + 3) / 4;
+            if (Sl * ncb4 >= (int64_t)1 << 31) return CNNQ_ERANGE;
+            const dim3 lgrid((unsigned)(Sl * ncb4)), lblock(TPB);
+            hipStream_t lst = (hipStream_t)stream;
+#define LAUNCH_ULEAN(S, R) hipLaunchKernelGGL((k_unpack_lean<S, R>), lgrid, lblock, 0, lst, packed, y, (int)N, (int)C, (int)HW, (int)rpw, qp, bits, rowoff)
+            if (nsl <= 128) { if (rag) LAUNCH_ULEAN(true, true); else LAUNCH_ULEAN(true, false); }
+            else { if (rag) LAUNCH_ULEAN(false, true); else LAUNCH_ULEAN(false, false); }
+#undef LAUNCH_ULEAN
+            return launch_status();
+        }
+        if (form == 2) return CNNQ_ENOTSUP;
+    }
     const dim3 grid((unsigned)(ncb * S)), block(TPB);
     static const int64_t rows_min = env_int("CNNQ_PACK_ROWS_MIN", 256);   // development knob (slots per row)
     const bool rows_form = 2 * ngroups >= rows_min;
@@ -362,6 +386,14 @@ int cnnq_pc_dequantize_packed(const uint8_t* packed, float* y, int64_t N, int64_
                               const float* bits, const uint32_t* rowoff, void* stream) {
     if (!y) return CNNQ_EINVAL;
     return packed_launch(false, nullptr, y, const_cast<uint8_t*>(packed), N, C, HW, qp, bits, rowoff, stream);
+}
+
+// the same with the kernel form spelled out (0 / 1 / 2 as in cnnq_pc_quantize_packed_form; the lean form needs a 4-byte
+// aligned packed buffer on top of the conditions on y).  Same floats.
+int cnnq_pc_dequantize_packed_form(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
+                                   const float* bits, const uint32_t* rowoff, int form, void* stream) {
+    if (!y || form < 0 || form > 2) return CNNQ_EINVAL;
+    return packed_launch(false, nullptr, y, const_cast<uint8_t*>(packed), N, C, HW, qp, bits, rowoff, stream, form);
 }
 
 int cnnq_pc_minmax_strided(const float* x, int64_t N, int64_t C, int64_t HW, int64_t sample_stride, float* pmm,

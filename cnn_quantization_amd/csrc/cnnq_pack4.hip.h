@@ -587,4 +587,123 @@ __global__ void __launch_bounds__(TPB) k_pack_lean(const float* __restrict__ x, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_unpack_lean (round 3): the load direction of the same geometry as k_pack_lean - one channel per wave (scalar scale /
+// zero point / width / row offset), chunks of 128 slots.  The chunk's bytes are read as DWORDS of the row's byte stream,
+// lane L the dwords L and 64 + L (two coalesced loads whatever the width), parked in the wave's own 128-dword LDS strip;
+// the lane that owns slot q then picks up the two dwords its 4 b code bits straddle with one ds_read2_b32, shifts
+// (v_alignbit), extracts four codes (v_bfe_u32 with scalar width), dequantizes (code - zp) * scale (iq.py:591-592) and
+// stores one 16-byte piece of y - fully coalesced on both sides, 5 vector operations per element, no per-lane width
+// tests, no byte loads.  Waves never talk (no barrier: a wave's LDS operations execute in order).  Same floats as
+// k_packed<false, *> (tests compare both with the fused Q/DQ).
+template <bool SHORT, bool RAG = false>
+__global__ void __launch_bounds__(TPB) k_unpack_lean(const uint8_t* __restrict__ packed, float* __restrict__ y, const int N,
+                                                     const int C, const int HW, const int rpw, const float* __restrict__ qp,
+                                                     const float* __restrict__ bits, const uint32_t* __restrict__ rowoff) {
+    __shared__ uint32_t sh_dw[TPB / 64][132];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ncb = (C + 3) / 4;
+    const int s = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - s * ncb;
+    const int c = cb * 4 + wv;                                                            // the wave's channel: a scalar
+    if (c >= C) return;
+    const int n0 = s * rpw, n1 = min(N, n0 + rpw);
+    const int nslots = RAG ? (HW + 3) / 4 : HW / 4, ngroups = (HW + 7) / 8, nsl = 2 * ngroups;
+    const int tail = HW - 4 * (nslots - 1);
+    const size_t P = (size_t)C * (size_t)HW;
+    const int b = (int)bits[c];                                                           // 0: every code is 0, nothing is read
+    const float sc = qp[(size_t)CNNQ_QP_SCALE * C + c], zp = qp[(size_t)CNNQ_QP_ZP * C + c];
+    const uint32_t off_c = rowoff[c], plane = rowoff[C];
+    const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b + 31u) / 32u) * 4u;
+    const int dpr = max(1, (int)(rowbytes / 4u));                                         // dwords per row
+    const int cdw = 16 * b;                                                               // long rows: dwords per full chunk
+    // the lane's two slots (as in k_pack_lean) and the two dwords it fetches, per chunk
+    int ra = 0, rb = 0, sa, sb;
+    int rpc = 1, cpr = 1;
+    int lr[2] = {0, 0}, ld[2];                                                            // row and dword (within the row / chunk) of the lane's loads
+    if constexpr (SHORT) {
+        rpc = 128 / nsl;
+        ra = lane / nsl; sa = lane - ra * nsl;
+        rb = (64 + lane) / nsl; sb = 64 + lane - rb * nsl;
+        lr[0] = lane / dpr; ld[0] = lane - lr[0] * dpr;
+        lr[1] = (64 + lane) / dpr; ld[1] = 64 + lane - lr[1] * dpr;
+    } else {
+        cpr = (nsl + 127) / 128;
+        sa = lane; sb = 64 + lane;
+        ld[0] = lane; ld[1] = 64 + lane;
+    }
+    // the strip index of the first dword of the lane's slots and the bit offset inside it
+    const int ta = min(130, (SHORT ? ra * dpr : 0) + (b * sa) / 8), tb = min(130, (SHORT ? rb * dpr : 0) + (b * sb) / 8);
+    const unsigned sha = 4u * (unsigned)((b * sa) & 7), shb = 4u * (unsigned)((b * sb) & 7);
+    const int nchunks = SHORT ? (n1 - n0 + rpc - 1) / rpc : (n1 - n0) * cpr;
+    if (nchunks <= 0) return;
+    auto chunk = [&](int i, int& nb, int& j) {
+        if constexpr (SHORT) { nb = n0 + i * rpc; j = 0; }
+        else { nb = n0 + i / cpr; j = i - (i / cpr) * cpr; }
+    };
+    auto loadd = [&](int i, uint32_t (&r)[2]) {
+        int nb, j;
+        const bool live = i < nchunks;
+        chunk(live ? i : nchunks - 1, nb, j);
+        const uint8_t* rowp = packed + (size_t)nb * plane + off_c;                        // uniform
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bool ok;
+            uint32_t off;
+            if constexpr (SHORT) {
+                ok = live && lr[k] < rpc && nb + lr[k] < n1 && b > 0;
+                off = (uint32_t)lr[k] * plane + 4u * (uint32_t)ld[k];
+            } else {
+                const uint32_t dd = (uint32_t)(j * cdw + ld[k]);
+                ok = live && ld[k] < cdw && 4u * dd < rowbytes;
+                off = 4u * dd;
+            }
+            // unconditional load (a branch around a load serialises the loads): dead lanes re-read the row's first dword
+            r[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(rowp + (ok ? off : 0u)));
+        }
+    };
+    uint32_t cur[2];
+    if (b > 0) loadd(0, cur); else { cur[0] = 0u; cur[1] = 0u; }
+    const unsigned cmask = b >= 8 ? 0xffu : ((1u << b) - 1u);
+    for (int i = 0; i < nchunks; ++i) {
+        uint32_t nxt[2] = {0u, 0u};
+        if (b > 0) loadd(i + 1, nxt);                                                     // b is a scalar: no divergence
+        sh_dw[wv][lane] = cur[0];
+        sh_dw[wv][64 + lane] = cur[1];
+        __builtin_amdgcn_wave_barrier();
+        const unsigned alo = sh_dw[wv][ta], ahi = sh_dw[wv][ta + 1];
+        const unsigned blo = sh_dw[wv][tb], bhi = sh_dw[wv][tb + 1];
+        __builtin_amdgcn_wave_barrier();
+        const unsigned ma = __builtin_amdgcn_alignbit(ahi, alo, sha), mb = __builtin_amdgcn_alignbit(bhi, blo, shb);
+        int nb, j;
+        chunk(i, nb, j);
+        float* ys = y + ((size_t)nb * P + (size_t)c * (size_t)HW);                       // uniform: the chunk's first row
+        const int qa = sa + j * 128, qb = sb + j * 128;
+        const bool oka = qa < nslots && (SHORT ? (ra < rpc && nb + ra < n1) : true);
+        const bool okb = qb < nslots && (SHORT ? (rb < rpc && nb + rb < n1) : true);
+        auto emit = [&](unsigned m, bool ok, int r, int q) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((float)((m >> (e * b)) & cmask) - zp) * sc;
+            if (!ok) return;
+            float* dst = ys + (size_t)((unsigned)r * (unsigned)P + (unsigned)q * 4u);
+            if constexpr (RAG) {
+                if (q == nslots - 1) {
+                    dst[0] = o[0];
+                    if (tail > 1) dst[1] = o[1];
+                    if (tail > 2) dst[2] = o[2];
+                } else {
+                    stv4_nt_a4(dst, o);
+                }
+            } else {
+                stv_nt<4>(dst, o);
+            }
+        };
+        emit(ma, oka, ra, qa);
+        emit(mb, okb, rb, qb);
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
+    }
+}
+
 }  // namespace

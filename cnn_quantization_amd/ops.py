@@ -704,16 +704,17 @@ def quantize_packed(x, qp, bits, out=None, form=0):
     return (packed if plane is None else packed[:N * plane]), rowoff
 
 
-def dequantize_packed(packed, shape, qp, bits, rowoff, out=None):
-    """Inverse of quantize_packed: the dequantized fp32 tensor (bit-identical to pc_qdq's output)."""
+def dequantize_packed(packed, shape, qp, bits, rowoff, out=None, form=0):
+    """Inverse of quantize_packed: the dequantized fp32 tensor (bit-identical to pc_qdq's output).  form as in
+    quantize_packed (cnnq_pc_dequantize_packed_form)."""
     lib = L.load()
     y = torch.empty(shape, dtype=torch.float32, device=packed.device) if out is None else out
     if out is not None and not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
                                 and tuple(out.shape) == tuple(shape)):
         raise L.CnnqError('out must be a contiguous float32 device tensor of the given shape')
     N, C, HW = geometry(y)
-    L.check(lib.cnnq_pc_dequantize_packed(_ptr(packed), _ptr(y), N, C, HW, _ptr(qp), _ptr(bits.contiguous()), _ptr(rowoff),
-                                          _stream(y)), 'cnnq_pc_dequantize_packed')
+    L.check(lib.cnnq_pc_dequantize_packed_form(_ptr(packed), _ptr(y), N, C, HW, _ptr(qp), _ptr(bits.contiguous()),
+                                               _ptr(rowoff), int(form), _stream(y)), 'cnnq_pc_dequantize_packed')
     return y
 
 

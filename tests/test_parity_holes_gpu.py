@@ -366,7 +366,9 @@ def test_packed_forms_write_the_same_bytes(ops, shape):
         b, ro_b = ops.quantize_packed(x, qp, bits, form=2)
         c, _ = ops.quantize_packed(x, qp, bits)
         assert torch.equal(ro_a, ro_b) and torch.equal(a, b) and torch.equal(a, c), shape
-        assert torch.equal(ops.dequantize_packed(b, shape, qp, bits, ro_b), ops.pc_qdq(x, N, C, H * W, qp))
+        ref = ops.pc_qdq(x, N, C, H * W, qp)
+        for form in (0, 1, 2):              # the load direction: the general and the lean kernel, the same floats
+            assert torch.equal(ops.dequantize_packed(b, shape, qp, bits, ro_b, form=form), ref), (shape, form)
 
 
 @pytest.mark.parametrize('shape', [(8, 16, 56, 56), (10, 12, 14, 14), (6, 12, 28, 28), (3, 8, 112, 112)])
