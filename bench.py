@@ -348,30 +348,34 @@ def other_configs(ops, device, batch):
                          '(-c laplace -baa)' % batch, bool(ok3))
     del ys, c3
     # the same configuration with the bit-allocated integer codes as the STORED result
-    # (sum(bits)/8 bytes per position instead of 4 B/elem of dequantized floats); the packing pass alone is timed,
-    # its parameters come from one untimed statistics + parameter run per tensor
+    # (sum(bits)/8 bytes per position instead of 4 B/elem of dequantized floats); the packing pass alone is timed: its
+    # parameters - scale / zero point / width per channel and the row layout that follows from the widths - come from
+    # one untimed statistics + parameter run per tensor
     pk = []
     for (x, half) in layers:
         _, parts = ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, want_parts=True)
-        pk.append((x, parts['qp'], parts['diag'][Lb.DIAG_BITS].contiguous()))
+        bits = parts['diag'][Lb.DIAG_BITS].contiguous()
+        pk.append((x, parts['qp'], bits, ops.packed_layout(bits, x.shape[2] * x.shape[3])))
     del _
-    stored = [ops.quantize_packed(x, qp, bits) for x, qp, bits in pk]
+    stored = [ops.quantize_packed(x, qp, bits) for x, qp, bits, _ in pk]
     nbytes = sum(p.numel() for p, _ in stored)
     del stored
     torch.cuda.empty_cache()
-    bufs = [torch.empty(ops.packed_capacity(x.shape), dtype=torch.uint8, device=device) for x, _, _ in pk]
-    t = timed_best(lambda: [ops.quantize_packed(x, qp, bits, out=b) for (x, qp, bits), b in zip(pk, bufs)])
+    bufs = [torch.empty(ops.packed_capacity(x.shape), dtype=torch.uint8, device=device) for x, _, _, _ in pk]
+    t = timed_best(lambda: [ops.quantize_packed(x, qp, bits, out=b, rowoff=ro) for (x, qp, bits, ro), b in zip(pk, bufs)])
+    t_with_layout = timed_best(lambda: [ops.quantize_packed(x, qp, bits, out=b) for (x, qp, bits, _), b in zip(pk, bufs)])
     bpe = 4 + nbytes / elems
     # ... and the way back: stored codes -> fp32 (what the next layer's kernel would fuse into its load)
-    offs = [ops.quantize_packed(x, qp, bits, out=b)[1] for (x, qp, bits), b in zip(pk, bufs)]
-    ys = [torch.empty_like(x) for x, _, _ in pk]
+    ys = [torch.empty_like(x) for x, _, _, _ in pk]
     t_load = timed_best(lambda: [ops.dequantize_packed(b, x.shape, qp, bits, ro, out=yy)
-                                 for (x, qp, bits), b, ro, yy in zip(pk, bufs, offs, ys)])
+                                 for (x, qp, bits, ro), b, yy in zip(pk, bufs, ys)])
     ok3p = bool(torch.equal(ys[big], y3))                 # stored codes -> fp32 == the fused Q/DQ of config 3, bit for bit
-    del bufs, offs, ys, y3
+    del bufs, ys, y3
     out['config3_packed_storage'] = obj(elems, t, bpe, 'ResNet-50 b%d, the quantize+pack pass of config 3 with the bit-allocated '
                                         'codes as the stored format: %.3f bytes per element written (fp32 dequantized: 4), into '
-                                        'preallocated buffers (no host read)' % (batch, nbytes / elems), ok3p)
+                                        'preallocated buffers (no host read); one launch per tensor, the row layout comes with '
+                                        'the parameters' % (batch, nbytes / elems), ok3p)
+    out['config3_packed_storage']['ms_with_layout_launch'] = t_with_layout * 1e3      # the layout recomputed in front of every pass
     out['config3_packed_load'] = obj(elems, t_load, bpe, 'ResNet-50 b%d, the inverse pass: bit-allocated stored codes -> '
                                      'dequantized fp32 (%.3f bytes per element read, 4 written)' % (batch, nbytes / elems), ok3p)
     del pk

@@ -333,6 +333,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         const int r = j < nrows ? j : nrows - 1;
         ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
     }
+    // nothing that consumes a loaded value may be scheduled in between the loads (as in k_mmq_flat: the scheduler otherwise
+    // starts folding after ~10 loads and issues the rest one by one as earlier ones land)
+    __builtin_amdgcn_sched_barrier(0);
     GRP_STAMP(1);
     float mn[A], mx[A];
     bool nan = false;
@@ -679,6 +682,7 @@ __global__ void __launch_bounds__(TPB) k_minmax_group(const float* __restrict__ 
         const int r = j < nrows ? j : nrows - 1;
         ldv<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
     }
+    __builtin_amdgcn_sched_barrier(0);      // the whole tile in flight before the first value is consumed
     float mn[A], mx[A];
     bool nan = false;
 #pragma unroll

@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
             for (int e = 0; e < 4; ++e) v[j][e] = v[0][e];
         }
     }
+    __builtin_amdgcn_sched_barrier(0);      // the whole tile in flight before the first value is consumed
     float mn[A], mx[A];
     bool nan = false;
 #pragma unroll

@@ -679,19 +679,35 @@ def packed_capacity(shape):
     return N * C * ((HW * 8 + 31) // 32 * 4)
 
 
-def quantize_packed(x, qp, bits, out=None, form=0):
+def packed_layout(bits, HW):
+    """rowoff int32 [C + 1] of the packed format for per-channel widths `bits` and H*W elements per row
+    (cnnq_pc_packed_layout): row (n, c) starts at byte n * rowoff[C] + rowoff[c].  A function of the parameters only - with
+    a fixed bit allocation it is computed once and handed to quantize_packed / dequantize_packed."""
+    lib = L.load()
+    bits = bits.contiguous()
+    C = bits.numel()
+    rowoff = torch.empty(C + 1, dtype=torch.int32, device=bits.device)
+    L.check(lib.cnnq_pc_packed_layout(_ptr(bits), C, int(HW), _ptr(rowoff), _stream(bits)), 'cnnq_pc_packed_layout')
+    return rowoff
+
+
+def quantize_packed(x, qp, bits, out=None, form=0, rowoff=None):
     """x [N, C, H, W] + parameter table + per-channel bit widths (diag[DIAG_BITS] of pc_params with bit
     allocation) -> (packed uint8 [N * bytes_per_sample], rowoff int32 [C + 1]): bits[c] bits per code, i.e.
     sum(bits)/8 bytes per spatial position (cnnq_pc_quantize_packed).  Sizing the buffer exactly takes one host
     read of rowoff[C]; with `out` (a uint8 buffer of at least packed_capacity(x.shape) bytes) nothing synchronises
     and the whole buffer is returned (the used prefix is N * rowoff[C] bytes).  form: 0 = the library's choice, 1 = the
-    general kernel, 2 = the lean kernel (cnnq_pc_quantize_packed_form); every form writes the same bytes."""
+    general kernel, 2 = the lean kernel (cnnq_pc_quantize_packed_form); every form writes the same bytes.  rowoff: the
+    layout of packed_layout(bits, H * W) when the caller already has it (one launch less)."""
     lib = L.load()
     x = _dev_f32(x, 'x')
     N, C, HW = geometry(x)
     bits = bits.contiguous()
-    rowoff = torch.empty(C + 1, dtype=torch.int32, device=x.device)
-    L.check(lib.cnnq_pc_packed_layout(_ptr(bits), C, HW, _ptr(rowoff), _stream(x)), 'cnnq_pc_packed_layout')
+    if rowoff is None:
+        rowoff = torch.empty(C + 1, dtype=torch.int32, device=x.device)
+        L.check(lib.cnnq_pc_packed_layout(_ptr(bits), C, HW, _ptr(rowoff), _stream(x)), 'cnnq_pc_packed_layout')
+    elif not (rowoff.is_cuda and rowoff.dtype == torch.int32 and rowoff.is_contiguous() and rowoff.numel() == C + 1):
+        raise L.CnnqError('rowoff must be the int32 device tensor [C + 1] of packed_layout(bits, H * W)')
     if out is not None:
         if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= packed_capacity(x.shape)):
             raise L.CnnqError('out must be a contiguous uint8 device buffer of at least packed_capacity(x.shape) bytes')

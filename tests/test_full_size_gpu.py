@@ -135,3 +135,23 @@ def test_config1_per_tensor_full_size(ops):
     ref2 = O.float2gemmlowp(xc, delta, offset, 8, False, bool((offset + delta) > 0 and offset < 0))
     frac = float((y != ref2).float().mean())
     assert frac < 2e-3, frac          # identical unless the device's mean of 32 extrema rounds differently from torch's
+
+
+@pytest.mark.parametrize('shape', [(512, 256, 56, 56), (512, 512, 28, 28), (512, 1024, 14, 14), (512, 2048, 7, 7)])
+def test_packed_storage_full_size(ops, shape):
+    """The bit-allocated packed storage at b512 size: the lean kernels (one channel per wave; 7x7: ragged rows) write the
+    bytes of the general kernel, and the round trip returns the fused Q/DQ's floats bit for bit, in both kernel forms."""
+    from cnn_quantization_amd import _lib as L
+    N, C, H, W = shape
+    x = bench.laplace_activation(shape, 5, torch.device('cuda'))
+    y, parts = ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True, want_parts=True)
+    qp, bits = parts['qp'], parts['diag'][L.DIAG_BITS].contiguous()
+    assert 3.5 <= float(bits.mean()) <= 4.5 and int(bits.max()) > int(bits.min())      # several widths in one tensor
+    a, ro = ops.quantize_packed(x, qp, bits, form=1)
+    b, ro_b = ops.quantize_packed(x, qp, bits, form=2)
+    assert torch.equal(ro, ro_b) and torch.equal(a, b)
+    del a
+    for form in (1, 2):
+        back = ops.dequantize_packed(b, shape, qp, bits, ro, form=form)
+        assert torch.equal(back, y), form
+        del back

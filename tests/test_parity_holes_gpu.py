@@ -365,6 +365,8 @@ def test_packed_forms_write_the_same_bytes(ops, shape):
         a, ro_a = ops.quantize_packed(x, qp, bits, form=1)
         b, ro_b = ops.quantize_packed(x, qp, bits, form=2)
         c, _ = ops.quantize_packed(x, qp, bits)
+        d, ro_d = ops.quantize_packed(x, qp, bits, rowoff=ops.packed_layout(bits, H * W))   # the layout handed in
+        assert torch.equal(ro_d, ro_a) and torch.equal(d, a)
         assert torch.equal(ro_a, ro_b) and torch.equal(a, b) and torch.equal(a, c), shape
         ref = ops.pc_qdq(x, N, C, H * W, qp)
         for form in (0, 1, 2):              # the load direction: the general and the lean kernel, the same floats
