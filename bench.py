@@ -588,6 +588,12 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     if world == 1 and not args.force_exchange:
         exchange_name = 'none (1 GPU)'
+    elif D.xrank_exchange(group) is not None:
+        xr = D.xrank_exchange(group)
+        exchange_name = ('in-launch exchange of the per-channel {min, max} through hipIpc windows (CNNQ_XRANK=1, verified against '
+                         'the collective; x is read once)%s' % (' (forced on a 1-rank group)' if args.force_exchange else ''))
+        if not xr.healthy():
+            exchange_name += ' - UNHEALTHY: a wait for a peer expired, results of this run are invalid'
     elif D.p2p_exchange(group) is not None:
         exchange_name = 'peer-to-peer stores over xGMI (CNNQ_P2P_EXCHANGE=1, verified against the collective)'
         if not D.p2p_exchange(group).healthy():
@@ -611,7 +617,8 @@ def main():
         v = torch.tensor([1 if verified else 0], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(int(v.item()))
-    dominant, objs = roofline_objects(layers, per_rank, world, single_launch=(world == 1 and not args.force_exchange))
+    dominant, objs = roofline_objects(layers, per_rank, world, single_launch=((world == 1 and not args.force_exchange)
+                                                                              or D.xrank_exchange(group) is not None))
     out = {
         'metric': 'activation elements/sec (and % HBM peak) for per-channel int4 Q/DQ, ResNet-50 b512',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -641,6 +648,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1 or args.force_exchange:
         from cnn_quantization_amd import rccl
+        if D.xrank_exchange(group) is not None:
+            D.xrank_exchange(group).close()
         rccl.close_all()
         dist.destroy_process_group()
 

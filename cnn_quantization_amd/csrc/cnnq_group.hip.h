@@ -35,6 +35,7 @@
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"
+#include "cnnq_xrank.hip.h"
 #include "cnnq_resident.hip.h"   // pmin / pmax / lane_acc
 
 namespace {
@@ -304,10 +305,11 @@ struct GWs {
     int gstride;   // pairs per group block
 };
 
-template <int A, int K, int OUT = 0>
+template <int A, int K, int OUT = 0, bool XR = false>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_group(
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
-    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}) {
+    const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{},
+    const XRank xr = XRank{}) {
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
     __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
     if constexpr (OUT == 1) {
@@ -395,7 +397,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     // ---- scale / zero point of the owned channels (iq.py:559-572), identical in every member
     const float qm = qmax_of(num_bits);
     for (int ch = tid; ch < nch; ch += TPB) {
-        const float cmn = sh_mn[ch], cmx = sh_mx[ch];
+        float cmn = sh_mn[ch], cmx = sh_mx[ch];
+        if constexpr (XR) (void)xr_merge(xr, b.c0 + ch, rb.member == 0, cmn, cmx);   // the batch is sharded: every rank's extrema
         const float offset = positive ? 0.f : cmn;
         const float delta = cmx - offset;
         float sc = delta / qm;
@@ -514,10 +517,10 @@ __device__ __forceinline__ void wg_minmax1(float tn, float tx, float* l_mn, floa
     cmx = pmax(pmax(l_mx[0], l_mx[1]), pmax(l_mx[2], l_mx[3]));
 }
 
-template <int K, int OUT = 0>
+template <int K, int OUT = 0, bool XR = false>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat(
     const float* __restrict__ x, float* __restrict__ y, const FGeo g, const int num_bits, const int positive, const GWs ws,
-    float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}) {
+    float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}, const XRank xr = XRank{}) {
     static_assert(TPB == 256, "wg_minmax1 folds four waves");
     __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
     __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
@@ -600,6 +603,19 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         }
     }
     wg_minmax1(tn, tx, l_mn, l_mx, cmn, cmx);
+    if constexpr (XR) {
+        // the batch is sharded: one thread exchanges the channel's extrema with the other ranks (cnnq_xrank.hip.h)
+        __shared__ float sh_x[2];
+        if (tid == 0) {
+            float a = cmn, b = cmx;
+            (void)xr_merge(xr, c, member == 0, a, b);
+            sh_x[0] = a;
+            sh_x[1] = b;
+        }
+        __syncthreads();
+        cmn = sh_x[0];
+        cmx = sh_x[1];
+    }
 
     // ---- scale / zero point (iq.py:559-572): every lane derives the same values from the same extrema
     const float qm = qmax_of(num_bits);

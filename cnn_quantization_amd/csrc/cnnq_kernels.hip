@@ -639,6 +639,67 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
     return CNNQ_ENOTSUP;
 }
 
+// The same single launch when the batch is sharded over `world` GPUs (opt-in; csrc/cnnq_xrank.hip.h): x is this rank's
+// shard, the channel extrema are exchanged with the other ranks through `windows` INSIDE the launch, y / qp / mm are
+// what a single GPU holding the whole batch would produce.  CNNQ_ENOTSUP when the shape has no single-launch kernel
+// (nothing is enqueued and no sequence number is consumed: the caller takes the collective path on every rank - the
+// plan depends only on the shape and the alignment of x / y, which must agree between the ranks).
+size_t cnnq_xrank_window_bytes(int world, int cmax) {
+    return (world > 0 && cmax > 0) ? xr_window_bytes(world, cmax) : 0;
+}
+
+int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64]) {
+    if (!window || !handle || world <= 0 || cmax <= 0) return CNNQ_EINVAL;
+    const size_t bytes = xr_window_bytes(world, cmax);
+    hipError_t e = hipExtMallocWithFlags(window, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(*window, 0, bytes);                  // sequence numbers start at 1
+    if (e != hipSuccess) return (int)e;
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, *window);
+    if (e != hipSuccess) return (int)e;
+    memcpy(handle, &h, 64);
+    return (int)hipDeviceSynchronize();
+}
+
+int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                             float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                             uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream) {
+    if (!x || !y || !ws || num_bits < 1 || num_bits > 32 || C <= 0) return CNNQ_EINVAL;
+    if (!windows || !status || world <= 0 || rank < 0 || rank >= world || !seq || C > cmax || timeout_ticks <= 0) return CNNQ_EINVAL;
+    if (gws && ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
+    float* qp = ws;                                       // the layout of cnnq_pc_minmax_qdq_auto's workspace
+    float* mm = ws + (size_t)CNNQ_NQP * C;
+    float* pmm = mm + 2 * (size_t)C;
+    XRank xr;
+    xr.windows = windows;
+    xr.rank = rank;
+    xr.world = world;
+    xr.seq = seq;
+    xr.cmax = cmax;
+    xr.status = status;
+    xr.timeout = timeout_ticks;
+    const bool al = al16(x) && al16(y);
+    GPlan gp;
+    const bool group_ok = gws && plan_group(N, C, HW, al, &gp) == 0 && gp.ws_bytes <= gws_bytes;
+    WPlan wp;
+    const bool whole_ok = plan_whole(N, C, HW, al, &wp) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (whole_ok && !(group_ok && wp.wgs < RES_MIN_WGS))
+        return launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, 0, XOut{}, 0u, &xr);
+    if (group_ok) return launch_group(x, y, gp, num_bits, positive ? 1 : 0, gws, qp, mm, 0u, st, 0, XOut{}, &xr);
+    if (whole_ok) return launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, 0, XOut{}, 0u, &xr);
+    // no single-launch kernel for this rank's shard (the ranks' shards may differ by a sample, and so may their plans):
+    // the same window protocol around two passes - local extrema, one thread per channel pushes / waits / folds, Q/DQ
+    // with the folded extrema as the only "gathered" record.  Every rank consumes the sequence number either way.
+    int rc = cnnq_pc_minmax_local_auto(x, N, C, HW, pmm, gws, gws_bytes, mm, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_xr_exchange, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, st, mm, (int)C, xr);
+    rc = launch_status();
+    if (rc) return rc;
+    return cnnq_pc_gathered_qdq(x, y, N, C, HW, mm, 1, num_bits, positive, qp, stream);
+}
+
 // entropy (bits) of the replica histogram the call above filled; the tables are zero again afterwards
 int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream) {
     if (!hist_rep || !out) return CNNQ_EINVAL;

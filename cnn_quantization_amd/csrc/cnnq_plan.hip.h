@@ -215,12 +215,16 @@ inline unsigned mmq_env_flags() {
 }
 
 int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int positive, float* qp, float* mm,
-                 hipStream_t st, int out = 0, const XOut& xo = XOut{}, unsigned flags = 0u) {
+                 hipStream_t st, int out = 0, const XOut& xo = XOut{}, unsigned flags = 0u, const XRank* xrp = nullptr) {
     const dim3 grid((unsigned)p.wgs);
     flags |= mmq_env_flags();
+    const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: the cross-rank stage of cnnq_xrank.hip.h (y only)
+    if (xrank && out != 0) return CNNQ_ENOTSUP;
+    const XRank xr = xrank ? *xrp : XRank{};
 #define LAUNCH_W(A, T, K)                                                                                                     \
     do {                                                                                                                      \
-        if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);      \
+        if (xrank) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
+        else if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);      \
         else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_whole<A, T, K, 2>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);               \
     } while (0)
@@ -372,8 +376,11 @@ int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* 
 }
 
 int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
-                 unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}) {
+                 unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}, const XRank* xrp = nullptr) {
     flags |= mmq_env_flags();
+    const bool xrank = xrp && xrp->world > 0;
+    if (xrank && out != 0) return CNNQ_ENOTSUP;
+    const XRank xr = xrank ? *xrp : XRank{};
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
@@ -384,7 +391,8 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
 #define LAUNCH_F(K)                                                                                                                  \
     do {                                                                                                                             \
-        if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);      \
+        if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);      \
         else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)
@@ -394,7 +402,8 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     }
 #define LAUNCH_G(A, K)                                                                                                                     \
     do {                                                                                                                                   \
-        if (out == 0) hipLaunchKernelGGL((k_mmq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);      \
+        if (xrank) hipLaunchKernelGGL((k_mmq_group<A, K, 0, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        else if (out == 0) hipLaunchKernelGGL((k_mmq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);      \
         else if (out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_group<A, K, 2>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)

@@ -22,6 +22,7 @@
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"
+#include "cnnq_xrank.hip.h"
 
 namespace {
 
@@ -48,10 +49,11 @@ struct WGeo {
     int RL;   // row lanes (<= N)
 };
 
-template <int A, int T, int K, int OUT = 0>
+template <int A, int T, int K, int OUT = 0, bool XR = false>
 __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, float* __restrict__ y, const WGeo g,
                                                  const int num_bits, const int positive, float* __restrict__ qp,
-                                                 float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}) {
+                                                 float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{},
+                                                 const XRank xr = XRank{}) {
     __shared__ float l_mn[T * A], l_mx[T * A];
     __shared__ float sh_rs[MAXCH];
     __shared__ int sh_slow;
@@ -138,7 +140,12 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     const float qm = qmax_of(num_bits);
     float p_sc = 0.f, p_zp = 0.f;
     if (tid < nch) {
-        const float cmn = sh_mn[tid], cmx = sh_mx[tid];
+        float cmn = sh_mn[tid], cmx = sh_mx[tid];
+        if constexpr (XR) {
+            (void)xr_merge(xr, c0 + tid, true, cmn, cmx);      // the batch is sharded: every rank's extrema (cnnq_xrank.hip.h)
+            sh_mn[tid] = cmn;                                  // own entry only; read again by the domain test below
+            sh_mx[tid] = cmx;
+        }
         const float offset = positive ? 0.f : cmn;
         const float delta = cmx - offset;
         p_sc = delta / qm;

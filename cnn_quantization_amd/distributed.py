@@ -109,7 +109,7 @@ class P2PExchange:
         handle = ctypes.create_string_buffer(64)
         local_ok = True
         try:
-            L.check(self.lib.cnnq_p2p_alloc(self.world, self.SLOT_FLOATS, ctypes.byref(own), handle), 'cnnq_p2p_alloc')
+            self._alloc_window(own, handle)
             self.own = own
         except Exception as e:
             local_ok, self.why = False, str(e)
@@ -137,6 +137,10 @@ class P2PExchange:
         self.seq = 0
         self.calls = 0
         self.stream = None
+
+    def _alloc_window(self, own, handle):
+        import ctypes
+        self.L.check(self.lib.cnnq_p2p_alloc(self.world, self.SLOT_FLOATS, ctypes.byref(own), handle), 'cnnq_p2p_alloc')
 
     def _all_agree(self, flag):
         """Group-wide AND of a local boolean (a collective)."""
@@ -209,7 +213,92 @@ class P2PExchange:
         self.mapped, self.own, self.ok = [], None, False
 
 
+class XRankExchange(P2PExchange):
+    """The windows of the IN-LAUNCH cross-rank exchange of config 2 (csrc/cnnq_xrank.hip.h, cnnq_pc_minmax_qdq_xrank): with
+    the batch sharded over the ranks of `group` (one process per GPU, one node), the single-launch kernels push their
+    channels' extrema into every rank's window and wait for the others' inside the launch - x is read once, 8 instead of
+    12 bytes per element.  Opt-in (CNNQ_XRANK=1); `verify()` cross-checks it against the collective path on every rank
+    and must pass before use.  Same rules as P2PExchange: one stream, never under graph capture, every rank issues the
+    same calls in the same order."""
+    CMAX = 4096                                         # channels per (parity, rank) record block: 1 MB at 8 ranks
+    TIMEOUT_TICKS = 200000000                           # 2 s of the 100 MHz clock
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        import os
+        ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
+        self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
+
+    def _alloc_window(self, own, handle):
+        import ctypes
+        self.L.check(self.lib.cnnq_xrank_alloc(self.world, self.CMAX, ctypes.byref(own), handle), 'cnnq_xrank_alloc')
+
+    def fits(self, C):
+        return 0 < C <= self.CMAX
+
+    def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st):
+        """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm land at the start of the
+        workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes)."""
+        import ctypes
+        if torch.cuda.is_current_stream_capturing():
+            raise self.L.CnnqError('the in-launch cross-rank exchange cannot be captured into a HIP graph (host-side sequence number)')
+        if self.stream is None:
+            self.stream = st
+        elif self.stream != st:
+            raise self.L.CnnqError('XRankExchange is bound to the stream of its first launch; use one stream per group')
+        self.seq += 1
+        self.calls += 1
+        if self.calls % self.CHECK_EVERY == 0 and not self.healthy():      # periodic host check (synchronises)
+            raise self.L.CnnqError('XRankExchange: a wait for a peer expired; results since the last check are invalid')
+        rc = self.lib.cnnq_pc_minmax_qdq_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
+                                               ws_ptr, gws, gws_bytes, self.windows.data_ptr(), self.rank, self.world,
+                                               self.CMAX, self.seq, self.status.data_ptr(), self.timeout, st)
+        if rc:
+            self.L.check(rc, 'cnnq_pc_minmax_qdq_xrank')
+
+    def all_gather(self, rec):
+        raise self.L.CnnqError('XRankExchange carries channel extrema inside the config-2 launch only')
+
+    def verify(self, rounds=12):
+        """Config 2 of random shards through the in-launch exchange and through the collective path, bit for bit, on
+        every rank: tile shapes of all three kernels and one without a single-launch kernel."""
+        from . import ops
+        g = torch.Generator(device=self.device).manual_seed(4321 + self.rank)
+        shapes = [(6, 8, 14, 14), (40, 6, 56, 56), (70, 40, 7, 7), (37, 24, 14, 14), (3, 16, 5, 9), (8, 64, 7, 7)]
+        ok = True
+        for i in range(rounds):
+            n, c, h, w = shapes[i % len(shapes)]
+            x = torch.randn((n, c, h, w), generator=g, device=self.device) * (1 + self.rank) + 0.1 * i
+            half = bool(i & 1)
+            ref = ops.minmax_qdq_fused(x, n, c, h * w, 4, half, group=self.group, _xrank=False)
+            got = ops.minmax_qdq_fused(x, n, c, h * w, 4, half, group=self.group, _xrank=self)
+            ok = ok and bool(torch.equal(ref, got))
+        return self._all_agree(ok and self.healthy())
+
+
 _P2P = {}
+_XRANK = {}
+
+
+def xrank_exchange(group=None):
+    """The process-wide XRankExchange of `group` when CNNQ_XRANK=1 and it verified against the collective path; else None.
+    World size 1 only under CNNQ_FORCE_EXCHANGE=1 (timing the protocol on a 1-GPU box)."""
+    import os
+    if os.environ.get('CNNQ_XRANK', '0') != '1' or not (dist.is_available() and dist.is_initialized()):
+        return None
+    if world_size(group) == 1 and not forced_exchange():
+        return None
+    key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    if key not in _XRANK:
+        ex = XRankExchange(group)                       # collective; never raises for a local failure
+        good = ex.ok and ex.verify()
+        if not good:
+            if rank(group) == 0:
+                print('cnn_quantization_amd: in-launch cross-rank exchange unavailable or not verified (%s); using the '
+                      'collective' % (ex.why or 'see other ranks',))
+            ex.close()
+        _XRANK[key] = ex if good else None
+    return _XRANK[key]
 
 
 def p2p_exchange(group=None):

@@ -44,7 +44,8 @@ def _dev_f32(x, what='tensor'):
 # switches, read ONCE at import (the hot call used to look three of them up per tensor: weak #10 of the round-2
 # review); reload_switches() re-reads them for callers that change the environment afterwards (tests, tools)
 def reload_switches():
-    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED
+    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED, _XRANK_ON
+    _XRANK_ON = os.environ.get('CNNQ_XRANK', '0') == '1'              # 1: sharded config 2 exchanges INSIDE the single launch (opt-in)
     _PT_FUSED = os.environ.get('CNNQ_PT_FUSED', '0') == '1'           # 1: config 1 in one launch (slower: see ops.minmax_qdq_per_tensor)
     _RESIDENT = os.environ.get('CNNQ_RESIDENT', '1') != '0'            # 0: never take a single-launch kernel
     _SINGLE_CODES = os.environ.get('CNNQ_SINGLE_CODES', '1') != '0'    # 0: codes / entropy requests take the chain
@@ -425,7 +426,7 @@ def minmax_quantize_pack4(x, num_bits=4, positive=False, out=None):
 
 
 def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
-                     want_parts=False, group=None, _checked=False, chain=False):
+                     want_parts=False, group=None, _checked=False, chain=False, _xrank=None):
     """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials -> parameter table (one tiny
     launch) -> fused Q/DQ in descending address order; no host sync.
 
@@ -466,6 +467,21 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         if rc:
             L.check(rc, 'cnnq_pc_minmax_qdq_auto')
         return y
+    if exchanging and not (want_codes or want_entropy or want_parts) and _xrank is not False and (_xrank is not None or _XRANK_ON):
+        # opt-in (CNNQ_XRANK=1, verified against the collective at first use): the exchange happens INSIDE the single
+        # launch - x is read once (csrc/cnnq_xrank.hip.h); every rank takes this branch or none does
+        xr = _xrank if _xrank is not None else D.xrank_exchange(group)
+        if xr is not None and xr.fits(C):
+            st = _raw_stream(x.device.index)
+            wplan = _WS_BYTES.get((N, C, HW))
+            nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+            if nbytes == 0:
+                L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+            y = _out_like(x, out)
+            gws = _group_workspace(x, st) if resident else None
+            xr.minmax_qdq(x, y, N, C, HW, num_bits, positive, _scratch(x, 'cfg2', nbytes, st).data_ptr(), gws,
+                          GROUP_WS_BYTES if gws is not None else 0, st)
+            return y
     if (exchanging and not (want_codes or want_entropy or want_parts)
             and not _EXCHANGE_OVERLAP):
         # the multi-GPU hot call: local extrema (one C call) -> all_gather of [2, C] -> parameters + Q/DQ (one C

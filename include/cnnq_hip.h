@@ -326,6 +326,26 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
                               uint8_t* packed, void* stream);
 int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
 
+/* Config 2 in ONE launch and ONE read of x when the batch is sharded over `world` GPUs of one node (opt-in;
+ * csrc/cnnq_xrank.hip.h; the default multi-GPU form is cnnq_pc_minmax_local_auto -> all_gather -> cnnq_pc_gathered_qdq,
+ * which reads x twice).  The reference has no counterpart (its DataParallel replicas use their own sub-batch's range,
+ * inference_sim.py:196-200); this reproduces the single-GPU result of int_quantizer.py:409-451,557-603 on the global batch.
+ *   windows  device array [world] of pointers: entry r is rank r's window (cnnq_xrank_alloc on rank r, opened here with
+ *            cnnq_p2p_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels.
+ *   seq      1, 2, 3, ...: the same on every rank for the same launch; the ranks issue the same launches in the same
+ *            order, each on ONE stream.  Not capturable into a graph (the number is a kernel argument).
+ *   status   device word: bit 2 is raised when a wait for a peer's record expired after timeout_ticks of the 100 MHz
+ *            clock (the affected channels' outputs are NaN then) - check it at the next synchronisation point.
+ *   ws / gws  as for cnnq_pc_minmax_qdq_auto (ws: cnnq_pc_minmax_qdq_workspace bytes; qp[CNNQ_NQP][C] and mm[2][C] - the
+ *            GLOBAL extrema - are left at its start).
+ * A rank whose shard has no single-launch kernel (shards may differ by a sample) speaks the same window protocol around
+ * two passes over x, so every rank consumes the sequence number whatever its own plan. */
+size_t cnnq_xrank_window_bytes(int world, int cmax);
+int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64]);   /* free / open / close: cnnq_p2p_* */
+int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                             float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                             uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream);
+
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace
  * prior) -> merge -> cnnq_pc_params(cfg) -> fused Q/DQ.  `ws`: caller workspace of cnnq_pc_aciq_workspace(...)
