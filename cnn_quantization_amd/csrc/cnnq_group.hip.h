@@ -492,6 +492,7 @@ struct FGeo {
     int Gs;               // members (tiles) per channel
     unsigned q256, r16;   // 256 / cpc and (256 % cpc) * 16: one step of 256 float4 in rows and in bytes
     unsigned rs;          // bytes between two samples of the tensor (P * 4)
+    int cb;               // dispatch order: blocks of cb adjacent channels, channel fastest inside a block (1: member fastest)
 };
 
 struct FWalk {
@@ -530,7 +531,18 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     __shared__ int sh_timed_out;
     GRP_STAMP(0);
     const int tid = threadIdx.x;
-    const int c = (int)blockIdx.x / g.Gs, member = (int)blockIdx.x - c * g.Gs;
+    int c, member;
+    if (g.cb <= 1) {
+        c = (int)blockIdx.x / g.Gs;
+        member = (int)blockIdx.x - c * g.Gs;
+    } else {
+        // consecutive workgroups hold the SAME member tile of cb adjacent channels: per sample they read one run of
+        // cb channel rows together
+        const int per = g.cb * g.Gs, blk = (int)blockIdx.x / per, r = (int)blockIdx.x - blk * per;
+        const int c0 = blk * g.cb, cbl = min(g.cb, g.C - c0);
+        member = r / cbl;
+        c = c0 + (r - member * cbl);
+    }
     const unsigned f0 = (unsigned)member * (256u * K);          // < total
     const unsigned n_first = f0 / g.cpc;
     const unsigned u = f0 + (unsigned)tid;
