@@ -303,7 +303,7 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p) {
     // chip reads runs of 4 channel rows together (A/B on one box, three rounds: the b512 step 9.14 -> 9.05 ms, k_mmq_flat
     // 0.640 -> 0.651 of peak; 2 and 4 alike, 8 and more no better).  CNNQ_GRP_CB=1: member fastest (development knob).
     static const int cb_knob = env_int("CNNQ_GRP_CB", 4);
-    const int64_t cb_fit = 700 / Gs;                             // a block's groups must be resident together (768 slots at K = 32)
+    const int64_t cb_fit = 384 / Gs;                             // a block's groups must be resident together: half of the 768 slots at K = 32
     f.cb = (int)(cb_knob > 1 ? (cb_fit < cb_knob ? (cb_fit < 1 ? 1 : cb_fit) : cb_knob) : 1);
     // describe(): a Geo that tells the same story
     p->g = Geo{};
