@@ -18,7 +18,8 @@
 // suffice because a rank can start launch s + 2 only after it has received every rank's records of launch s + 1, which
 // a rank pushes only after its launch s has completed.  A wait gives up after `timeout` ticks of the 100 MHz clock:
 // the channel's outputs are then NaN and bit 2 of the status word is raised (a peer that never launches would otherwise
-// hang the device); the host checks the word at its next synchronisation point and falls back to the collective.
+// hang the device); once raised, later waits give up at once.  The host checks the word at its next synchronisation
+// point and falls back to the collective.
 #pragma once
 #include "cnnq_common.hip.h"
 
@@ -68,7 +69,8 @@ __device__ __forceinline__ bool xr_merge(const XRank& xr, int c, bool push, floa
     }
     void* own = xr.windows[xr.rank];
     float a = INFINITY, b = -INFINITY;
-    bool ok = true;
+    // one expired wait poisons every later one (a peer that is gone would otherwise cost `timeout` per channel)
+    bool ok = !(__hip_atomic_load(xr.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & XR_STATUS_PEER_TIMEOUT);
     const long long t0 = wall_clock64();
     for (int r = 0; r < xr.world && ok; ++r) {
         const XRec* s = xr_rec(own, xr, r, c);
