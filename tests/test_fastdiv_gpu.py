@@ -93,7 +93,16 @@ def test_edges_equal_the_divide(ops, shape, bits, half, out_of_domain):
     assert bits_equal(y.cpu(), yc.cpu().numpy()) and torch.equal(codes, cc)
     qa, qb = parts['qp'].cpu().numpy().view(np.uint32), pc['qp'].cpu().numpy().view(np.uint32)
     assert np.array_equal(qa, qb), [(i, hex(qa[i]), hex(qb[i])) for i in zip(*np.nonzero(qa != qb))]
-    ref = np.asarray(O.act_per_channel_qdq(x, bits, half_range=half), dtype=np.float32)
+    ref, rp = O.act_per_channel_qdq(x, bits, half_range=half, return_parts=True)
+    ref = np.asarray(ref, dtype=np.float32)
+    # the parameter table against the oracle's: scale and zero point bit for bit (the zero point of a channel whose
+    # minimum is +-0 is +0, iq.py:570-572 - the compiler once turned it into -0), NaN where the oracle has NaN
+    from cnn_quantization_amd import _lib as L
+    for row, key in ((L.QP_SCALE, 'scale'), (L.QP_ZP, 'zero_point')):
+        want = np.asarray(rp[key], dtype=np.float32).reshape(-1)
+        got = parts['qp'][row].cpu().numpy()
+        nn = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nn) and bits_equal(np.where(nn, 0, got), np.where(nn, 0, want)), key
     yh = y.cpu().numpy()
     na = np.isnan(ref)                      # NaN where the oracle has NaN (the payloads of x86 and gfx950 differ), bits elsewhere
     assert np.array_equal(np.isnan(yh), na) and bits_equal(np.where(na, 0, yh), np.where(na, 0, ref))
