@@ -359,7 +359,8 @@ def test_packed_forms_write_the_same_bytes(ops, shape):
     N, C, H, W = shape
     x = (torch.randn(shape, generator=gen) * torch.exp(torch.randn(1, C, 1, 1, generator=gen) * 1.5) + 0.1).cuda()
     y, parts = ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True, want_parts=True)
-    for bits in (parts['diag'][L.DIAG_BITS], torch.arange(C, device='cuda', dtype=torch.float32) % 9):
+    ar = torch.arange(C, device='cuda', dtype=torch.float32)
+    for bits in (parts['diag'][L.DIAG_BITS], ar % 9, (ar + 3) % 9, (ar + 6) % 9):      # every width on every shape, few channels or many
         qp = parts['qp'].clone()
         qp[L.QP_QMAX] = 2. ** bits - 1.                 # keep the codes inside the widths under test
         a, ro_a = ops.quantize_packed(x, qp, bits, form=1)
