@@ -32,6 +32,8 @@
 //   * forward progress does not depend on dispatch order: the wait is bounded twice (20 ms of the 100 MHz clock,
 //     2^20 polls); a workgroup that gives up recomputes its channels' extrema from x itself (exact, hence the
 //     same bits) and raises bit 0 of the status word (bit 1: the recompute was forced by the test hook, flags & 1).
+//     While bit 0 is up (cnnq_group_ws_status_clear lowers it) the bound is 0.5 ms instead of 20: a device shared with
+//     another process's workgroups loses 20 ms per expiry otherwise, and a meeting that works takes 10-40 us.
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_qdq.hip.h"
@@ -41,6 +43,10 @@
 namespace {
 
 constexpr long long GRP_TIMEOUT_TICKS = 2000000;   // 20 ms of the 100 MHz constant clock
+constexpr long long GRP_TIMEOUT_SHORT = 50000;     // 0.5 ms: once a wait HAS expired on this workspace (status bit 0) the
+                                                   // device is evidently shared - another process's workgroups hold the
+                                                   // slots a group needs - and every further expiry would cost 20 ms; a
+                                                   // meeting that works takes 10-40 us, so 0.5 ms changes nothing for it
 constexpr int GRP_TIMEOUT_SPINS = 1 << 20;         // second bound on the same wait
 constexpr int GRP_CNT_STRIDE = 64;                 // words between two groups' counters: one 256-byte line each - with
                                                    // 16 counters per line every arrival, departure and poll of 16
@@ -224,7 +230,8 @@ __device__ __forceinline__ unsigned* grp_lines(unsigned* cnt, int group, int Gs,
 // arriver of a sub-group, before it reports to the top line (two-level groups only): the place to fold the
 // sub-group's records.
 template <typename F>
-__device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsigned flags, F on_sub_last) {
+__device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsigned flags, F on_sub_last,
+                                        long long timeout_ticks = GRP_TIMEOUT_TICKS) {
     const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
     const int si = member / GRP_SUB;
     const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
@@ -260,7 +267,7 @@ __device__ __forceinline__ int grp_meet(unsigned* top, int member, int Gs, unsig
             if ((spins & 31) == 31) {
                 const long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
-                if (now - t0 > GRP_TIMEOUT_TICKS) { timed_out = 1; break; }
+                if (now - t0 > timeout_ticks) { timed_out = 1; break; }
             }
             if (spins > GRP_TIMEOUT_SPINS) { timed_out = 1; break; }
         }
@@ -318,6 +325,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH], sh_rs[MAXCH];
     __shared__ int sh_timed_out, sh_slow;
     if (threadIdx.x == 0) sh_slow = 0;      // the barriers of the reduction and of the exchange come before its writers
+    // has a wait expired on this workspace before?  (asked now, needed after the tile has landed)
+    const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     GRP_STAMP(0);
     const RBlk rb = rblk_of(g, Gs);
     const Blk& b = rb.b;
@@ -360,7 +369,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     __syncthreads();
     GRP_STAMP(3);
     if (tid == 0) {
-        const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {});
+        const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {},
+                                       (st0 & 1u) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS);
         if (timed_out) atomicOr(ws.status, (unsigned)timed_out);   // bit 0: a wait expired, bit 1: the test hook
         sh_timed_out = timed_out;
         GRP_STAMP(4);
@@ -529,6 +539,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }
     __shared__ int sh_timed_out;
+    const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     GRP_STAMP(0);
     const int tid = threadIdx.x;
     int c, member;
@@ -587,7 +598,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         __hip_atomic_store(blk + member, pack_pair(cmn, cmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair has left the CU
         GRP_STAMP(3);
-        const int timed_out = grp_meet(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs, flags, [] {});
+        const int timed_out = grp_meet(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs, flags, [] {},
+                                       (st0 & 1u) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS);
         if (timed_out) atomicOr(ws.status, (unsigned)timed_out);
         sh_timed_out = timed_out;
         GRP_STAMP(4);

@@ -270,7 +270,8 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
  *        memory, zeroed once (the kernel re-arms it), so that what a workgroup reads never depends on the state of
  *        a per-XCD L2; one workspace must not be used by two launches that can run concurrently.
  *        Word 0 is a status word (cnnq_group_ws_status copies it to the host, synchronising): bit 0 is set when
- *        a wait timed out (diagnostic only, results are unaffected).
+ *        a wait timed out (results are unaffected; while it is set, later waits give up after 0.5 ms instead of 20 -
+ *        cnnq_group_ws_status_clear lowers it).
  *   qp   out: qp[CNNQ_NQP][C].   mm: optional out [2][C] = the per-channel min and max.
  *   flags  bit 0: take the recompute path unconditionally (tests).
  *          bit 1: quantize every channel through the hardware divide (tests; CNNQ_IEEE_DIVIDE=1 sets it for every
