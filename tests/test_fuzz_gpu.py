@@ -176,3 +176,49 @@ def test_weights_random_geometry(shape, seed, ba, vc, bc):
         c_ref = O.weight_correction(w, ref.clone(), vcorr=vc, bcorr=bc)
         c_out = ops.weight_correction(wd, ref.cuda(), vcorr=vc, bcorr=bc)
         np.testing.assert_allclose(c_out.cpu().numpy(), c_ref.numpy(), rtol=2e-4, atol=2e-6)
+
+
+@settings(**CFG)
+@given(shape=st.tuples(st.integers(1, 70), st.integers(1, 24), st.integers(1, 30), st.integers(1, 30)),
+       seed=st.integers(0, 2 ** 20), offset=st.integers(0, 3), wpat=st.integers(0, 8), poff=st.sampled_from([0, 4, 8, 12]))
+def test_bit_allocated_packing_random_geometry(shape, seed, offset, wpat, poff):
+    """The bit-allocated packed format over random geometries (rows of 1 ... 900 elements, whole float4s or not, short
+    and long rows), every width pattern, x / y at every 4-byte misalignment, the packed buffer at every 4-byte offset: the
+    library's choice of kernel writes the bytes of the general kernel, decodes to the codes the fused Q/DQ produces, and
+    the way back returns its floats - bit for bit; the lean forms are forced wherever they apply."""
+    from cnn_quantization_amd import _lib as L
+    from cnn_quantization_amd import ops
+    N, C, H, W = shape
+    x, xv = make(shape, seed, offset)
+    g = torch.Generator().manual_seed(seed + 1)
+    bits = ((torch.arange(C) + wpat) % 9).float().cuda()
+    qp = torch.empty((L.NQP, C))
+    qp[L.QP_SCALE] = torch.rand(C, generator=g) * 0.7 + 0.02
+    qp[L.QP_ZP] = torch.randint(0, 6, (C,), generator=g).float()
+    qp[L.QP_QMAX] = 2. ** bits.cpu() - 1.
+    qp = qp.cuda()
+    ref = ops.pc_qdq(xv, N, C, H * W, qp)
+    ro = ops.packed_layout(bits, H * W)
+    cap = ops.packed_capacity(shape)
+    pbase = torch.zeros(cap + 16, dtype=torch.uint8, device='cuda')
+    a, _ = ops.quantize_packed(xv, qp, bits, form=1)
+    used = a.numel()
+    for form in (0, 2):
+        out = pbase[poff:poff + cap]
+        try:
+            b, ro_b = ops.quantize_packed(xv, qp, bits, out=out, form=form, rowoff=ro)
+        except L.CnnqError:
+            assert form == 2                                 # the lean kernel refuses rows of < 8 elements / unaligned whole-float4 rows
+            continue
+        assert torch.equal(b[:used], a), (shape, form, offset, poff)
+    ybase = torch.empty(int(np.prod(shape)) + 3, device='cuda')
+    yv = ybase[offset:offset + int(np.prod(shape))].view(shape)
+    pk = pbase[poff:poff + cap]
+    pk[:used].copy_(a)
+    for form in (0, 1, 2):
+        try:
+            back = ops.dequantize_packed(pk, shape, qp, bits, ro, out=yv, form=form)
+        except L.CnnqError:
+            assert form == 2
+            continue
+        assert torch.equal(back, ref), (shape, form, offset, poff)
