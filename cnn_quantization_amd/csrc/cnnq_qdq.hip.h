@@ -33,7 +33,7 @@ __device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax
 //     to zp when zp != 0, and for zp == 0 (zp is never -0) both clamp / round to +0 - the same code and the same y.
 // No NaN can occur inside the domain, so the clamp is one v_med3_f32 instead of two compare+select pairs.
 // 10 VALU operations per element against 19 (of which one quarter-rate).  tests/test_fastdiv_cpu.py brute-forces the
-// quotient against the C divide; the -m gpu parity tests compare whole tensors with the oracle bit for bit.
+// quotient against the C divide; the -m gpu parity tests compare whole tensors with the CPU restatement bit for bit.
 constexpr unsigned MMQ_FLAG_TEST_HOOK = 1u;     // group kernels: skip the wait, recompute (tests)
 constexpr unsigned MMQ_FLAG_IEEE_DIVIDE = 2u;   // every channel through the hardware divide (tests, A/B: CNNQ_IEEE_DIVIDE=1)
 
