@@ -647,17 +647,39 @@ def main():
     # expire and the attempt reports verified: false - measured, expected, and why the default there is to skip).
     xrank_info = None
     import threading
+    sentinel_w = None
 
     def _bail():                                          # the attempt hangs (IPC set-up, a collective): the numbers above still go out
         out['xrank'] = {'available': False, 'note': 'the attempt did not finish within 180 s'}
         if rank == 0:
             os.write(json_fd, (json.dumps(out) + '\n').encode())
+            if sentinel_w is not None:
+                os.write(sentinel_w, b'1')
         os._exit(0)
     watchdog = threading.Timer(180., _bail)
     watchdog.daemon = True
     want_xrank = os.environ.get('CNNQ_BENCH_XRANK', '1' if backend == 'nccl' else '0') != '0'
     if world > 1 and D.xrank_exchange(group) is None and want_xrank:
+        if rank == 0:
+            # a sentinel process holds the finished line: if this process dies inside the attempt (a fault in the IPC
+            # mapping, a rank killed by the launcher), the line still reaches stdout
+            line = (json.dumps(dict(out, xrank={'available': False, 'note': 'the attempt ended the process'})) + '\n').encode()
+            pr, pw = os.pipe()
+            if os.fork() == 0:
+                os.close(pw)
+                try:
+                    msg = os.read(pr, 1)                  # b'1': the parent printed its own line; b'': it is gone
+                except OSError:
+                    msg = b''
+                if msg != b'1':
+                    os.write(json_fd, line)
+                os._exit(0)
+            os.close(pr)
+            sentinel_w = pw
         watchdog.start()
+        if os.environ.get('CNNQ_BENCH_XRANK_CRASH') == '1':      # test hook: die the hard way inside the attempt
+            import signal
+            os.kill(os.getpid(), signal.SIGKILL)
         os.environ['CNNQ_XRANK'] = '1'
         ops.reload_switches()
         try:
@@ -698,6 +720,9 @@ def main():
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
+        if sentinel_w is not None:
+            os.write(sentinel_w, b'1')                   # the line is out: the sentinel has nothing to do
+            os.close(sentinel_w)
     if world > 1 or args.force_exchange:
         from cnn_quantization_amd import rccl
         if D.xrank_exchange(group) is not None:
