@@ -708,7 +708,6 @@ def main():
                           'note': 'the same job with the per-channel exchange inside the single-launch kernels (x read once); '
                                   'opt-in, not the reported value'}
             xr.close()
-            D._XRANK.clear()
         os.environ['CNNQ_XRANK'] = '0'
         ops.reload_switches()
         watchdog.cancel()

@@ -211,6 +211,9 @@ class P2PExchange:
         if self.own is not None:
             self.lib.cnnq_p2p_free(self.own)
         self.mapped, self.own, self.ok = [], None, False
+        for cache in (_P2P, _XRANK):                     # a closed exchange must not be handed out again
+            for k in [k for k, v in cache.items() if v is self]:
+                del cache[k]
 
 
 class XRankExchange(P2PExchange):
