@@ -197,7 +197,9 @@ def roofline_objects(layers, batch, world, single_launch=True):
     # HBM bytes from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command and
     # committed under profiles/ (never measured inside a timed run); attached only to the configuration they
     # were measured on
-    pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+    pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
@@ -207,7 +209,24 @@ def roofline_objects(layers, batch, world, single_launch=True):
                 if world == 1 and k in rec.get('bytes_per_launch', {}):
                     o['traffic'] = rec['bytes_per_launch'][k]
                     o['traffic_unit'] = 'bytes per launch'
-                    o['traffic_source'] = rec.get('source', 'profiles/r03_pmc_traffic.json')
+                    o['traffic_source'] = rec.get('source', 'profiles/' + os.path.basename(pmc))
+        except (OSError, ValueError):
+            pass
+    # the same kernel's average duration under `rocprofv3 --kernel-trace --stats` of this command, committed with the box
+    # it was measured on (profiles/r04_rocprof_headline.json): next to the live figure so the two can be paired
+    rp = os.path.join(ROOT, 'profiles', 'r04_rocprof_headline.json')
+    if os.path.exists(rp) and world == 1:
+        try:
+            with open(rp) as f:
+                rec = json.load(f)
+            for name, o in objs.items():
+                k = '%s@b%d' % (name, batch)
+                if k in rec.get('avg_launch_us', {}):
+                    us = rec['avg_launch_us'][k]
+                    o['frac_rocprof'] = o['bytes_per_launch'] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    o['rocprof_avg_launch_us'] = us
+                    o['rocprof_box'] = rec.get('box')
+                    o['rocprof_source'] = rec.get('source')
         except (OSError, ValueError):
             pass
     dominant = max((n for n in objs if KERNEL_BYTES[n][0]), key=lambda n: objs[n]['time_per_step_ms'])
@@ -410,6 +429,17 @@ def other_configs(ops, device, batch):
     del vl, y5, c5
     torch.cuda.empty_cache()
     return out
+
+
+def box_id(index=0):
+    """The GPU's unique id (what `rocm-smi --showuniqueid` prints; torch exposes it as the ASCII of the device uuid): the
+    boxes of the pool differ by several percent on this workload, so every bench line and every profiles/ file names
+    the box it comes from."""
+    try:
+        u = str(torch.cuda.get_device_properties(index).uuid).replace('-', '')
+        return 'gpu-' + bytes.fromhex(u).decode('ascii')
+    except Exception:                                        # noqa: BLE001 - an identifier, never a reason to fail
+        return 'unknown'
 
 
 def cpu_model():
@@ -631,7 +661,7 @@ def main():
                    'per_gpu_batch': per_rank, 'global_batch': args.batch * (world if args.scaling == 'weak' else 1),
                    'parallelism': 'batch-sharded dp%d, per-channel stats all_gather' % world,
                    'exchange': exchange_name, 'launch': 'hip graph replay' if args.graph else 'eager'},
-        'verified': verified, 'group_status': group_status, 'xrank': None,
+        'verified': verified, 'group_status': group_status, 'xrank': None, 'box': box_id(dev_index),
         'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
         'path_note': '12 B/elem is SURVEY 8(d3)\'s accounting (statistics read + Q/DQ read + write); layers that run '
@@ -639,78 +669,12 @@ def main():
         'roofline': objs[dominant],
         'roofline_other_kernels': {k: v for k, v in objs.items() if k != dominant},
     }
-    # Several ranks, default (collective) exchange: the in-launch exchange (CNNQ_XRANK=1, csrc/cnnq_xrank.hip.h) is timed
-    # as well, AFTER the numbers above are final, and reported next to them - it has only ever run with two processes on one
-    # GPU, and a node is where it can be confirmed.  It is used only if it reproduces the collective path's bits on every
-    # rank (XRankExchange.verify); all its waits are bounded.  CNNQ_BENCH_XRANK=0 skips it, =1 runs it on a gloo rig too
-    # (several ranks sharing ONE GPU oversubscribe it at bench sizes: the co-residency the exchange relies on is gone, waits
-    # expire and the attempt reports verified: false - measured, expected, and why the default there is to skip).
+    # The in-launch cross-rank exchange (csrc/cnnq_xrank.hip.h) is opt-in: `CNNQ_XRANK=1 ... bench.py --gpus N` runs the
+    # whole job through it (config.exchange then names it; `xrank` reports whether it stayed healthy).  It is never
+    # attempted next to the default run: a hang there must surface as a failing run of its own, not behind a printed line.
     xrank_info = None
-    import threading
-    sentinel_w = None
-
-    def _bail():                                          # the attempt hangs (IPC set-up, a collective): the numbers above still go out
-        out['xrank'] = {'available': False, 'note': 'the attempt did not finish within 180 s'}
-        if rank == 0:
-            os.write(json_fd, (json.dumps(out) + '\n').encode())
-            if sentinel_w is not None:
-                os.write(sentinel_w, b'1')
-        os._exit(0)
-    watchdog = threading.Timer(180., _bail)
-    watchdog.daemon = True
-    want_xrank = os.environ.get('CNNQ_BENCH_XRANK', '1' if backend == 'nccl' else '0') != '0'
-    if world > 1 and D.xrank_exchange(group) is None and want_xrank:
-        if rank == 0:
-            # a sentinel process holds the finished line: if this process dies inside the attempt (a fault in the IPC
-            # mapping, a rank killed by the launcher), the line still reaches stdout
-            line = (json.dumps(dict(out, xrank={'available': False, 'note': 'the attempt ended the process'})) + '\n').encode()
-            pr, pw = os.pipe()
-            if os.fork() == 0:
-                os.close(pw)
-                try:
-                    msg = os.read(pr, 1)                  # b'1': the parent printed its own line; b'': it is gone
-                except OSError:
-                    msg = b''
-                if msg != b'1':
-                    os.write(json_fd, line)
-                os._exit(0)
-            os.close(pr)
-            sentinel_w = pw
-        watchdog.start()
-        if os.environ.get('CNNQ_BENCH_XRANK_CRASH') == '1':      # test hook: die the hard way inside the attempt
-            import signal
-            os.kill(os.getpid(), signal.SIGKILL)
-        os.environ['CNNQ_XRANK'] = '1'
-        ops.reload_switches()
-        try:
-            xr = D.xrank_exchange(group)                  # collective: windows, handles, verification
-        except Exception as e:                            # noqa: BLE001 - the reported numbers must still go out
-            xr, xrank_info = None, {'available': False, 'error': str(e)[:200]}
-        if xr is None:
-            xrank_info = xrank_info or {'available': False}
-        else:
-            for _ in range(max(1, args.warmup)):
-                step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            barrier()
-            dtx = time.perf_counter() - t0
-            tx = torch.tensor([dtx], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
-            dist.all_reduce(tx, op=dist.ReduceOp.MAX)
-            okx = verify_outputs(ops, layers, group, world) and xr.healthy()     # against the collective path's second run
-            vx = torch.tensor([1 if okx else 0], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
-            dist.all_reduce(vx, op=dist.ReduceOp.MIN)
-            xrank_info = {'available': True, 'ms_per_step': float(tx.item()) * 1e3 / args.steps,
-                          'value': total_elems * args.steps / float(tx.item()), 'unit': 'elements/s',
-                          'verified': bool(int(vx.item())),
-                          'note': 'the same job with the per-channel exchange inside the single-launch kernels (x read once); '
-                                  'opt-in, not the reported value'}
-            xr.close()
-        os.environ['CNNQ_XRANK'] = '0'
-        ops.reload_switches()
-        watchdog.cancel()
+    if D.xrank_exchange(group) is not None:
+        xrank_info = {'used': True, 'healthy': bool(D.xrank_exchange(group).healthy())}
     out['xrank'] = xrank_info
     if rank == 0:
         if world == 1 and not args.force_exchange:
@@ -719,9 +683,6 @@ def main():
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
-        if sentinel_w is not None:
-            os.write(sentinel_w, b'1')                   # the line is out: the sentinel has nothing to do
-            os.close(sentinel_w)
     if world > 1 or args.force_exchange:
         from cnn_quantization_amd import rccl
         if D.xrank_exchange(group) is not None:

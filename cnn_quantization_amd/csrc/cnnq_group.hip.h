@@ -65,10 +65,10 @@ constexpr int GRP_SUB = 16;                        // members per arrival counte
 
 #ifdef GRP_TRACE
 // development build only (tools/trace_group.py): lane 0 of every workgroup stamps its phases with the 100 MHz clock
-__device__ unsigned long long* g_grp_trace = nullptr;   // [workgroup][8]
+__device__ unsigned long long* g_grp_trace = nullptr;   // [workgroup][16]: 0-6 phases, 7 hardware id, 8 stores drained
 #define GRP_STAMP(i)                                                                                     \
     do {                                                                                                 \
-        if (g_grp_trace && threadIdx.x == 0) g_grp_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+        if (g_grp_trace && threadIdx.x == 0) g_grp_trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
 #else
 #define GRP_STAMP(i)
@@ -312,6 +312,16 @@ struct GWs {
     int gstride;   // pairs per group block
 };
 
+#ifndef FLAT_ABL
+#define FLAT_ABL 0        // development builds only (tools/runs/r4_ablate.sh; timing, WRONG results): bit 0 - the stores of y compiled out,
+                          // bit 1 - the meeting compiled out (every workgroup uses its own tile's extrema),
+                          // bit 2 - the loads of k_mmq_flat compiled out (synthetic values)
+#endif
+#if FLAT_ABL & 1
+#define FLAT_ABL_NOSTORE(o) && (o)[0] == 3.0e38f      // never true; the arithmetic stays
+#else
+#define FLAT_ABL_NOSTORE(o)
+#endif
 template <int A, int K, int OUT = 0, bool XR = false>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_group(
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
@@ -368,6 +378,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
     __syncthreads();
     GRP_STAMP(3);
+#if FLAT_ABL & 2
+    if (tid == 0) sh_timed_out = 0;
+    __syncthreads();
+    if (true) {
+    } else
+#else
     if (tid == 0) {
         const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {},
                                        (st0 & 1u) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS);
@@ -376,6 +392,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         GRP_STAMP(4);
     }
     __syncthreads();
+#endif
     if (sh_timed_out) {
         group_minmax_from_x<A>(x, g, b, l_mn, l_mx, sh_mn, sh_mx);
     } else if (g.mode == 1) {
@@ -456,7 +473,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o[e] = qdq1_fast(v[j][e], sc[A == 1 ? 0 : e], rs[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
-                if (ok)
+                if (ok FLAT_ABL_NOSTORE(o))
                     xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o,
                                    cd, sh_hist, zp, nzp);
             }
@@ -468,7 +485,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
                 float o[4], cd[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
-                if (ok)
+                if (ok FLAT_ABL_NOSTORE(o))
                     xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o,
                                    cd, sh_hist, zp, nzp);
             }
@@ -480,11 +497,19 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     // ---- leave the group (after the stores are issued: the round trip hides behind them); the last departure of a
     //      counter line re-arms it for the next launch
     GRP_STAMP(6);
+#if !(FLAT_ABL & 2)
     if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
+#endif
 #ifdef GRP_TRACE
-    if (g_grp_trace && tid == 0)
-        g_grp_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
-                                                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    if (g_grp_trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // what s_endpgm waits for anyway: the tile's stores acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            g_grp_trace[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+            g_grp_trace[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                       (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
 #endif
 }
 
@@ -528,6 +553,47 @@ __device__ __forceinline__ void wg_minmax1(float tn, float tx, float* l_mn, floa
     cmx = pmax(pmax(l_mx[0], l_mx[1]), pmax(l_mx[2], l_mx[3]));
 }
 
+// OUT = 2 of k_mmq_flat: the tile's packed words (one 16-bit word per float4, in the flat order of the tile: word
+// 256 j + t is lane t's step j) back out of LDS as 2 * PKL CONSECUTIVE bytes of the stream per lane, consecutive lanes
+// consecutive pieces: a wave's store instruction covers 128 * PKL contiguous bytes (inside a row), like a store of y.
+// Rows are whole groups of PKL float4 and sit on 2 * PKL byte boundaries of the stream (H*W % (4 * PKL) == 0 and an
+// aligned buffer: the caller checked).
+template <int K, int PKL, bool NT>
+__device__ __forceinline__ void flat_pk_flush(const FGeo& g, const uint16_t* sh_pk, uint8_t* pbb, unsigned f0, unsigned n_first,
+                                              unsigned lim) {
+    static_assert(PKL == 8 || PKL == 4, "16- or 8-byte stores");
+    const unsigned i0 = (unsigned)threadIdx.x * PKL;           // first word of this lane's piece in pass 0
+    const unsigned u2 = f0 + i0;
+    const unsigned n2 = u2 / g.cpc;
+    unsigned ro2 = (n2 - n_first) * g.rs, co2 = (u2 - n2 * g.cpc) * 16u;
+    constexpr unsigned stepf = 256u * PKL;                     // float4 between two passes
+    const unsigned sq = stepf / g.cpc, sr16 = (stepf % g.cpc) * 16u;
+#pragma unroll
+    for (int r = 0; r < K / PKL; ++r) {
+        const uint16_t* src = sh_pk + (r * stepf + i0);
+        if constexpr (PKL == 8) {
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            const u4v q = *reinterpret_cast<const u4v*>(src);
+            if (ro2 < lim) {
+                if (NT) __builtin_nontemporal_store(q, reinterpret_cast<u4v*>(pbb + (ro2 + co2) / 8));
+                else *reinterpret_cast<u4v*>(pbb + (ro2 + co2) / 8) = q;
+            }
+        } else {
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            const u2v q = *reinterpret_cast<const u2v*>(src);
+            if (ro2 < lim) {
+                if (NT) __builtin_nontemporal_store(q, reinterpret_cast<u2v*>(pbb + (ro2 + co2) / 8));
+                else *reinterpret_cast<u2v*>(pbb + (ro2 + co2) / 8) = q;
+            }
+        }
+        co2 += sr16;
+        ro2 += sq * g.rs;
+        const bool wrap = co2 >= g.cpc * 16u;
+        co2 -= wrap ? g.cpc * 16u : 0u;
+        ro2 += wrap ? g.rs : 0u;
+    }
+}
+
 template <int K, int OUT = 0, bool XR = false>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat(
     const float* __restrict__ x, float* __restrict__ y, const FGeo g, const int num_bits, const int positive, const GWs ws,
@@ -539,6 +605,10 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }
     __shared__ int sh_timed_out;
+    // OUT = 2: the tile's packed nibbles go through a strip of LDS per wave - written as one 16-bit word per float4
+    // ([step][lane], what a lane produces), read back as 16 (or 8) CONSECUTIVE bytes of the stream per lane and stored
+    // with one dwordx4 (dwordx2) per lane: 4 (8) store instructions per lane instead of 32 two-byte ones
+    __shared__ __attribute__((aligned(16))) uint16_t sh_pk[OUT == 2 ? TPB * K : 1];
     const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     GRP_STAMP(0);
     const int tid = threadIdx.x;
@@ -568,6 +638,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     char* yb = reinterpret_cast<char*>(y) + base;
     uint8_t* cbb = (OUT == 1 && xo.codes) ? xo.codes + base / 4 : nullptr;     // the tile's bases of the other outputs
     uint8_t* pbb = (OUT == 2) ? xo.packed + base / 8 : nullptr;
+    // lanes per wide packed store: 8 (16 bytes) when rows are whole groups of 8 float4 and sit on 16-byte boundaries of
+    // the stream, 4 (8 bytes) for rows of whole groups of 4 (28x28), else 1 (the 2-byte store per float4)
+    const int pkl = (OUT != 2 || (flags & MMQ_FLAG_PK_NARROW)) ? 1 : (g.cpc % 8u == 0u) ? 8 : (g.cpc % 4u == 0u) ? 4 : 1;
 
     // ---- the tile: K 16-byte loads per lane, back to back; past the end of the channel a lane re-reads the tile
     //      base's row start (an element of the same channel: harmless for the extrema, never stored)
@@ -576,7 +649,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+#if FLAT_ABL & 4
+        for (int e = 0; e < 4; ++e) v[j][e] = (float)(int)((off >> 4) + (unsigned)e) * 1e-4f - 3.f;      // no loads: synthetic values
+        (void)xb;
+#else
         ldv_nt<4>(reinterpret_cast<const float*>(xb + off), v[j]);
+#endif
         w.step(g);
     }
     // nothing that consumes a loaded value may be scheduled in between the loads (the scheduler otherwise folds the
@@ -594,6 +672,10 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
 
     // ---- publish, arrive, wait (the protocol of k_mmq_group; one pair per member)
     unsigned long long* blk = ws.part + (size_t)c * ws.gstride;
+#if FLAT_ABL & 2
+    if (tid == 0) sh_timed_out = 0;
+    const float own_mn = cmn, own_mx = cmx;
+#else
     if (tid == 0) {
         __hip_atomic_store(blk + member, pack_pair(cmn, cmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair has left the CU
@@ -604,6 +686,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         sh_timed_out = timed_out;
         GRP_STAMP(4);
     }
+#endif
     __syncthreads();
     float tn = INFINITY, tx = -INFINITY;
     if (sh_timed_out) {
@@ -619,12 +702,17 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             }
         if (nn) { tn = NAN; tx = NAN; }
     } else {
+#if FLAT_ABL & 2
+        tn = own_mn;
+        tx = own_mx;
+#else
         for (int m = tid; m < g.Gs; m += TPB) {
             float a, b;
             unpack_pair(__hip_atomic_load(blk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, b);
             tn = pmin(tn, a);
             tx = pmax(tx, b);
         }
+#endif
     }
     wg_minmax1(tn, tx, l_mn, l_mx, cmn, cmx);
     if constexpr (XR) {
@@ -672,7 +760,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             float o[4], cd[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], s_sc, s_rs, s_zp, qm, cd[e]);
-            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            if constexpr (OUT == 2) {
+                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
+                else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            } else {
+                if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            }
             w.step(g);
         }
     } else {
@@ -681,19 +774,44 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             float o[4], cd[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
-            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            if constexpr (OUT == 2) {
+                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
+                else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            } else {
+                if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            }
             w.step(g);
         }
     }
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zpa, nzp);
     }
+    if constexpr (OUT == 2) {
+        if (pkl > 1) {
+            __syncthreads();
+            if (flags & MMQ_FLAG_PK_PLAIN) {
+                if (pkl == 8) flat_pk_flush<K, 8, false>(g, sh_pk, pbb, f0, n_first, lim);
+                else flat_pk_flush<K, 4, false>(g, sh_pk, pbb, f0, n_first, lim);
+            } else {
+                if (pkl == 8) flat_pk_flush<K, 8, true>(g, sh_pk, pbb, f0, n_first, lim);
+                else flat_pk_flush<K, 4, true>(g, sh_pk, pbb, f0, n_first, lim);
+            }
+        }
+    }
     GRP_STAMP(6);
+#if !(FLAT_ABL & 2)
     if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);
+#endif
 #ifdef GRP_TRACE
-    if (g_grp_trace && tid == 0)
-        g_grp_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
-                                                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    if (g_grp_trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // what s_endpgm waits for anyway: the tile's stores acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            g_grp_trace[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+            g_grp_trace[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                       (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
 #endif
 }
 

@@ -654,12 +654,16 @@ int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64
     hipError_t e = hipExtMallocWithFlags(window, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) return (int)e;
     e = hipMemset(*window, 0, bytes);                  // sequence numbers start at 1
-    if (e != hipSuccess) return (int)e;
     hipIpcMemHandle_t h;
-    e = hipIpcGetMemHandle(&h, *window);
-    if (e != hipSuccess) return (int)e;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, *window);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {                             // nothing is handed out on failure: the window is released here
+        (void)hipFree(*window);
+        *window = nullptr;
+        return (int)e;
+    }
     memcpy(handle, &h, 64);
-    return (int)hipDeviceSynchronize();
+    return 0;
 }
 
 int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,

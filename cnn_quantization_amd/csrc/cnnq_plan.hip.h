@@ -395,6 +395,10 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
     if (p.flat) {
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
+        static const int pk_narrow = env_int("CNNQ_PK_NARROW", 0);          // development knob: the 2-byte stores of round 3
+        if (out == 2 && (pk_narrow || ((uintptr_t)xo.packed & 15))) flags |= MMQ_FLAG_PK_NARROW;
+        static const int pk_plain = env_int("CNNQ_PK_PLAIN", 0);
+        if (out == 2 && pk_plain) flags |= MMQ_FLAG_PK_PLAIN;
 #define LAUNCH_F(K)                                                                                                                  \
     do {                                                                                                                             \
         if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo, xr); \

@@ -36,6 +36,8 @@ __device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax
 // quotient against the C divide; the -m gpu parity tests compare whole tensors with the CPU restatement bit for bit.
 constexpr unsigned MMQ_FLAG_TEST_HOOK = 1u;     // group kernels: skip the wait, recompute (tests)
 constexpr unsigned MMQ_FLAG_IEEE_DIVIDE = 2u;   // every channel through the hardware divide (tests, A/B: CNNQ_IEEE_DIVIDE=1)
+constexpr unsigned MMQ_FLAG_PK_PLAIN = 8u;      // OUT = 2 (development, CNNQ_PK_PLAIN=1): plain instead of non-temporal wide stores
+constexpr unsigned MMQ_FLAG_PK_NARROW = 4u;     // OUT = 2: the packed buffer is not 16-byte aligned (or CNNQ_PK_NARROW=1): one 2-byte store per float4
 
 __device__ __forceinline__ bool qdq_fast_domain(float cmn, float cmx, float scale) {
     return fabsf(cmn) <= 0x1p70f && fabsf(cmx) <= 0x1p70f && scale <= 0x1p30f;   // false for NaN / Inf extrema
@@ -232,6 +234,11 @@ __device__ __forceinline__ void xhist_flush(unsigned* sh_hist, unsigned long lon
         for (int r = 0; r < HREP; ++r) tot += sh_hist[tid * HREP + ((r + tid) & (HREP - 1))];
         if (tot) atomicAdd(&hist[(size_t)(blockIdx.x & (XHIST_REPLICAS - 1)) * 256 + tid], (unsigned long long)tot);
     }
+}
+// four 4-bit codes of one float4 -> the 16-bit word of the packed stream (element 0 in the low nibble)
+__device__ __forceinline__ uint16_t pack4_of(const float (&cd)[4]) {
+    return (uint16_t)(((unsigned)cd[0] & 15u) | (((unsigned)cd[1] & 15u) << 4) | (((unsigned)cd[2] & 15u) << 8) |
+                      (((unsigned)cd[3] & 15u) << 12));
 }
 // one float4 of results at byte offset `boff` (of the fp32 tensor) from the three bases: y, the codes (one byte per
 // element: boff / 4) and the packed nibbles (boff / 8).  OFF is size_t, or unsigned when the bases are per-workgroup

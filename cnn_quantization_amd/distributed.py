@@ -225,6 +225,9 @@ class XRankExchange(P2PExchange):
     same calls in the same order."""
     CMAX = 4096                                         # channels per (parity, rank) record block: 1 MB at 8 ranks
     TIMEOUT_TICKS = 200000000                           # 2 s of the 100 MHz clock
+    CHECK_EVERY = 64                                    # launches between two host checks of the status word (about one per
+                                                        # ResNet-50 forward): an expired peer wait poisons that rank's y / qp
+                                                        # with NaN while its peers finish, so the ranks diverge until the check
 
     def __init__(self, group=None):
         super().__init__(group)

@@ -106,6 +106,10 @@ def _out_like(x, out):
     if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
             and out.shape == x.shape and out.device == x.device):
         raise L.CnnqError('out must be a contiguous float32 tensor on %s shaped like the input' % (x.device,))
+    if out.untyped_storage().data_ptr() == x.untyped_storage().data_ptr():
+        # the kernels declare x and y __restrict__, and a single-launch workgroup whose bounded wait expires recomputes
+        # its channels' extrema by re-reading x after other members may have stored y (include/cnnq_hip.h: x != y)
+        raise L.CnnqError('out must not share storage with the input (in-place quantization is not supported)')
     return out
 
 
@@ -361,6 +365,11 @@ def _hist_replicas(x, st):
     key = (x.device.index, st)
     t = _HIST_REP.get(key)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            # first use under a stream capture: the zero fill would only be RECORDED and the block would belong to the
+            # graph's pool - an eager call on this stream later would count into a table that was never zeroed.  The
+            # caller takes the chain for this call instead (its histogram is a per-call buffer).
+            return None
         t = _HIST_REP[key] = torch.zeros(L.load().cnnq_hist_replica_bytes() // 8, dtype=torch.int64, device=x.device)
     return t
 
@@ -380,6 +389,8 @@ def minmax_qdq_single(x, N, C, HW, num_bits, positive=False, want_codes=False, w
     qp = torch.empty((L.NQP + 2, C), dtype=torch.float32, device=x.device)
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
     hist = _hist_replicas(x, st) if want_entropy else None
+    if want_entropy and hist is None:
+        return None
     rc = lib.cnnq_pc_minmax_qdq_single(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), gws,
                                        GROUP_WS_BYTES if gws is not None else 0, _ptr(qp), _ptr(qp[L.NQP:]), _ptr(codes),
                                        _ptr(hist), None, st)

@@ -60,6 +60,7 @@ SHAPES = [
     (70, 40, 7, 7), (300, 24, 7, 7), (37, 24, 14, 14), (200, 12, 14, 14), (64, 256, 14, 14),          # group (A = 4, 1)
     (8, 32, 14, 14), (8, 64, 7, 7), (4, 16, 28, 28), (64, 40, 7, 7),                                   # whole channels
     (130, 2, 40, 36), (600, 2, 8, 8),
+    (40, 3, 4, 131), (64, 6, 28, 28), (96, 5, 56, 56),      # flat tiles: rows of odd / 4-float4 / 8-float4 groups (packed store widths)
 ]
 
 
@@ -107,6 +108,10 @@ def test_packed_from_the_single_launch(ops, shape, bits, half):
         # the product's own decoder, and the bytes of the separate quantize+pack pass with the same parameters
         assert torch.equal(ops.dequantize_pack4(packed, x.shape, qp), y)
         assert torch.equal(ops.quantize_pack4(x, qp), packed)
+    # a packed buffer that is only 2-byte aligned (the ABI's requirement): the narrow stores, the same bytes
+    big = torch.zeros(packed.numel() + 16, dtype=torch.uint8, device='cuda')
+    p2, _ = ops.minmax_quantize_pack4(x, bits, half, out=big[2:2 + packed.numel()])
+    assert torch.equal(p2, packed) and int(big[:2].sum()) == 0 and int(big[2 + packed.numel():].sum()) == 0
     with pytest.raises(Exception):
         ops.minmax_quantize_pack4(x, 8, half)
 

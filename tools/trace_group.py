@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--shapes', type=str, default='256x56,64x112,512x28,1024x14,256x14')
+    ap.add_argument('--save', type=str, default='', help='directory for the raw stamps (npz per shape)')
     args = ap.parse_args()
     lib = _lib.load()
     lib.cnnq_debug_group_trace.restype = ctypes.c_int
@@ -39,7 +40,7 @@ def main():
         d = (ctypes.c_int32 * 8)()
         assert lib.cnnq_pc_group_describe(N, C, HW, d) == 0
         A, K, mode, S, ncb, Gs, ngroups, wgs = list(d)
-        tr = torch.zeros((wgs, 8), dtype=torch.int64, device=dev)
+        tr = torch.zeros((wgs, 16), dtype=torch.int64, device=dev)
 
         def run(i):
             _lib.check(lib.cnnq_pc_minmax_qdq_group(xs[i].data_ptr(), ys[i].data_ptr(), N, C, HW, 4, int(half), ws,
@@ -58,6 +59,9 @@ def main():
         t_traced = e0.elapsed_time(e1) * 1e3
         _lib.check(lib.cnnq_debug_group_trace(None), 'trace off')
         t = tr.cpu().numpy()
+        if args.save:
+            os.makedirs(args.save, exist_ok=True)
+            np.savez_compressed(os.path.join(args.save, 'trace_%dx%d.npz' % (C, hw)), t=t, plain_us=t_plain, traced_us=t_traced, Gs=Gs, K=K)
         hw_id = t[:, 7]
         T = t[:, :7].astype(np.float64) / 100.0     # us
         T -= T[:, 0].min()
@@ -66,9 +70,10 @@ def main():
               'stamped span %.1f us | %.0f GB/s (8 B/elem)' % (N, C, hw, hw, A, K, mode, S, Gs, ngroups, wgs, t_plain,
                                                              t_traced, span, N * C * HW * 8 / t_plain / 1e3))
         names = ['start->loads issued', 'issued->tile reduced', 'reduced->published', 'published->met',
-                 'met->params', 'params->stores issued', 'whole workgroup']
+                 'met->params', 'params->stores issued', 'stores issued->drained', 'whole workgroup']
+        Tend = t[:, 8].astype(np.float64) / 100.0 - (t[:, 0].astype(np.float64) / 100.0).min()
         segs = [T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], T[:, 4] - T[:, 3], T[:, 5] - T[:, 4],
-                T[:, 6] - T[:, 5], T[:, 6] - T[:, 0]]
+                T[:, 6] - T[:, 5], Tend - T[:, 6], Tend - T[:, 0]]
         for nm, sgm in zip(names, segs):
             print('   %-24s p10 %6.2f  p50 %6.2f  p90 %6.2f  max %7.2f us' % (nm, pct(sgm, 10), pct(sgm, 50), pct(sgm, 90), sgm.max()))
         # residency over time
