@@ -1,0 +1,152 @@
+"""bench_other.py - the `other_configs` object of bench.py's JSON line: BASELINE.json configs 1, 3, 4, 5 (and config 2 with
+its optional outputs) on one GPU, each timed like the headline and checked after its timed region.  Imported by bench.py
+only when the default single-GPU run asks for it (`--no-other-configs` skips it)."""
+import math
+
+import torch
+
+from bench import HBM_PEAK_GBS, RESNET50_CONV_OUTPUTS, VGG16_CONV_OUTPUTS, laplace_activation, timed_best
+
+
+def other_configs(ops, device, batch):
+    """BASELINE.json configs 1, 3, 4, 5 (and config 2 with its optional outputs) on one GPU, inputs resident, best of 3
+    wall-clock passes bracketed by synchronisation; algorithmic bytes per element as SURVEY.md 8(d3).  After the timing
+    of each entry ONE layer of it is checked (`verified`): properties of the result that need no oracle, on the
+    largest tensor of the set."""
+    from cnn_quantization_amd import _lib as Lb
+
+    def obj(elems, t, bpe, what, verified=None):
+        gbs = elems * bpe / t / 1e9
+        return {'workload': what, 'ms': t * 1e3, 'value': elems / t, 'unit': 'elements/s', 'verified': verified,
+                'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                             'algorithmic_bytes_per_element': bpe, 'traffic': None}}
+
+    def codes_consistent(y, codes, qp, C):
+        sc, zp, qm = (qp[r].view(1, C, 1, 1) for r in (Lb.QP_SCALE, Lb.QP_ZP, Lb.QP_QMAX))
+        cf = codes.float()
+        return bool((cf <= qm).all()) and bool(torch.equal((cf - zp) * sc, y))
+
+    out = {}
+    # ---- config 1
+    xs = [laplace_activation((32, 64, 112, 112), 1 + i, device) for i in range(16)]
+    t = timed_best(lambda: [ops.minmax_qdq_per_tensor(x, 8, avg_over_batch=True) for x in xs])
+    x = xs[0]
+    y = ops.minmax_qdq_per_tensor(x, 8, avg_over_batch=True)
+    flat = x.view(32, -1)
+    mn, mx = float(flat.min(1)[0].mean()), float(flat.max(1)[0].mean())        # iq.py:361-379: batch mean of the extrema
+    step = (mx - mn) / 255.
+    inside = (x >= mn) & (x <= mx)
+    ok1 = int(torch.unique(y).numel()) <= 256 and float(((x - y).abs() * inside).max()) <= 0.5001 * step + 1e-6
+    out['config1'] = obj(xs[0].numel() * 16, t, 12, 'per-tensor int8 GEMMLOWP Q/DQ with dynamic min/max on 16 distinct '
+                         '[32,64,112,112] tensors (%.1f us per tensor)' % (t / 16 * 1e6), bool(ok1))
+    del xs, x, y, flat, inside
+    layers, seed = [], 100
+    for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
+        for _ in range(count):
+            layers.append((laplace_activation((batch, C, hw, hw), seed, device), half))
+            seed += 1
+    elems = sum(x.numel() for x, _ in layers)
+    big = max(range(len(layers)), key=lambda i: layers[i][0].numel())
+    xb, hb = layers[big]
+    Cb = xb.shape[1]
+    ys = [torch.empty_like(x) for x, _ in layers]
+    # ---- config 2 with the entropy of the codes (-me), and with the packed codes as the stored result
+    t = timed_best(lambda: [ops.act_qdq_per_channel(x, 4, positive=half, want_entropy=True, out=y)
+                            for (x, half), y in zip(layers, ys)])
+    yb, cb, eb, pb = ops.act_qdq_per_channel(xb, 4, positive=hb, want_codes=True, want_entropy=True, want_parts=True)
+    cnt = torch.bincount(cb.flatten()[:1 << 28].long(), minlength=16) if cb.numel() <= (1 << 28) else None
+    if cnt is None:
+        cnt = torch.zeros(16, dtype=torch.int64, device=device)
+        for n0 in range(0, xb.shape[0], 64):
+            cnt += torch.bincount(cb[n0:n0 + 64].flatten().long(), minlength=16)
+    pr = cnt[cnt > 0].double() / xb.numel()
+    ent_ref = float(-(pr * torch.log2(pr)).sum())
+    ok2 = (bool(torch.equal(yb, ys[big])) and codes_consistent(yb, cb, pb['qp'], Cb)
+           and abs(float(eb) - ent_ref) <= 2e-5 * max(1., ent_ref))
+    out['config2_entropy'] = obj(elems, t, 8, 'ResNet-50 b%d, config 2 plus the Shannon entropy of the integer codes (-me, '
+                                 'iq.py:586-587): one launch per tensor with the code histogram fused in, one tiny entropy '
+                                 'launch' % batch, bool(ok2))
+    del cb, cnt
+    pbufs = [torch.empty(x.numel() // 2, dtype=torch.uint8, device=device) for x, _ in layers]
+    t = timed_best(lambda: [ops.minmax_quantize_pack4(x, 4, half, out=b) for (x, half), b in zip(layers, pbufs)])
+    pk, qpk = ops.minmax_quantize_pack4(xb, 4, hb)
+    ok2p = bool(torch.equal(pk, pbufs[big])) and bool(torch.equal(qpk, pb['qp']))
+    if xb[0, 0].numel() % 4 == 0:
+        ok2p = ok2p and bool(torch.equal(ops.dequantize_pack4(pk, xb.shape, qpk), yb))
+    out['config2_packed_single_launch'] = obj(elems, t, 4.5, 'ResNet-50 b%d, config 2 with the packed 4-bit codes as the STORED '
+                                              'result instead of the dequantized floats: one launch, 4 B read + 0.5 B written '
+                                              'per element (SURVEY 8 f3)' % batch, bool(ok2p))
+    del pbufs, pk, yb, pb
+    # ---- config 3
+    t = timed_best(lambda: [ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, out=y)
+                            for (x, half), y in zip(layers, ys)])
+    y3, c3, p3 = ops.act_qdq_per_channel(xb, 4, positive=hb, clip='laplace', bit_alloc=True, want_codes=True, want_parts=True)
+    bits3 = p3['diag'][Lb.DIAG_BITS]
+    ok3 = (bool(torch.equal(y3, ys[big])) and codes_consistent(y3, c3, p3['qp'], Cb) and float(bits3.min()) >= 0
+           and float(bits3.max()) <= 8 and abs(float(bits3.mean()) - 4.) <= 0.011 + 1. / Cb)      # iq.py:403, in steps of 1/C
+    out['config3'] = obj(elems, t, 16, 'ResNet-50 b%d, per-channel int4 + ACIQ laplace + bit allocation, dynamic statistics '
+                         '(-c laplace -baa)' % batch, bool(ok3))
+    del ys, c3
+    # the same configuration with the bit-allocated integer codes as the STORED result
+    # (sum(bits)/8 bytes per position instead of 4 B/elem of dequantized floats); the packing pass alone is timed: its
+    # parameters - scale / zero point / width per channel and the row layout that follows from the widths - come from
+    # one untimed statistics + parameter run per tensor
+    pk = []
+    for (x, half) in layers:
+        _, parts = ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, want_parts=True)
+        bits = parts['diag'][Lb.DIAG_BITS].contiguous()
+        pk.append((x, parts['qp'], bits, ops.packed_layout(bits, x.shape[2] * x.shape[3])))
+    del _
+    stored = [ops.quantize_packed(x, qp, bits) for x, qp, bits, _ in pk]
+    nbytes = sum(p.numel() for p, _ in stored)
+    del stored
+    torch.cuda.empty_cache()
+    bufs = [torch.empty(ops.packed_capacity(x.shape), dtype=torch.uint8, device=device) for x, _, _, _ in pk]
+    t = timed_best(lambda: [ops.quantize_packed(x, qp, bits, out=b, rowoff=ro) for (x, qp, bits, ro), b in zip(pk, bufs)])
+    t_with_layout = timed_best(lambda: [ops.quantize_packed(x, qp, bits, out=b) for (x, qp, bits, _), b in zip(pk, bufs)])
+    bpe = 4 + nbytes / elems
+    # ... and the way back: stored codes -> fp32 (what the next layer's kernel would fuse into its load)
+    ys = [torch.empty_like(x) for x, _, _, _ in pk]
+    t_load = timed_best(lambda: [ops.dequantize_packed(b, x.shape, qp, bits, ro, out=yy)
+                                 for (x, qp, bits, ro), b, yy in zip(pk, bufs, ys)])
+    ok3p = bool(torch.equal(ys[big], y3))                 # stored codes -> fp32 == the fused Q/DQ of config 3, bit for bit
+    del bufs, ys, y3
+    out['config3_packed_storage'] = obj(elems, t, bpe, 'ResNet-50 b%d, the quantize+pack pass of config 3 with the bit-allocated '
+                                        'codes as the stored format: %.3f bytes per element written (fp32 dequantized: 4), into '
+                                        'preallocated buffers (no host read); one launch per tensor, the row layout comes with '
+                                        'the parameters' % (batch, nbytes / elems), ok3p)
+    out['config3_packed_storage']['ms_with_layout_launch'] = t_with_layout * 1e3      # the layout recomputed in front of every pass
+    out['config3_packed_load'] = obj(elems, t_load, bpe, 'ResNet-50 b%d, the inverse pass: bit-allocated stored codes -> '
+                                     'dequantized fp32 (%.3f bytes per element read, 4 written)' % (batch, nbytes / elems), ok3p)
+    del pk
+    # ---- config 4
+    t = timed_best(lambda: [ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True,
+                                         need_relu=True) for x, _ in layers])
+    st4, _ = ops.pc_stats(xb, xb.shape[0], Cb, xb.shape[2] * xb.shape[3], need_b=True, need_kurt=True, need_relu=True)
+    sub = xb[:, :8].double()
+    m8, s8 = sub.mean(dim=(0, 2, 3)), sub.transpose(0, 1).reshape(8, -1).std(1, unbiased=True)
+    ok4 = (bool(torch.equal(st4[Lb.STAT_MAX], xb.amax(dim=(0, 2, 3)))) and bool(torch.equal(st4[Lb.STAT_MIN], xb.amin(dim=(0, 2, 3))))
+           and float(((st4[Lb.STAT_MEAN][:8].double() - m8).abs() / m8.abs().clamp(min=1e-3)).max()) < 1e-5
+           and float(((st4[Lb.STAT_STD][:8].double() - s8).abs() / s8).max()) < 1e-5)
+    out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics' % batch, bool(ok4))
+    del layers, xb, sub
+    torch.cuda.empty_cache()
+    # ---- config 5
+    vl, seed = [], 500
+    for (C, hw, count) in VGG16_CONV_OUTPUTS:
+        for _ in range(count):
+            vl.append(laplace_activation((batch, C, hw, hw), seed, device))
+            seed += 1
+    elems = sum(x.numel() for x in vl)
+    t = timed_best(lambda: [ops.mid_tread_qdq(x, 4, clip=True, sym=False, want_entropy=True) for x in vl], reps=2)
+    xv = vl[2]                                             # [b, 128, 112, 112]
+    y5, e5, c5, p5 = ops.mid_tread_qdq(xv, 4, clip=True, sym=False, want_entropy=True, want_codes=True, want_parts=True)
+    Cv = xv.shape[1]
+    d5, lo5, hi5 = (p5['mt'][r].view(1, Cv, 1, 1) for r in (Lb.MT_DELTA, Lb.MT_CMIN, Lb.MT_CMAX))
+    ok5 = (bool(torch.equal(c5 * d5, y5)) and bool((c5 >= lo5).all()) and bool((c5 <= hi5).all())
+           and int(p5['hist'][:-1].sum()) == xv.numel() and math.isfinite(float(e5)))
+    out['config5'] = obj(elems, t, 16, 'VGG-16 b%d, mid-tread per-channel W4A4 + ACIQ + bin allocation + entropy (-mtq -me)' % batch,
+                         bool(ok5))
+    del vl, y5, c5
+    torch.cuda.empty_cache()
+    return out

@@ -399,12 +399,18 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         if (out == 2 && (pk_narrow || ((uintptr_t)xo.packed & 15))) flags |= MMQ_FLAG_PK_NARROW;
         static const int pk_plain = env_int("CNNQ_PK_PLAIN", 0);
         if (out == 2 && pk_plain) flags |= MMQ_FLAG_PK_PLAIN;
+        // With no y to write the launch is bound by what the resident workgroups hold for how long, not by the stores:
+        // a channel's members dispatched in one burst (member fastest) wait 2-4 us for each other, blocks of 4 channels
+        // ~9 us (a channel's members then start over four slot releases).  [512,256,56,56]: 464 -> 421 us (round 4).
+        FGeo fg = p.fg;
+        static const int cb_forced = env_int("CNNQ_GRP_CB", 0);
+        if (out == 2 && !cb_forced) fg.cb = 1;
 #define LAUNCH_F(K)                                                                                                                  \
     do {                                                                                                                             \
-        if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
-        else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);      \
-        else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo); \
-        else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, p.fg, num_bits, positive, w, qp, mm, flags, xo);               \
+        if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);      \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo); \
+        else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)
         if (p.K == 32) LAUNCH_F(32); else if (p.K == 16) LAUNCH_F(16); else LAUNCH_F(8);
 #undef LAUNCH_F

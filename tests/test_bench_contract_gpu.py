@@ -31,7 +31,7 @@ def test_json_line_contract():
     d = run_bench('--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '8')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'verified', 'group_status',
-              'other_configs', 'ms_per_step_by_rank', 'rccl_ranks'):
+              'other_configs', 'ms_per_step_by_rank', 'rccl_ranks', 'box'):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
     assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['verified'] is True
@@ -62,3 +62,16 @@ def test_plain_process_starts_its_own_ranks():
     assert abs(max(d['ms_per_step_by_rank']) - d['ms_per_step']) / d['ms_per_step'] < 0.5
     elems = sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 64
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - elems) / elems < 1e-6       # whole-job elements over the max time
+
+
+def test_eight_ranks_on_one_gpu():
+    """The driver's N = 8 form (one batch of 64 sharded eight ways), all ranks on the one GPU over gloo: exit 0, one line,
+    eight per-rank times, the job's elements over the slowest rank's time, outputs verified on every rank."""
+    d = run_bench('--gpus', '8', '--batch', '64', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                  env={'CNNQ_BENCH_BACKEND': 'gloo'})
+    assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and d['verified'] is True
+    assert d['config']['per_gpu_batch'] == 8 and d['config']['global_batch'] == 64
+    assert len(d['ms_per_step_by_rank']) == 8 and all(t > 0 for t in d['ms_per_step_by_rank'])
+    elems = sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 64
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - elems) / elems < 1e-6
+    assert d['box'].startswith('gpu-')
