@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--shapes', type=str, default='256x56,64x112,512x28,1024x14,256x14')
     ap.add_argument('--save', type=str, default='', help='directory for the raw stamps (npz per shape)')
+    ap.add_argument('--packed', action='store_true', help='trace the packed-nibble form (OUT = 2) of the single launch')
     args = ap.parse_args()
     lib = _lib.load()
     lib.cnnq_debug_group_trace.restype = ctypes.c_int
@@ -42,7 +43,13 @@ def main():
         A, K, mode, S, ncb, Gs, ngroups, wgs = list(d)
         tr = torch.zeros((wgs, 16), dtype=torch.int64, device=dev)
 
+        pk = [torch.empty(xs[0].numel() // 2, dtype=torch.uint8, device=dev) for _ in range(2)] if args.packed else None
+
         def run(i):
+            if args.packed:
+                _lib.check(lib.cnnq_pc_minmax_qdq_single(xs[i].data_ptr(), None, N, C, HW, 4, int(half), ws, 32 << 20,
+                                                         qp.data_ptr(), None, None, None, pk[i].data_ptr(), st), 'single')
+                return
             _lib.check(lib.cnnq_pc_minmax_qdq_group(xs[i].data_ptr(), ys[i].data_ptr(), N, C, HW, 4, int(half), ws,
                                                     qp.data_ptr(), None, 0, st), 'group')
         _lib.check(lib.cnnq_debug_group_trace(None), 'trace off')
