@@ -326,7 +326,27 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
         }
         if (form == 2) return CNNQ_ENOTSUP;
     }
-    if (!quant && form != 1) {
+    if (!quant && (form == 0 || form == 3)) {
+        // round 4: one-shot workgroups in address order of y (k_unpack_flat); form 3 forces it (CNNQ_ENOTSUP when y is not
+        // 16-byte aligned, the stream not 4-byte aligned, or the tensor has 2^32 elements or more)
+        static const int allow_flat = env_int("CNNQ_UNPACK_FLAT", 1);               // development knob
+        const int64_t total = N * C * HW;
+        const bool flat_ok = al16(y) && ((uintptr_t)packed & 3) == 0 && total < ((int64_t)1 << 32) - 1024 && N * C < ((int64_t)1 << 31);
+        if (flat_ok && (allow_flat || form == 3)) {
+            const unsigned total4 = (unsigned)((total + 3) / 4), tail = (unsigned)(total - (int64_t)(total4 - 1) * 4);
+            hipStream_t fst = (hipStream_t)stream;
+            static const int U = env_int("CNNQ_UNPACK_U", 4);                     // development knob: float4 per lane
+            const dim3 fblock(TPB);
+#define LAUNCH_UF(R, UU) hipLaunchKernelGGL((k_unpack_flat<R, UU>), dim3((total4 + TPB * UU - 1) / (TPB * UU)), fblock, 0, fst, packed, y, (int)N, (int)C, (int)HW, qp, bits, rowoff, total4, tail)
+            if (HW % 4 == 0) { if (U == 1) LAUNCH_UF(1, 1); else if (U == 2) LAUNCH_UF(1, 2); else if (U == 8) LAUNCH_UF(1, 8); else LAUNCH_UF(1, 4); }
+            else if (HW >= 4) { if (U == 1) LAUNCH_UF(2, 1); else if (U == 2) LAUNCH_UF(2, 2); else LAUNCH_UF(2, 4); }
+            else LAUNCH_UF(4, 1);
+#undef LAUNCH_UF
+            return launch_status();
+        }
+        if (form == 3) return CNNQ_ENOTSUP;
+    }
+    if (!quant && form != 1 && form != 3) {
         // the load direction's lean form (k_unpack_lean): the same geometry; the packed stream is read as dwords
         const int64_t nsl = 2 * ngroups;
         const int64_t rpc = nsl <= 128 ? 128 / nsl : 1;
@@ -392,7 +412,7 @@ int cnnq_pc_dequantize_packed(const uint8_t* packed, float* y, int64_t N, int64_
 // aligned packed buffer on top of the conditions on y).  Same floats.
 int cnnq_pc_dequantize_packed_form(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,
                                    const float* bits, const uint32_t* rowoff, int form, void* stream) {
-    if (!y || form < 0 || form > 2) return CNNQ_EINVAL;
+    if (!y || form < 0 || form > 3) return CNNQ_EINVAL;
     return packed_launch(false, nullptr, y, const_cast<uint8_t*>(packed), N, C, HW, qp, bits, rowoff, stream, form);
 }
 

@@ -706,4 +706,146 @@ __global__ void __launch_bounds__(TPB) k_unpack_lean(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_unpack_flat (round 4): the load direction as ONE-SHOT workgroups in ADDRESS ORDER of y.  Measured this round
+// (tools/ubench_rw.py): a write stream runs at 6.6-7.0 TB/s when consecutive workgroups write consecutive 4 KB and at
+// 4.7-5.9 when a workgroup walks a 16-64 KB region in pieces (what one channel row per wave amounts to: four rows of
+// 12.5 KB written 2 KB at a time), while the order of the reads is free.  Here workgroup g owns float4 [256 g, 256 g + 256)
+// of the flattened y and every lane decodes its own float4: row (n, c) and slot q from the flat index (one scalar
+// division pair per workgroup, a float reciprocal per lane: at most a few row wraps inside 256 slots), the channel's
+// scale / zero point / width / row offset as per-lane loads of the small tables (L1-resident: a wave spans one or two
+// channels when rows are long), the slot's 4 b bits from the one or two dwords of the row's stream that hold them
+// (dword loads through the L1: 64 lanes read 32 b consecutive bytes), (code - zp) * scale (iq.py:591-592), one 16-byte
+// non-temporal store.  RAG (H*W % 4 != 0, e.g. 7x7): a float4 of y may straddle rows, so everything is per ELEMENT.
+// Same floats as k_unpack_lean / k_packed<false> (tests compare all forms with the fused Q/DQ).
+template <int S, int U>
+__global__ void __launch_bounds__(TPB) k_unpack_flat(const uint8_t* __restrict__ packed, float* __restrict__ y, const int N,
+                                                     const int C, const int HW, const float* __restrict__ qp,
+                                                     const float* __restrict__ bits, const uint32_t* __restrict__ rowoff,
+                                                     const unsigned total4, const unsigned tail) {
+    // A workgroup owns U * 256 consecutive float4 of y; lane t its float4 t, 256 + t, ... (U coalesced 4 KB stores).  The
+    // three memory round trips of a float4 - channel tables, stream dwords, store - are issued U at a time: with one
+    // float4 per lane the pass was latency-bound beyond the reach of the address-translation caches (3.9 TB/s on a
+    // rotated set of more than 2 GB against 6 TB/s below it; U = 4: 5.2 and 7).
+    // S = decode units per float4: 1 - rows are whole float4s (H*W % 4 == 0); 2 - ragged rows of at least 4 elements
+    // (7x7): a float4 holds the end of one row and the start of the next, each a run of consecutive bits of its row's
+    // stream; 4 - rows of fewer than 4 elements: every element is its own unit.
+    static_assert(S == 1 || S == 2 || S == 4, "units per float4");
+    const unsigned g0 = (unsigned)blockIdx.x * (TPB * U);
+    const uint32_t plane = rowoff[C];
+    constexpr int E = S * U;
+    unsigned row[E], idx[E], cnt[E];            // row (n * C + c), first element inside the row, elements (0: dead unit)
+    if constexpr (S == 1) {
+        const unsigned cpc = (unsigned)HW / 4u;
+        const unsigned row0 = g0 / cpc, q0 = g0 - row0 * cpc;
+        const float rc = 1.0f / (float)cpc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned t = q0 + (unsigned)u * TPB + threadIdx.x;            // < 2^24: the float quotient is exact +- 1
+            unsigned w = (unsigned)((float)t * rc);
+            w -= (w * cpc > t) ? 1u : 0u;
+            w += ((w + 1u) * cpc <= t) ? 1u : 0u;
+            const bool live = g0 + (unsigned)u * TPB + threadIdx.x < total4;
+            row[u] = live ? row0 + w : 0u;
+            idx[u] = live ? 4u * (t - w * cpc) : 0u;
+            cnt[u] = live ? 4u : 0u;
+        }
+    } else {
+        const double rh = 1.0 / (double)HW;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned g = g0 + (unsigned)u * TPB + threadIdx.x;
+            const unsigned e0 = g * 4u;                                       // < 2^32 - 4096 (the launch checked)
+            unsigned r0 = (unsigned)((double)e0 * rh);                        // exact +- 1 in double
+            r0 -= ((unsigned long long)r0 * (unsigned)HW > e0) ? 1u : 0u;
+            r0 += ((unsigned long long)(r0 + 1u) * (unsigned)HW <= e0) ? 1u : 0u;
+            const unsigned i0 = e0 - r0 * (unsigned)HW;
+            const unsigned have = g + 1u < total4 ? 4u : (g + 1u == total4 ? tail : 0u);      // elements of this float4 inside the tensor
+            if constexpr (S == 2) {
+                const unsigned ka = min(have, (unsigned)HW - i0);
+                row[2 * u] = have ? r0 : 0u; idx[2 * u] = have ? i0 : 0u; cnt[2 * u] = ka;
+                row[2 * u + 1] = have > ka ? r0 + 1u : 0u; idx[2 * u + 1] = 0u; cnt[2 * u + 1] = have - ka;
+            } else {
+                unsigned i = i0, r = r0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool live = (unsigned)e < have;
+                    row[4 * u + e] = live ? r : 0u; idx[4 * u + e] = live ? i : 0u; cnt[4 * u + e] = live ? 1u : 0u;
+                    ++i;
+                    if (i == (unsigned)HW) { i = 0u; ++r; }
+                }
+            }
+        }
+    }
+    // ---- round trip 1: the channels' tables (L1 / L2 resident)
+    int b[E];
+    float sc[E], zp[E];
+    uint32_t roff[E];
+    unsigned nn[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const unsigned n = row[k] / (unsigned)C, c = row[k] - n * (unsigned)C;
+        nn[k] = n;
+        b[k] = (int)bits[c];
+        sc[k] = qp[(size_t)CNNQ_QP_SCALE * C + c];
+        zp[k] = qp[(size_t)CNNQ_QP_ZP * C + c];
+        roff[k] = rowoff[c];
+    }
+    // ---- round trip 2: the one or two dwords of the row's stream that hold the unit's bits
+    uint32_t m[E], lo[E], hi[E];
+    unsigned sh[E];
+    bool anyk[E], twok[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint32_t rowbytes = (((uint32_t)HW * (uint32_t)b[k] + 31u) / 32u) * 4u;
+        const uint8_t* rowp = packed + (size_t)nn[k] * plane + roff[k];
+        const unsigned bit = (unsigned)b[k] * idx[k], d = bit >> 5;
+        // unconditional, clamped: a dead unit or a 0-bit channel (an empty row) reads the layout table instead of the
+        // stream, a unit that ends in its row's last dword reads that dword twice
+        const bool any = b[k] > 0 && cnt[k] > 0u, two = any && 4u * (d + 1u) < rowbytes;
+        const uint8_t* pl = any ? rowp + 4u * d : reinterpret_cast<const uint8_t*>(rowoff);
+        lo[k] = *reinterpret_cast<const uint32_t*>(pl);
+        hi[k] = *reinterpret_cast<const uint32_t*>(two ? pl + 4 : pl);
+        sh[k] = bit & 31u;
+        anyk[k] = any;
+        twok[k] = two;
+    }
+    // every unit's dwords in flight before the first is consumed (the scheduler otherwise waits for each pair in turn:
+    // U dependent round trips instead of one)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < E; ++k) m[k] = anyk[k] ? __builtin_amdgcn_alignbit(twok[k] ? hi[k] : 0u, lo[k], sh[k]) : 0u;
+    // ---- decode, (code - zp) * scale (iq.py:591-592), store
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned g = g0 + (unsigned)u * TPB + threadIdx.x;
+        float o[4];
+        unsigned have = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int k;
+            unsigned pos;                                                     // which unit, which of its codes
+            if constexpr (S == 1) { k = u; pos = (unsigned)e; }
+            else if constexpr (S == 4) { k = 4 * u + e; pos = 0u; }
+            else { const bool first = (unsigned)e < cnt[2 * u]; k = 2 * u; pos = first ? (unsigned)e : (unsigned)e - cnt[2 * u];
+                   if (!first) {      // the second run of the float4: the next row's first codes
+                       const unsigned cm = b[2 * u + 1] >= 8 ? 0xffu : ((1u << b[2 * u + 1]) - 1u);
+                       o[e] = ((float)((m[2 * u + 1] >> (pos * (unsigned)b[2 * u + 1])) & cm) - zp[2 * u + 1]) * sc[2 * u + 1];
+                       continue;
+                   } }
+            const unsigned cm = b[k] >= 8 ? 0xffu : ((1u << b[k]) - 1u);
+            o[e] = ((float)((m[k] >> (pos * (unsigned)b[k])) & cm) - zp[k]) * sc[k];
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) have += cnt[S * u + j];
+        if (have == 4u) {
+            stv_nt<4>(y + (size_t)g * 4, o);
+        } else if constexpr (S != 1) {            // the tensor's last, partial float4 (ragged rows only)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((unsigned)e < have) y[(size_t)g * 4 + e] = o[e];
+        }
+    }
+}
+
 }  // namespace

@@ -370,8 +370,27 @@ def test_packed_forms_write_the_same_bytes(ops, shape):
         assert torch.equal(ro_d, ro_a) and torch.equal(d, a)
         assert torch.equal(ro_a, ro_b) and torch.equal(a, b) and torch.equal(a, c), shape
         ref = ops.pc_qdq(x, N, C, H * W, qp)
-        for form in (0, 1, 2):              # the load direction: the general and the lean kernel, the same floats
+        for form in (0, 1, 2, 3):           # the load direction: the general, the lean and the flat (round 4) kernel, the same floats
             assert torch.equal(ops.dequantize_packed(b, shape, qp, bits, ro_b, form=form), ref), (shape, form)
+
+
+@pytest.mark.parametrize('shape', [(7, 6, 1, 3), (9, 5, 1, 1), (4, 3, 1, 2), (130, 7, 1, 3), (1031, 3, 1, 1)])
+def test_packed_rows_shorter_than_a_float4(ops, shape):
+    """Rows of 1-3 elements (1x1 feature maps, tiny kernels): the general kernel and the flat load kernel (every element
+    its own decode unit) against the fused Q/DQ, every width."""
+    from cnn_quantization_amd import _lib as L
+    gen = torch.Generator().manual_seed(sum(shape) + 5)
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=gen) * 3 + 0.2).cuda()
+    _, parts = ops.act_qdq_per_channel(x, 4, want_parts=True)
+    ar = torch.arange(C, device='cuda', dtype=torch.float32)
+    for bits in (ar % 9, (ar + 4) % 9, torch.full_like(ar, 4.)):
+        qp = parts['qp'].clone()
+        qp[L.QP_QMAX] = 2. ** bits - 1.
+        a, ro = ops.quantize_packed(x, qp, bits, form=1)
+        ref = ops.pc_qdq(x, N, C, H * W, qp)
+        for form in (0, 1, 3):
+            assert torch.equal(ops.dequantize_packed(a, shape, qp, bits, ro, form=form), ref), (shape, form)
 
 
 @pytest.mark.parametrize('shape', [(8, 16, 56, 56), (10, 12, 14, 14), (6, 12, 28, 28), (3, 8, 112, 112)])

@@ -78,3 +78,39 @@ extern "C" float urw(int J, int R, int order, int mode, int nt, const void* x, v
     CASE(1, 32) CASE(1, 8) CASE(1, 4) CASE(1, 1) CASE(4, 8) CASE(4, 1) CASE(2, 16) CASE(8, 4) CASE(16, 2) CASE(32, 1)
     return -1.f;
 }
+
+// the same over `nb` buffer pairs round-robin (cold address translations: the rotated set exceeds what the TLBs reach)
+template <int J, int R>
+static float multi(int order, int mode, int nt, void* const* xs, void* const* ys, int nb, void* out, int N, int P4, int rounds) {
+    const int ncb = (P4 + J * 256 - 1) / (J * 256), nrb = (N + R - 1) / R;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    auto go = [&](int i) {
+#define M_(O, M, T) if (order == O && mode == M && nt == T) hipLaunchKernelGGL((k_rw<J, R, O, M, T>), dim3(ncb * nrb), dim3(256), 0, 0, (const f4*)xs[i], (f4*)ys[i], (float*)out, N, P4, ncb);
+        M_(0, 0, 1) M_(1, 0, 1) M_(0, 1, 1) M_(1, 1, 1) M_(0, 2, 1) M_(1, 2, 1)
+#undef M_
+    };
+    for (int i = 0; i < nb; ++i) go(i);
+    (void)hipEventRecord(a, 0);
+    for (int r = 0; r < rounds; ++r)
+        for (int i = 0; i < nb; ++i) go(i);
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return ms / (rounds * nb);
+}
+
+extern "C" float urw_multi(int J, int R, int order, int mode, void* const* xs, void* const* ys, int nb, void* out, int N, int P4, int rounds) {
+    if (J == 1 && R == 1) return multi<1, 1>(order, mode, 1, xs, ys, nb, out, N, P4, rounds);
+    if (J == 1 && R == 32) return multi<1, 32>(order, mode, 1, xs, ys, nb, out, N, P4, rounds);
+    return -1.f;
+}
+
+extern "C" int urw_alloc(size_t bytes, int flags, void** p) {
+    if (flags < 0) return (int)hipMalloc(p, bytes);
+    return (int)hipExtMallocWithFlags(p, bytes, (unsigned)flags);
+}
+extern "C" int urw_free(void* p) { return (int)hipFree(p); }
+extern "C" int urw_fill(void* p, size_t bytes) { return (int)hipMemset(p, 0x3c, bytes); }
