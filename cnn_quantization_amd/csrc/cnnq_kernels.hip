@@ -686,12 +686,14 @@ int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64
     return 0;
 }
 
-int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
-                             float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
-                             uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream) {
+static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive, float* ws, void* gws,
+                        size_t gws_bytes, void* const* windows, int rank, int world, int cmax, uint32_t seq, uint32_t* seq_dev,
+                        uint32_t* status, int64_t timeout_ticks, uint8_t* codes, uint64_t* hist_rep, void* stream) {
     if (!x || !y || !ws || num_bits < 1 || num_bits > 32 || C <= 0) return CNNQ_EINVAL;
-    if (!windows || !status || world <= 0 || rank < 0 || rank >= world || !seq || C > cmax || timeout_ticks <= 0) return CNNQ_EINVAL;
+    if (!windows || !status || world <= 0 || rank < 0 || rank >= world || (!seq && !seq_dev) || C > cmax || timeout_ticks <= 0) return CNNQ_EINVAL;
     if (gws && ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
+    if ((codes || hist_rep) && num_bits > 8) return CNNQ_EINVAL;
+    if (((uintptr_t)codes & 3) || ((uintptr_t)hist_rep & 7) || ((uintptr_t)seq_dev & 3)) return CNNQ_EINVAL;
     float* qp = ws;                                       // the layout of cnnq_pc_minmax_qdq_auto's workspace
     float* mm = ws + (size_t)CNNQ_NQP * C;
     float* pmm = mm + 2 * (size_t)C;
@@ -700,28 +702,73 @@ int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int
     xr.rank = rank;
     xr.world = world;
     xr.seq = seq;
+    xr.seq_dev = seq_dev;
     xr.cmax = cmax;
     xr.status = status;
     xr.timeout = timeout_ticks;
+    const int out = (codes || hist_rep) ? 1 : 0;
+    XOut xo;
+    xo.codes = codes;
+    xo.hist = reinterpret_cast<unsigned long long*>(hist_rep);
+    xo.packed = nullptr;
     const bool al = al16(x) && al16(y);
     GPlan gp;
     const bool group_ok = gws && plan_group(N, C, HW, al, &gp) == 0 && gp.ws_bytes <= gws_bytes;
     WPlan wp;
     const bool whole_ok = plan_whole(N, C, HW, al, &wp) == 0;
     hipStream_t st = (hipStream_t)stream;
-    if (whole_ok && !(group_ok && wp.wgs < RES_MIN_WGS))
-        return launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, 0, XOut{}, 0u, &xr);
-    if (group_ok) return launch_group(x, y, gp, num_bits, positive ? 1 : 0, gws, qp, mm, 0u, st, 0, XOut{}, &xr);
-    if (whole_ok) return launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, 0, XOut{}, 0u, &xr);
-    // no single-launch kernel for this rank's shard (the ranks' shards may differ by a sample, and so may their plans):
-    // the same window protocol around two passes - local extrema, one thread per channel pushes / waits / folds, Q/DQ
-    // with the folded extrema as the only "gathered" record.  Every rank consumes the sequence number either way.
-    int rc = cnnq_pc_minmax_local_auto(x, N, C, HW, pmm, gws, gws_bytes, mm, stream);
+    int rc;
+    if (whole_ok && !(group_ok && wp.wgs < RES_MIN_WGS)) rc = launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, out, xo, 0u, &xr);
+    else if (group_ok) rc = launch_group(x, y, gp, num_bits, positive ? 1 : 0, gws, qp, mm, 0u, st, out, xo, &xr);
+    else if (whole_ok) rc = launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, out, xo, 0u, &xr);
+    else {
+        // no single-launch kernel for this rank's shard (the ranks' shards may differ by a sample, and so may their plans):
+        // the same window protocol around two passes - local extrema, one thread per channel pushes / waits / folds, Q/DQ
+        // with the folded extrema as the only "gathered" record (codes / histogram: the parameter kernel + the fused Q/DQ,
+        // which counts into the first replica table).  Every rank consumes the sequence number either way.
+        rc = cnnq_pc_minmax_local_auto(x, N, C, HW, pmm, gws, gws_bytes, mm, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_xr_exchange, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, st, mm, (int)C, xr);
+        rc = launch_status();
+        if (rc) return rc;
+        if (!out) rc = cnnq_pc_gathered_qdq(x, y, N, C, HW, mm, 1, num_bits, positive, qp, stream);
+        else {
+            rc = cnnq_pc_minmax_params(mm, 1, C, num_bits, positive, qp, stream);
+            if (!rc) rc = cnnq_pc_qdq(x, y, N, C, HW, qp, codes, hist_rep, 1, stream);
+        }
+    }
     if (rc) return rc;
-    hipLaunchKernelGGL(k_xr_exchange, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, st, mm, (int)C, xr);
-    rc = launch_status();
-    if (rc) return rc;
-    return cnnq_pc_gathered_qdq(x, y, N, C, HW, mm, 1, num_bits, positive, qp, stream);
+    if (seq_dev) {
+        hipLaunchKernelGGL(k_xr_bump, dim3(1), dim3(1), 0, st, seq_dev);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                             float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                             uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream) {
+    if (!seq) return CNNQ_EINVAL;
+    return xrank_launch(x, y, N, C, HW, num_bits, positive, ws, gws, gws_bytes, windows, rank, world, cmax, seq, nullptr, status,
+                        timeout_ticks, nullptr, nullptr, stream);
+}
+
+int cnnq_pc_minmax_qdq_xrank_dev(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                                 float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                                 uint32_t* seq_dev, uint32_t* status, int64_t timeout_ticks, uint8_t* codes, uint64_t* hist_rep,
+                                 void* stream) {
+    if (!seq_dev) return CNNQ_EINVAL;
+    return xrank_launch(x, y, N, C, HW, num_bits, positive, ws, gws, gws_bytes, windows, rank, world, cmax, 0u, seq_dev, status,
+                        timeout_ticks, codes, hist_rep, stream);
+}
+
+// the replica tables of the single-launch kernels folded into one plain table hist[256] (+=: the caller zeroes it), the
+// replicas left zero: a sharded run sums the ranks' tables before the entropy
+int cnnq_hist_replicas_fold(uint64_t* hist_rep, uint64_t* hist, void* stream) {
+    if (!hist_rep || !hist) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_hist_replicas_fold, dim3(1), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned long long*>(hist_rep), reinterpret_cast<unsigned long long*>(hist));
+    return launch_status();
 }
 
 // entropy (bits) of the replica histogram the call above filled; the tables are zero again afterwards

@@ -218,12 +218,13 @@ int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int pos
                  hipStream_t st, int out = 0, const XOut& xo = XOut{}, unsigned flags = 0u, const XRank* xrp = nullptr) {
     const dim3 grid((unsigned)p.wgs);
     flags |= mmq_env_flags();
-    const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: the cross-rank stage of cnnq_xrank.hip.h (y only)
-    if (xrank && out != 0) return CNNQ_ENOTSUP;
+    const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: the cross-rank stage of cnnq_xrank.hip.h (y, or y + codes / histogram)
+    if (xrank && out == 2) return CNNQ_ENOTSUP;
     const XRank xr = xrank ? *xrp : XRank{};
 #define LAUNCH_W(A, T, K)                                                                                                     \
     do {                                                                                                                      \
-        if (xrank) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
+        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
+        else if (xrank) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
         else if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);      \
         else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_whole<A, T, K, 2>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);               \
@@ -385,7 +386,7 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
                  unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}, const XRank* xrp = nullptr) {
     flags |= mmq_env_flags();
     const bool xrank = xrp && xrp->world > 0;
-    if (xrank && out != 0) return CNNQ_ENOTSUP;
+    if (xrank && out == 2) return CNNQ_ENOTSUP;
     const XRank xr = xrank ? *xrp : XRank{};
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
@@ -407,7 +408,8 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         if (out == 2 && !cb_forced) fg.cb = 1;
 #define LAUNCH_F(K)                                                                                                                  \
     do {                                                                                                                             \
-        if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1, true>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        else if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
         else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);      \
         else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);               \
@@ -418,7 +420,8 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     }
 #define LAUNCH_G(A, K)                                                                                                                     \
     do {                                                                                                                                   \
-        if (xrank) hipLaunchKernelGGL((k_mmq_group<A, K, 0, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        else if (xrank) hipLaunchKernelGGL((k_mmq_group<A, K, 0, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
         else if (out == 0) hipLaunchKernelGGL((k_mmq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);      \
         else if (out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_group<A, K, 2>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);               \

@@ -515,4 +515,16 @@ __global__ void __launch_bounds__(TPB) k_entropy_replicas(unsigned long long* __
     if (tid == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// the replica tables folded into one plain 256-bin table (added to it), the replicas left zero
+__global__ void __launch_bounds__(TPB) k_hist_replicas_fold(unsigned long long* __restrict__ rep, unsigned long long* __restrict__ hist) {
+    static_assert(TPB == 256, "one thread per bin");
+    const int tid = threadIdx.x;
+    unsigned long long c = 0;
+    for (int r = 0; r < XHIST_REPLICAS; ++r) {
+        c += rep[(size_t)r * 256 + tid];
+        rep[(size_t)r * 256 + tid] = 0ull;
+    }
+    hist[tid] += c;
+}
+
 }  // namespace

@@ -14,7 +14,8 @@
 //          holding the whole batch), and goes on to scale / zero point and the Q/DQ out of the registers.
 // Nothing is pushed after something is waited for, so no rank can wait for a record whose producer waits for it: the
 // ranks need the co-residency the local exchange needs and nothing more.  Sequence numbers come from the host (one per
-// launch, the same on every rank: the ranks issue the same launches in the same order on ONE stream each); two parities
+// launch, the same on every rank: the ranks issue the same launches in the same order on ONE stream each; round 4: or from a
+// device word that a one-thread kernel advances behind every launch, which makes the launch capturable); two parities
 // suffice because a rank can start launch s + 2 only after it has received every rank's records of launch s + 1, which
 // a rank pushes only after its launch s has completed.  A wait gives up after `timeout` ticks of the 100 MHz clock:
 // the channel's outputs are then NaN and bit 2 of the status word is raised (a peer that never launches would otherwise
@@ -34,7 +35,9 @@ struct XRec {
 struct XRank {
     void* const* windows;      // [world] device pointers, the own window at [rank]; world == 0: no cross-rank stage
     int rank, world;
-    unsigned seq;              // 1, 2, 3, ...
+    unsigned seq;              // 1, 2, 3, ... (host-side numbering: seq_dev == nullptr)
+    const unsigned* seq_dev;   // device-side numbering (round 4): the launch's number is *seq_dev + 1; k_xr_bump advances the
+                               // word behind the launch, so a captured graph replays with fresh numbers
     int cmax;                  // channels a window holds per (parity, rank)
     unsigned* status;          // |= XR_STATUS_PEER_TIMEOUT
     long long timeout;         // ticks of the 100 MHz clock
@@ -54,7 +57,10 @@ __device__ __forceinline__ XRec* xr_rec(void* win, const XRank& xr, int r, int c
 
 // One thread per channel: push the local extrema (if `push`), then wait for every rank's and fold them.  Returns false
 // when a wait expired (mn / mx are NaN then and the status word is raised).
-__device__ __forceinline__ bool xr_merge(const XRank& xr, int c, bool push, float& mn, float& mx) {
+__device__ __forceinline__ bool xr_merge(const XRank& xr_in, int c, bool push, float& mn, float& mx) {
+    XRank xr = xr_in;
+    // the word is only written by k_xr_bump, between launches of one stream: every thread of a launch reads the same value
+    if (xr.seq_dev) xr.seq = __hip_atomic_load(xr.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (push) {
         const unsigned long long pr = xr_pack(mn, mx);
         // The windows are uncached (fine-grained) memory: every access goes to the owner's memory, so ordering is a
@@ -97,6 +103,9 @@ __device__ __forceinline__ bool xr_merge(const XRank& xr, int c, bool push, floa
     mx = b;
     return ok;
 }
+
+// device-side sequence numbers: one thread, enqueued behind every exchanging launch
+__global__ void k_xr_bump(unsigned* seq_dev) { *seq_dev += 1u; }
 
 // the exchange alone, for a rank whose shard has no single-launch kernel: mm[2][C] local extrema in, folded extrema out
 __global__ void __launch_bounds__(TPB) k_xr_exchange(float* __restrict__ mm, const int C, const XRank xr) {

@@ -43,7 +43,7 @@ def shard_batch(n, rank_, world):
 
 def all_gather_records(rec, group=None, out=None):
     """rec [K, C] on every rank -> [W, K, C] in rank order (the G axis cnnq_pc_combine merges): the verified
-    peer-to-peer exchange when CNNQ_P2P_EXCHANGE=1, otherwise the backend's all_gather.  `out`: optional
+    peer-to-peer exchange when CNNQ_P2P_EXCHANGE=1 (or CNNQ_XRANK=1), otherwise the backend's all_gather.  `out`: optional
     preallocated [W, K, C] result (collective path only)."""
     ex = p2p_exchange(group)
     if ex is not None and ex.fits(rec):
@@ -221,8 +221,8 @@ class XRankExchange(P2PExchange):
     the batch sharded over the ranks of `group` (one process per GPU, one node), the single-launch kernels push their
     channels' extrema into every rank's window and wait for the others' inside the launch - x is read once, 8 instead of
     12 bytes per element.  Opt-in (CNNQ_XRANK=1); `verify()` cross-checks it against the collective path on every rank
-    and must pass before use.  Same rules as P2PExchange: one stream, never under graph capture, every rank issues the
-    same calls in the same order."""
+    and must pass before use.  Same rules as P2PExchange - one stream, every rank issues the same calls in the same order -
+    except that its launches CAN be captured into a HIP graph (round 4: the sequence number is a device word)."""
     CMAX = 4096                                         # channels per (parity, rank) record block: 1 MB at 8 ranks
     TIMEOUT_TICKS = 200000000                           # 2 s of the 100 MHz clock
     CHECK_EVERY = 64                                    # launches between two host checks of the status word (about one per
@@ -234,6 +234,7 @@ class XRankExchange(P2PExchange):
         import os
         ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
         self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
+        self.seq_dev = None                             # the device-side sequence word (allocated at the first launch)
 
     def _alloc_window(self, own, handle):
         import ctypes
@@ -242,25 +243,32 @@ class XRankExchange(P2PExchange):
     def fits(self, C):
         return 0 < C <= self.CMAX
 
-    def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st):
-        """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm land at the start of the
-        workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes)."""
-        import ctypes
-        if torch.cuda.is_current_stream_capturing():
-            raise self.L.CnnqError('the in-launch cross-rank exchange cannot be captured into a HIP graph (host-side sequence number)')
+    def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st, codes=None, hist_rep=None):
+        """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm (the GLOBAL extrema) land at the
+        start of the workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes).  codes / hist_rep: this rank's codes and
+        code counts (the replica tables of the single-launch kernels).  The launch's sequence number lives in device memory
+        (cnnq_pc_minmax_qdq_xrank_dev), so the call may be captured into a HIP graph - every rank then replays its graph
+        the same number of times."""
+        capturing = torch.cuda.is_current_stream_capturing()
         if self.stream is None:
             self.stream = st
         elif self.stream != st:
             raise self.L.CnnqError('XRankExchange is bound to the stream of its first launch; use one stream per group')
-        self.seq += 1
+        if self.seq_dev is None:
+            if capturing:
+                raise self.L.CnnqError('XRankExchange: run one launch eagerly before capturing (the sequence word is allocated at first use)')
+            self.seq_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.seq += 1                                   # launches ENQUEUED here (a replayed graph advances the device word, not this)
         self.calls += 1
-        if self.calls % self.CHECK_EVERY == 0 and not self.healthy():      # periodic host check (synchronises)
+        if not capturing and self.calls % self.CHECK_EVERY == 0 and not self.healthy():      # periodic host check (synchronises)
             raise self.L.CnnqError('XRankExchange: a wait for a peer expired; results since the last check are invalid')
-        rc = self.lib.cnnq_pc_minmax_qdq_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
-                                               ws_ptr, gws, gws_bytes, self.windows.data_ptr(), self.rank, self.world,
-                                               self.CMAX, self.seq, self.status.data_ptr(), self.timeout, st)
+        rc = self.lib.cnnq_pc_minmax_qdq_xrank_dev(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
+                                                   ws_ptr, gws, gws_bytes, self.windows.data_ptr(), self.rank, self.world,
+                                                   self.CMAX, self.seq_dev.data_ptr(), self.status.data_ptr(), self.timeout,
+                                                   codes.data_ptr() if codes is not None else None,
+                                                   hist_rep.data_ptr() if hist_rep is not None else None, st)
         if rc:
-            self.L.check(rc, 'cnnq_pc_minmax_qdq_xrank')
+            self.L.check(rc, 'cnnq_pc_minmax_qdq_xrank_dev')
 
     def all_gather(self, rec):
         raise self.L.CnnqError('XRankExchange carries channel extrema inside the config-2 launch only')
@@ -310,7 +318,9 @@ def xrank_exchange(group=None):
 def p2p_exchange(group=None):
     """The process-wide P2PExchange of `group` when CNNQ_P2P_EXCHANGE=1 and it verified; else None (RCCL)."""
     import os
-    if os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' or world_size(group) == 1:
+    # CNNQ_XRANK=1 implies it (round 4): a sharded run that exchanges config 2's extrema inside the launch moves the moment
+    # records of the statistics passes (configs 3 / 4 / 5) through the same kind of window - no collective launch anywhere
+    if (os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' and os.environ.get('CNNQ_XRANK', '0') != '1') or world_size(group) == 1:
         return None
     # keyed by the group's membership, not by id(group): a new group object may reuse a collected one's id
     key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))

@@ -478,21 +478,41 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         if rc:
             L.check(rc, 'cnnq_pc_minmax_qdq_auto')
         return y
-    if exchanging and not (want_codes or want_entropy or want_parts) and _xrank is not False and (_xrank is not None or _XRANK_ON):
+    if exchanging and _xrank is not False and (_xrank is not None or _XRANK_ON) and not ((want_codes or want_entropy) and num_bits > 8):
         # opt-in (CNNQ_XRANK=1, verified against the collective at first use): the exchange happens INSIDE the single
-        # launch - x is read once (csrc/cnnq_xrank.hip.h); every rank takes this branch or none does
+        # launch - x is read once (csrc/cnnq_xrank.hip.h); every rank takes this branch or none does.  Round 4: also with
+        # the codes / the entropy of the codes / the parameters wanted (the ranks' code counts are summed afterwards)
         xr = _xrank if _xrank is not None else D.xrank_exchange(group)
-        if xr is not None and xr.fits(C):
-            st = _raw_stream(x.device.index)
+        st = _raw_stream(x.device.index)
+        hist_rep = _hist_replicas(x, st) if (want_entropy and xr is not None) else None
+        if xr is not None and xr.fits(C) and not (want_entropy and hist_rep is None):
             wplan = _WS_BYTES.get((N, C, HW))
             nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
             if nbytes == 0:
                 L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
             y = _out_like(x, out)
             gws = _group_workspace(x, st) if resident else None
-            xr.minmax_qdq(x, y, N, C, HW, num_bits, positive, _scratch(x, 'cfg2', nbytes, st).data_ptr(), gws,
-                          GROUP_WS_BYTES if gws is not None else 0, st)
-            return y
+            ws = _scratch(x, 'cfg2', nbytes, st)
+            codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+            xr.minmax_qdq(x, y, N, C, HW, num_bits, positive, ws.data_ptr(), gws,
+                          GROUP_WS_BYTES if gws is not None else 0, st, codes=codes, hist_rep=hist_rep)
+            if not (want_codes or want_entropy or want_parts):
+                return y
+            res = [y]
+            if want_codes:
+                res.append(codes)
+            if want_entropy:
+                hist = torch.zeros(256, dtype=torch.int64, device=x.device)
+                L.check(lib.cnnq_hist_replicas_fold(_ptr(hist_rep), _ptr(hist), st), 'cnnq_hist_replicas_fold')
+                D.all_reduce_sum_(hist, group)                       # the global batch's code counts
+                res.append(entropy_from_hist(hist))
+            if want_parts:
+                tab = ws[:4 * (L.NQP + 2) * C].view(torch.float32).view(L.NQP + 2, C).clone()    # qp rows, then the global {min, max}
+                stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
+                stats[L.STAT_MIN] = tab[L.NQP]
+                stats[L.STAT_MAX] = tab[L.NQP + 1]
+                res.append(dict(stats=stats, qp=tab[:L.NQP], diag=None))
+            return res[0] if len(res) == 1 else tuple(res)
     if (exchanging and not (want_codes or want_entropy or want_parts)
             and not _EXCHANGE_OVERLAP):
         # the multi-GPU hot call: local extrema (one C call) -> all_gather of [2, C] -> parameters + Q/DQ (one C

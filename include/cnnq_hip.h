@@ -336,7 +336,7 @@ int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
  *   windows  device array [world] of pointers: entry r is rank r's window (cnnq_xrank_alloc on rank r, opened here with
  *            cnnq_p2p_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels.
  *   seq      1, 2, 3, ...: the same on every rank for the same launch; the ranks issue the same launches in the same
- *            order, each on ONE stream.  Not capturable into a graph (the number is a kernel argument).
+ *            order, each on ONE stream.  Not capturable into a graph (the number is a kernel argument; see _xrank_dev).
  *   status   device word: bit 2 is raised when a wait for a peer's record expired after timeout_ticks of the 100 MHz
  *            clock (the affected channels' outputs are NaN then) - check it at the next synchronisation point.
  *   ws / gws  as for cnnq_pc_minmax_qdq_auto (ws: cnnq_pc_minmax_qdq_workspace bytes; qp[CNNQ_NQP][C] and mm[2][C] - the
@@ -348,6 +348,19 @@ int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64
 int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
                              uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream);
+/* The same with DEVICE-side sequence numbers and the optional outputs of cnnq_pc_minmax_qdq_single (round 4):
+ *   seq_dev   device word (zero at start, one per rank): the launch's number is *seq_dev + 1 and a one-thread kernel
+ *             enqueued behind the launch advances the word - nothing about the call changes from launch to launch, so it
+ *             can be captured into a HIP graph and replayed (every rank replays the same graph the same number of times).
+ *   codes / hist_rep   as for cnnq_pc_minmax_qdq_single (num_bits <= 8): this rank's codes, and this rank's code counts in
+ *             the replica tables - fold them with cnnq_hist_replicas_fold, sum the folded tables over the ranks, then
+ *             cnnq_entropy gives the entropy of the global batch's codes (iq.py:586-587).
+ * cnnq_hist_replicas_fold adds the replica tables to hist[256] and leaves them zero. */
+int cnnq_pc_minmax_qdq_xrank_dev(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                                 float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                                 uint32_t* seq_dev, uint32_t* status, int64_t timeout_ticks, uint8_t* codes, uint64_t* hist_rep,
+                                 void* stream);
+int cnnq_hist_replicas_fold(uint64_t* hist_rep, uint64_t* hist, void* stream);
 
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
  * one call: pass A -> merge -> pass B when `b` is needed (laplace clipping, or bit allocation with the laplace

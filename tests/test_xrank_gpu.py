@@ -53,6 +53,39 @@ def _worker(rank, world, port, tmp):
                     if rnd == 2:
                         out['y_%d_%d' % (i, half)] = y.cpu()
         out['launches'] = ex.seq - seq0
+        # round 4: the codes, the entropy of the GLOBAL batch's codes and the parameters out of the same in-launch exchange
+        for i, shape in enumerate(SHAPES):
+            x = _batch(i, shape)
+            n0, n1 = D.shard_batch(shape[0], rank, world)
+            xs = x[n0:n1].contiguous().cuda()
+            for half in (False, True):
+                y, codes, ent, parts = ops.act_qdq_per_channel(xs, 4, positive=half, want_codes=True, want_entropy=True, want_parts=True)
+                y2, ent2 = ops.act_qdq_per_channel(xs, 4, positive=half, want_entropy=True)
+                out['o_%d_%d' % (i, half)] = (y.cpu(), codes.cpu(), float(ent), parts['qp'].cpu(), parts['stats'].cpu(), float(ent2),
+                                              bool(torch.equal(y, y2)))
+        out['launches_out'] = ex.seq - seq0 - out['launches']
+        # CNNQ_XRANK=1 also moves the moment records of the statistics passes through windows (P2PExchange): configs 3 and 5
+        # and the seven statistics, through the windows and - same calls, switch off - through the collective, bit for bit
+        x = _batch(3, (38, 24, 14, 14))
+        n0, n1 = D.shard_batch(38, rank, world)
+        xs = x[n0:n1].contiguous().cuda()
+        def stats_paths():
+            r = [ops.act_qdq_per_channel(xs, 4, clip='laplace', bit_alloc=True),
+                 ops.mid_tread_qdq(xs, 4, clip=True, sym=False)[0],
+                 ops.pc_stats(xs, xs.shape[0], 24, 196, need_b=True, need_kurt=True, need_relu=True)[0]]
+            torch.cuda.synchronize()
+            return [t.cpu() for t in r]
+        p2p = D.p2p_exchange(None)
+        out['p2p_on'] = p2p is not None
+        a = stats_paths()
+        out['p2p_used'] = p2p is not None and p2p.calls > 0 and p2p.healthy()
+        os.environ['CNNQ_XRANK'] = '0'
+        ops.reload_switches()
+        out['p2p_off'] = D.p2p_exchange(None) is None
+        b = stats_paths()
+        os.environ['CNNQ_XRANK'] = '1'
+        ops.reload_switches()
+        out['stats_same'] = all(bool(torch.equal(u, v)) for u, v in zip(a, b))
         torch.cuda.synchronize()
         out['healthy'] = ex.healthy()
         out['group_status'] = ops.group_status(xs)
@@ -79,6 +112,18 @@ def test_two_ranks_on_one_gpu_equal_the_whole_batch(tmp_path):
             ref = O.act_per_channel_qdq(x, 4, half_range=half)
             y = torch.cat([p['y_%d_%d' % (i, half)] for p in parts])
             assert torch.equal(y, torch.as_tensor(ref)), (shape, half)
+            # codes / entropy / parameters of the global batch from the sharded single launch
+            ref2, rp = O.act_per_channel_qdq(x, 4, half_range=half, return_parts=True)
+            eref = float(O.shannon_entropy(rp['codes']))
+            outs = [p['o_%d_%d' % (i, half)] for p in parts]
+            assert torch.equal(torch.cat([o[0] for o in outs]), torch.as_tensor(ref2)), (shape, half)
+            assert torch.equal(torch.cat([o[1] for o in outs]).float(), rp['codes'].float()), (shape, half)
+            for o in outs:
+                assert abs(o[2] - eref) <= 2e-5 * max(1., eref) and abs(o[5] - eref) <= 2e-5 * max(1., eref), (shape, half, o[2], eref)
+                assert torch.equal(o[3][0], rp['scale'].flatten()) and torch.equal(o[3][1], rp['zero_point'].flatten()), (shape, half)
+                assert torch.equal(o[4][1], torch.as_tensor(rp['max']).flatten()) and o[6]
+    assert all(p['launches_out'] == 2 * len(SHAPES) * 2 for p in parts)    # they too went through the in-launch exchange
+    assert all(p['p2p_on'] and p['p2p_used'] and p['p2p_off'] and p['stats_same'] for p in parts), [(p['p2p_on'], p['p2p_used'], p['p2p_off'], p['stats_same']) for p in parts]
 
 
 def _single(rank, world, port, tmp):
@@ -117,3 +162,57 @@ def test_one_rank_forced_through_the_exchange(tmp_path):
     mp.spawn(_single, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     r = torch.load(os.path.join(str(tmp_path), 'single.pt'))
     assert r['ok'] and r['same']
+
+
+def _graph(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['CNNQ_XRANK'] = '1'
+    os.environ['CNNQ_FORCE_EXCHANGE'] = '1'
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    from cnn_quantization_amd import ops, distributed as D
+    ops.reload_switches()
+    side = torch.cuda.Stream()                           # the exchange binds to ONE stream: a capturable one from the start
+    with torch.cuda.stream(side):
+        ex = D.xrank_exchange(None)
+    ok, same, replays = ex is not None, True, 0
+    if ok:
+        shapes = [(40, 6, 56, 56), (70, 40, 7, 7), (37, 24, 14, 14), (8, 32, 14, 14), (7, 16, 5, 9)]
+        xs = [_batch(i, sh).cuda() for i, sh in enumerate(shapes)]
+        ys = [torch.empty_like(x) for x in xs]
+        refs = [ops.minmax_qdq_fused(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], 4, False, _xrank=False) for x in xs]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for x, y in zip(xs, ys):                     # eagerly once on this stream: workspaces and the sequence word exist
+                ops.act_qdq_per_channel(x, 4, out=y)
+            seq_before = int(ex.seq_dev.item())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for x, y in zip(xs, ys):
+                    ops.act_qdq_per_channel(x, 4, out=y)
+            for rep in range(3):                          # odd and even sequence numbers: both parities of the windows
+                for y in ys:
+                    y.zero_()
+                g.replay()
+                side.synchronize()
+                replays += 1
+                same = same and all(bool(torch.equal(y, r)) for y, r in zip(ys, refs))
+            same = same and int(ex.seq_dev.item()) == seq_before + 3 * len(xs)     # the device word advanced once per replayed launch
+            same = same and ex.healthy()
+        torch.cuda.current_stream().wait_stream(side)
+    torch.save({'ok': ok, 'same': same, 'replays': replays}, os.path.join(tmp, 'graph.pt'))
+    if ex is not None:
+        ex.close()
+    dist.destroy_process_group()
+
+
+def test_exchange_launches_replay_from_a_graph(tmp_path):
+    """Round 4: the sequence number of the in-launch exchange lives in device memory (a one-thread kernel advances it behind
+    every launch), so the launches can be captured and replayed: three replays of five tensors through the window of one
+    forced rank, the collective path's bits every time."""
+    port = 34100 + os.getpid() % 1500
+    mp.spawn(_graph, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(str(tmp_path), 'graph.pt'))
+    assert r['ok'] and r['same'] and r['replays'] == 3
