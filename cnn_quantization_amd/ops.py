@@ -214,11 +214,9 @@ def _params_cfg(num_bits, positive, clip, bit_alloc, prior_is_b, target, round_m
     elif 'std' in clip:
         cfg.clip, cfg.pstd = 3, float(clip.replace('std', ''))
     elif clip == 'mix':
-        # iq.py:310-323: picks laplace / gaus / min-max per channel from the mse_laplace / mse_gaus / mse_lowp
-        # columns of a statistics file written with collect_err=True - a diagnostic mode outside SURVEY 8(a7)
-        # that the statistics managers here do not collect
-        raise L.CnnqError("clipping 'mix' needs the mse_* error statistics (collect_err), which are out of scope: "
-                          "use 'laplace', 'gaus' or '<p>std'")
+        # iq.py:310-323 picks per channel between three clipping values from error columns of a statistics file: that is
+        # act_qdq_mix (three parameter tables merged per channel), not one configuration of this kernel
+        raise L.CnnqError("clipping 'mix' goes through ops.act_qdq_mix (it needs the mse_* columns of a statistics file)")
     else:
         raise L.CnnqError('unsupported clipping %r' % (clip,))
     cfg.bit_alloc = int(bool(bit_alloc))
@@ -240,6 +238,49 @@ def pc_params(stats, num_bits, positive=False, clip='no', bit_alloc=False, prior
     L.check(lib.cnnq_pc_params(_ptr(stats), C, ctypes.byref(cfg), _ptr(qp), _ptr(diag), _stream(stats)),
             'cnnq_pc_params')
     return qp, diag
+
+
+def act_qdq_mix(x, num_bits, stats, mse, positive=False, bit_alloc=False, prior_is_b=False, target=None, round_mode=True,
+                whole_tensor=False, want_codes=False, want_entropy=False, out=None):
+    """clip_type == 'mix' of the `-sm use` route (iq.py:310-323 + 327-359): per channel the Gaussian clipping value where
+    mse_gaus < mse_laplace, else the Laplace one, and the min/max half range (max - min) / 2 where mse_lowp < mse_gaus;
+    comparisons with NaN are False, so a file whose error columns are NaN - all the reference's own collection writes -
+    gives plain Laplace clipping.  stats [NSTAT, C]: the file's mean_{min, max, mean, b, std} rows; mse [3, C]: rows
+    laplace, gaus, lowp.  Everything downstream of the clipping value is per channel and elementwise, so the three
+    candidates' parameter tables are merged per channel: two cnnq_pc_params launches, the min/max candidate in a few
+    [C]-sized fp32 torch ops that repeat that kernel's arithmetic (iq.py:284-300, 351, 443, 559-572), one fused Q/DQ."""
+    x = _dev_f32(x, 'x')
+    N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x)
+    stats = stats.to(device=x.device, dtype=torch.float32)
+    mse = torch.as_tensor(mse, dtype=torch.float32, device=x.device).view(3, C)
+    kw = dict(positive=positive, bit_alloc=bit_alloc, prior_is_b=prior_is_b, target=target, round_mode=round_mode,
+              direct_range=whole_tensor)
+    qp_l, dg_l = pc_params(stats, num_bits, clip='laplace', **kw)
+    qp_g, _ = pc_params(stats, num_bits, clip='gaus', **kw)
+    mn, mx, mean = stats[L.STAT_MIN], stats[L.STAT_MAX], stats[L.STAT_MEAN]
+    alpha = (mx - mn) / 2
+    if positive:
+        rng, off = torch.clamp_min(mean, 0.) + alpha, torch.zeros_like(alpha)
+    else:
+        rng, off = 2 * alpha, torch.maximum(mn, mean - alpha)
+    delta = rng if whole_tensor else (off + rng) - off
+    if bit_alloc and num_bits <= 4:
+        qmax = torch.exp2(dg_l[L.DIAG_BITS]) - 1.
+        scale = torch.where(qmax > 0, delta / qmax, torch.zeros_like(delta))
+    else:
+        qmax = torch.full_like(delta, float(2 ** int(num_bits) - 1))
+        scale = delta / qmax
+    scale = torch.where(scale < 1e-8, torch.full_like(scale, 1e-8), scale)
+    zp = torch.round(0. - off / scale)
+    qp_p = torch.stack([scale, zp, qmax])
+    pick_g = (mse[1] < mse[0]).view(1, C)
+    pick_p = (mse[2] < mse[1]).view(1, C)
+    qp = torch.where(pick_p, qp_p, torch.where(pick_g, qp_g, qp_l)).contiguous()
+    hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
+    res = pc_qdq(x, N, C, HW, qp, want_codes=want_codes, out=out, hist=hist)
+    if want_entropy:
+        res = (res + (entropy_from_hist(hist),)) if want_codes else (res, entropy_from_hist(hist))
+    return res
 
 
 # ------------------------------------------------------------------------------------- Q/DQ
@@ -291,18 +332,21 @@ def _group_workspace(x, st=None):
 GROUP_WAIT_EXPIRED, GROUP_TEST_HOOK = 1, 2
 
 
-def group_status(x, clear=False):
+def group_status(x, clear=None):
     """Status word of this stream's group workspace (synchronises).  Bit 0 (GROUP_WAIT_EXPIRED): a bounded wait of the
     in-launch exchange ran out and its workgroup recomputed the extrema from x - results are unaffected, but the
     launch was slow (a group's members were not co-resident: another kernel held the CUs).  Bit 1 (GROUP_TEST_HOOK):
-    the recompute path was forced by the test flag.  The word is sticky; clear=True zeroes it after the read."""
+    the recompute path was forced by the test flag.  The word is sticky on the device, and while bit 0 is up every later
+    wait is bounded by 0.5 ms instead of 20 ms (csrc/cnnq_group.hip.h): reading it ACKNOWLEDGES it - a non-zero word is
+    zeroed after the read unless clear=False - so one transient expiry (a profiler attaching, a co-tenant's kernel) does
+    not leave the short bound in force for the rest of the process.  clear=True zeroes unconditionally."""
     ws = _GROUP_WS.get((x.device.index, _raw_stream(x.device.index)))
     if ws is None:
         return 0
     v = ctypes.c_uint32()
     lib = L.load()
     L.check(lib.cnnq_group_ws_status(ws, ctypes.byref(v)), 'cnnq_group_ws_status')
-    if clear:
+    if clear or (clear is None and v.value != 0):
         L.check(lib.cnnq_group_ws_status_clear(ws), 'cnnq_group_ws_status_clear')
     return int(v.value)
 

@@ -167,6 +167,8 @@ class IntQuantizer:
         """iq.py:327-359: ACIQ clipping (laplace / gaus / <p>std), per channel when -pcq_a applies,
         otherwise per tensor with scalar statistics."""
         prior_b = self.bit_alloc_prior != 'gaus'
+        if clip_type == 'mix':
+            return self._clipping_mix(tensor, id, stat_id, prior_b)
         if self.pcq_a and _is_pc_act(tensor):
             table = None
             if stat_id is not None:
@@ -192,6 +194,34 @@ class IntQuantizer:
             table = self._stats_table(stat_id, 1, tensor.device, rows)
         out = ops.act_qdq_per_channel(tensor, self.num_bits, positive=self._positive, clip=clip_type,
                                       bit_alloc=False, group=self.group, stats=table, whole_tensor=True)
+        return out.view(tensor.shape)
+
+    def _clipping_mix(self, tensor, id, stat_id, prior_b):
+        """iq.py:310-323: `-c mix` picks the clipping value per channel from the mse_laplace / mse_gaus / mse_lowp columns of
+        the statistics file (`-sm use` only: the reference looks them up by stat_id unconditionally).  A column the file
+        does not have counts as NaN - every comparison False, i.e. Laplace clipping, which is also what the files the
+        reference itself writes (NaN error columns) amount to."""
+        if stat_id is None:
+            raise ValueError("clipping 'mix' needs a statistics file (-sm use): int_quantizer.py:311-313 reads mse_* by stat_id")
+        pc = self.pcq_a and _is_pc_act(tensor)
+        C = tensor.shape[1] if pc else 1
+        rows = {L.STAT_MIN: ('min', 'mean'), L.STAT_MAX: ('max', 'mean'), L.STAT_MEAN: ('mean', 'mean'),
+                L.STAT_B: ('b', 'mean'), L.STAT_STD: ('std', 'mean')}
+        table = self._stats_table(stat_id, C, tensor.device, rows)
+        mse = torch.full((3, C), float('nan'), dtype=torch.float32)
+        for r, name in enumerate(('mse_laplace', 'mse_gaus', 'mse_lowp')):
+            try:
+                v = self.sm().get_tensor_stat(stat_id, name, 'mean')
+            except KeyError:
+                v = None
+            if v is not None:
+                mse[r] = _to_f32_vec(v, C)
+        out = ops.act_qdq_mix(tensor, self.num_bits, table, mse, positive=self._positive,
+                              bit_alloc=self.bit_alloc_act and pc, prior_is_b=prior_b, target=self.bit_alloc_target_act,
+                              round_mode=self.bit_alloc_round, whole_tensor=not pc, want_entropy=self.measure_entropy and pc)
+        if self.measure_entropy and pc:
+            out, entropy = out
+            self._log_entropy(id, entropy, 'avg.entropy.act', out.numel())
         return out.view(tensor.shape)
 
     # ------------------------------------------------------------------ weights

@@ -272,6 +272,39 @@ def act_clipping_qdq(x, num_bits, clip_type='laplace', half_range=False, force_p
 
 
 # ----------------------------------------------------------------------------- weights (a10, a11)
+def act_clipping_mix_qdq(x, num_bits, stats, mse, half_range=False, force_positive=False, bit_alloc_act=False,
+                         bit_alloc_prior='gaus', bit_alloc_target=None, bit_alloc_round=True, return_parts=False):
+    """clip_type == 'mix' of iq.py:310-323 on the per-channel `-sm use` route (iq.py:327-352): `stats` holds the file's
+    per-channel `mean_*` columns {min, max, mean, b, std}, `mse` the columns {laplace, gaus, lowp}.  Per channel the
+    clipping value is the Gaussian one where mse_gaus < mse_laplace, else the Laplace one, and the min/max half range
+    where mse_lowp < mse_gaus (comparisons with NaN are False: a file whose error columns are NaN - all the reference's
+    own collection ever writes - gives plain Laplace clipping)."""
+    positive = force_positive or half_range
+    f32 = lambda v: np.asarray(v, dtype=np.float32)
+    mn, mx, mean, b, std = (f32(stats[k]) for k in ('min', 'max', 'mean', 'b', 'std'))
+    bits = None
+    if bit_alloc_act and num_bits <= 4:
+        prior = std if bit_alloc_prior == 'gaus' else b
+        target = bit_alloc_target if bit_alloc_target is not None else num_bits
+        bits = bits_alloc_fixed_target(torch.from_numpy(prior), target, bit_alloc_round)
+    a_lap = alpha_laplace(torch.from_numpy(b), num_bits, positive, bits)
+    a_lap = a_lap.numpy() if isinstance(a_lap, torch.Tensor) else f32(a_lap)
+    a_gaus = std * np.float32(aciq_factor(num_bits, 'gaus', positive))
+    a_lowp = (mx - mn) / 2
+    with np.errstate(invalid='ignore'):
+        alpha = np.where(f32(mse['gaus']) < f32(mse['laplace']), a_gaus, a_lap)
+        alpha = np.where(f32(mse['lowp']) < f32(mse['gaus']), a_lowp, alpha)
+    rng, off = alpha_to_delta_offset(alpha, mx, mn, mean, positive)
+    off = _as_f32(off)
+    rng = _as_f32(rng)
+    out = act_per_channel_qdq(x.contiguous(), num_bits, half_range, force_positive, bit_alloc_act, bit_alloc_prior,
+                              bit_alloc_target, bit_alloc_round, min_=off, max_=off + rng,
+                              prior_stat=torch.from_numpy(std if bit_alloc_prior == 'gaus' else b), return_parts=return_parts)
+    if return_parts:
+        out[1].update(alpha=alpha, range=rng, offset=off)
+    return out
+
+
 def weights_per_channel_qdq(w, num_bits, bit_alloc_weight=False, bit_alloc_target=None,
                             bit_alloc_round=True, return_parts=False):
     """Row a10, iq.py:453-476: rows are the output channels of [OFM, IFM*K*K]."""

@@ -170,3 +170,30 @@ def test_nan_golden(golden):
         na, nb = np.isnan(y), np.isnan(ref)
         assert np.array_equal(na, nb) and np.array_equal(y[~na].view(np.uint32), ref[~nb].view(np.uint32)), i
         assert nb[:, 2].all() and not nb[:, 3:].any()
+
+
+def _mix_inputs(g):
+    cols = [str(c) for c in g.np('summary_columns')]
+    vals = g.np('summary_values')
+    stats = {k: vals[:, cols.index('mean_%s' % k)] for k in ('min', 'max', 'mean', 'b', 'std')}
+    mse = {k: g.np('mse_%s' % k) for k in ('laplace', 'gaus', 'lowp')}
+    return stats, mse
+
+
+def test_clipping_mix(golden):
+    """clip_type == 'mix' (iq.py:310-323) on the `-sm use` route: the restatement against the reference run on a
+    statistics file whose mse_* columns select every branch (tests/golden/make_golden_mix.py)."""
+    g = golden('mix')
+    stats, mse = _mix_inputs(g)
+    picks = set()
+    for nm in g.np('names'):
+        nm = str(nm)
+        half, baa = nm[8] == '1', nm[-1] == '1'
+        y, parts = O.act_clipping_mix_qdq(g.t('x0'), 4, stats, mse, half_range=half, bit_alloc_act=baa, return_parts=True)
+        assert bits_equal(y, g.np(nm + '_y')), nm
+        assert np.array_equal(parts['codes'].numpy().astype(np.int32), g.np(nm + '_codes')), nm
+    with np.errstate(invalid='ignore'):
+        gaus = mse['gaus'] < mse['laplace']
+        lowp = mse['lowp'] < mse['gaus']
+    picks = {('lowp' if lo else 'gaus' if ga else 'laplace') for ga, lo in zip(gaus, lowp)}
+    assert picks == {'laplace', 'gaus', 'lowp'}                  # the fixture exercises all three

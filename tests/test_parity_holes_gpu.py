@@ -203,6 +203,60 @@ def test_stat_id_route_bit_exact(ops, golden, tmp_path, monkeypatch, cfg, half):
     Singleton._instances.pop(StatisticManagerPerChannel, None)
 
 
+@pytest.mark.parametrize('half', [0, 1])
+@pytest.mark.parametrize('baa', [0, 1])
+def test_clipping_mix_bit_exact(ops, golden, tmp_path, monkeypatch, half, baa):
+    """`-c mix` on the `-sm use` route (int_quantizer.py:310-323): the statistics file the reference wrote plus the three
+    error columns that select Laplace / Gaussian / min-max clipping per channel (NaN included); floats and codes of the
+    reference run bit for bit (tests/golden/mix.npz), through the quantizer and through the op."""
+    import pandas as pd
+    from cnn_quantization_amd import _lib as L
+    from cnn_quantization_amd.inference.statistic_manager_perchannel import StatisticManagerPerChannel
+    from cnn_quantization_amd.qtypes import int_quantizer
+    from cnn_quantization_amd.utils.misc import Singleton
+    monkeypatch.setenv('HOME', str(tmp_path))
+    g = golden('mix')
+    df = pd.DataFrame(g.np('summary_values'), columns=[str(c) for c in g.np('summary_columns')]).astype(np.float32)
+    folder = os.path.join(str(tmp_path), 'mxt-sim', 'statistics', 'per_channel', 'golden_mix')
+    os.makedirs(folder)
+    with open(os.path.join(folder, 'golden_mix_statistics_perchannel_summary.pkl'), 'wb') as f:
+        pickle.dump({'conv0_activation': df}, f)
+    Singleton._instances.pop(StatisticManagerPerChannel, None)
+    sm = StatisticManagerPerChannel('golden_mix', load_stats=True)
+    params = dict(clipping='mix', stats_kind='mean', true_zero=False, kld=False, pcq_weights=False, pcq_act=True,
+                  bit_alloc_act=bool(baa), bit_alloc_weight=False, bit_alloc_rmode='round', bit_alloc_prior='gaus',
+                  bit_alloc_target_act=None, bit_alloc_target_weight=None, bcorr_act=False, bcorr_weight=False,
+                  vcorr_weight=False, logger=None, measure_entropy=False, mtd_quant=False)
+    q = int_quantizer('int4', params)
+    q.sm = lambda: sm
+    q.half_range = bool(half)
+    x = g.t('x0').cuda()
+    nm = 'mix_half%d_baa%d' % (half, baa)
+    # without the error columns (what the reference's own collection leaves behind: NaN) 'mix' is Laplace clipping
+    q2 = int_quantizer('int4', dict(params, clipping='laplace'))
+    q2.sm = lambda: sm
+    q2.half_range = bool(half)
+    assert torch.equal(q(x, 'conv0_activation', 'activation', stat_id='conv0_activation'),
+                       q2(x, 'conv0_activation', 'activation', stat_id='conv0_activation'))
+    st = sm.stats['conv0_activation']
+    for k in ('laplace', 'gaus', 'lowp'):
+        st['mean_mse_%s' % k] = g.np('mse_%s' % k)
+    y = q(x, 'conv0_activation', 'activation', stat_id='conv0_activation')
+    assert bits_equal(y.cpu(), g.np(nm + '_y')), nm
+    C = x.shape[1]
+    rows = {L.STAT_MIN: ('min', 'mean'), L.STAT_MAX: ('max', 'mean'), L.STAT_MEAN: ('mean', 'mean'),
+            L.STAT_B: ('b', 'mean'), L.STAT_STD: ('std', 'mean')}
+    table = q._stats_table('conv0_activation', C, x.device, rows)
+    mse = torch.from_numpy(np.stack([g.np('mse_%s' % k) for k in ('laplace', 'gaus', 'lowp')]))
+    y2, codes, ent = ops.act_qdq_mix(x, 4, table, mse, positive=bool(half), bit_alloc=bool(baa), want_codes=True, want_entropy=True)
+    assert torch.equal(y2, y)
+    assert np.array_equal(codes.cpu().numpy().astype(np.int32), g.np(nm + '_codes')), nm
+    assert np.isfinite(float(ent))
+    with pytest.raises(Exception):
+        q(x, 'conv0_activation', 'activation')                    # no statistics file route: the reference fails there too
+    Singleton._instances.pop(StatisticManagerPerChannel, None)
+
+
 def test_stored_codes_equal_golden_codes(ops, golden):
     """f3: the packed int4 nibbles and the one-byte codes are the reference's integer codes (act_pc.npz `_codes`),
     and dequantizing them gives the reference's floats."""
