@@ -315,7 +315,8 @@ struct GWs {
 #ifndef FLAT_ABL
 #define FLAT_ABL 0        // development builds only (tools/runs/r4_ablate.sh; timing, WRONG results): bit 0 - the stores of y compiled out,
                           // bit 1 - the meeting compiled out (every workgroup uses its own tile's extrema),
-                          // bit 2 - the loads of k_mmq_flat compiled out (synthetic values)
+                          // bit 2 - the loads of k_mmq_flat compiled out (synthetic values), bit 3 - the Q/DQ arithmetic of
+                          // k_mmq_flat compiled out (y = x): with bit 1 the kernel is the bare copy of its own address stream
 #endif
 #if FLAT_ABL & 1
 #define FLAT_ABL_NOSTORE(o) && (o)[0] == 3.0e38f      // never true; the arithmetic stays
@@ -759,7 +760,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         for (int j = 0; j < K; ++j) {
             float o[4], cd[4];
 #pragma unroll
+#if FLAT_ABL & 8
+            for (int e = 0; e < 4; ++e) { o[e] = v[j][e]; cd[e] = 0.f; }
+#else
             for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], s_sc, s_rs, s_zp, qm, cd[e]);
+#endif
             if constexpr (OUT == 2) {
                 if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
                 else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);

@@ -57,7 +57,7 @@ def main():
     torch.cuda.empty_cache()
     print('\nThe kernels on the same box (`tools/bench_group.py`, rotating buffers, us per launch and TB/s of the 8 B/elem):\n')
     libs = [('product library', os.path.join(root, 'cnn_quantization_amd', 'libcnnq_hip.so'))]
-    for a, nm in ((2, 'meeting compiled out'), (1, 'stores of y compiled out'), (3, 'stores and meeting compiled out (read only)'),
+    for a, nm in ((10, 'meeting and Q/DQ arithmetic compiled out: the bare copy of the kernel\'s own address stream'), (2, 'meeting compiled out'), (1, 'stores of y compiled out'), (3, 'stores and meeting compiled out (read only)'),
                   (4, 'loads compiled out (write only)'), (6, 'loads and meeting compiled out')):
         p = os.path.join(here, 'alt', 'libcnnq_abl%d.so' % a)
         if os.path.exists(p):
