@@ -13,7 +13,7 @@ dev = torch.device('cuda')
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ws = ctypes.c_void_p()
 _lib.check(lib.cnnq_group_ws_alloc(32 << 20, ctypes.byref(ws)), 'alloc')
-N, C, hw = 512, 256, 56
+N, C, hw = int(os.environ.get('NB', '512')), 256, 56
 HW = hw * hw
 n = N * C * HW
 nb = n * 4
@@ -30,9 +30,10 @@ def measure(xp, yp):
     for r in range(6): run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 6 * 1e3
-for kind in ('torch.empty (x and y separate tensors)', 'hipMalloc', 'hipExtMallocWithFlags(Contiguous)'):
+print('batch %d: %d MB per tensor, %d pages of 2 MB for x and y together' % (N, nb >> 20, 2 * nb >> 21))
+for kind in ('torch.empty (x and y separate tensors)', 'hipMalloc'):
     line = '%-42s' % kind
-    for i in range(6):
+    for i in range(8):
         if kind.startswith('torch'):
             x = torch.empty(n, dtype=torch.float32, device=dev); y = torch.empty(n, dtype=torch.float32, device=dev)
             keep.append((x, y)); xp, yp = x.data_ptr(), y.data_ptr()
@@ -42,5 +43,6 @@ for kind in ('torch.empty (x and y separate tensors)', 'hipMalloc', 'hipExtMallo
             if al.urw_alloc(nb, flags, ctypes.byref(px)) or al.urw_alloc(nb, flags, ctypes.byref(py)):
                 line += '  alloc failed'; break
             xp, yp = px.value, py.value
-        line += '  %.0f us (x 0x%x)' % (measure(xp, yp), xp)
+        t = measure(xp, yp)
+        line += '  %.0f us (%.2f TB/s)' % (t, n * 8 / t / 1e6)
     print(line, flush=True)
