@@ -106,10 +106,12 @@ def _out_like(x, out):
     if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
             and out.shape == x.shape and out.device == x.device):
         raise L.CnnqError('out must be a contiguous float32 tensor on %s shaped like the input' % (x.device,))
-    if out.untyped_storage().data_ptr() == x.untyped_storage().data_ptr():
+    nbytes = x.numel() * 4
+    if out.data_ptr() < x.data_ptr() + nbytes and x.data_ptr() < out.data_ptr() + nbytes:
         # the kernels declare x and y __restrict__, and a single-launch workgroup whose bounded wait expires recomputes
-        # its channels' extrema by re-reading x after other members may have stored y (include/cnnq_hip.h: x != y)
-        raise L.CnnqError('out must not share storage with the input (in-place quantization is not supported)')
+        # its channels' extrema by re-reading x after other members may have stored y (include/cnnq_hip.h: x != y).
+        # Byte ranges, not storages: two views of one arena that do not overlap are fine.
+        raise L.CnnqError('out must not overlap the input (in-place quantization is not supported)')
     return out
 
 

@@ -268,6 +268,8 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
  * every workgroup keeps its tile of x in registers; the workgroups that hold pieces of the same channels exchange
  * their {min, max} pairs through `ws` (write-through stores, one arrival counter per channel group, a bounded wait
  * that falls back to recomputing the extrema from x - never a deadlock, never different bits).
+ *   x, y must not overlap (both are read / written through __restrict__ pointers, and a workgroup whose bounded wait
+ *        expires re-reads x after other workgroups may have stored y); the same holds for every single-launch entry point.
  *   ws   from cnnq_group_ws_alloc(bytes >= cnnq_pc_group_workspace(N, C, HW)): fine-grained (uncached) device
  *        memory, zeroed once (the kernel re-arms it), so that what a workgroup reads never depends on the state of
  *        a per-XCD L2; one workspace must not be used by two launches that can run concurrently.

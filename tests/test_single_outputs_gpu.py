@@ -153,3 +153,17 @@ def test_single_outputs_full_size(ops, shape, half):
             nib = torch.stack([pk & 15, pk >> 4], dim=1).flatten().view(-1, C, H, W).float()
             assert torch.equal((nib - zp) * sc, y[n0:n0 + 64])
     assert ops.group_status(x) == 0
+
+
+def test_out_must_not_overlap_the_input(ops):
+    """`out` overlapping x is refused (the kernels' pointers are __restrict__, the cold path of the exchange re-reads
+    x); two views of one arena that do not overlap are accepted."""
+    arena = torch.randn(2 * 8 * 16 * 14 * 14 + 64, device='cuda')
+    n = 8 * 16 * 14 * 14
+    x = arena[:n].view(8, 16, 14, 14)
+    with pytest.raises(Exception):
+        ops.act_qdq_per_channel(x, 4, out=x)
+    with pytest.raises(Exception):
+        ops.act_qdq_per_channel(x, 4, out=arena[16:16 + n].view(8, 16, 14, 14))
+    y = ops.act_qdq_per_channel(x, 4, out=arena[n:2 * n].view(8, 16, 14, 14))
+    assert torch.equal(y, ops.act_qdq_per_channel(x.clone(), 4))
