@@ -595,7 +595,10 @@ __device__ __forceinline__ void flat_pk_flush(const FGeo& g, const uint16_t* sh_
     }
 }
 
-template <int K, int OUT = 0, bool XR = false>
+// KL (round 4, opt-in: CNNQ_FLAT_KL=8): KL more steps of the tile live in LDS - filled by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers), lane-linear, read back by the lane that owns them - so a workgroup holds 256 * (K + KL) float4 at
+// the same register budget: 160 instead of 128 KB (three workgroups keep 96 of the CU's 160 KB of LDS busy).
+template <int K, int OUT = 0, bool XR = false, int KL = 0>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat(
     const float* __restrict__ x, float* __restrict__ y, const FGeo g, const int num_bits, const int positive, const GWs ws,
     float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}, const XRank xr = XRank{}) {
@@ -609,7 +612,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     // OUT = 2: the tile's packed nibbles go through a strip of LDS per wave - written as one 16-bit word per float4
     // ([step][lane], what a lane produces), read back as 16 (or 8) CONSECUTIVE bytes of the stream per lane and stored
     // with one dwordx4 (dwordx2) per lane: 4 (8) store instructions per lane instead of 32 two-byte ones
-    __shared__ __attribute__((aligned(16))) uint16_t sh_pk[OUT == 2 ? TPB * K : 1];
+    __shared__ __attribute__((aligned(16))) uint16_t sh_pk[OUT == 2 ? TPB * (K + KL) : 1];
+    __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
     const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     GRP_STAMP(0);
     const int tid = threadIdx.x;
@@ -625,7 +629,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         member = r / cbl;
         c = c0 + (r - member * cbl);
     }
-    const unsigned f0 = (unsigned)member * (256u * K);          // < total
+    const unsigned f0 = (unsigned)member * (256u * (K + KL));   // < total
     const unsigned n_first = f0 / g.cpc;
     const unsigned u = f0 + (unsigned)tid;
     const unsigned n = u / g.cpc;
@@ -647,6 +651,17 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     //      base's row start (an element of the same channel: harmless for the extrema, never stored)
     float v[K][4];
     FWalk w = w0;
+    if constexpr (KL > 0) {
+        // the tile's FIRST KL steps go straight into LDS (issued first: the compiler waits for every outstanding ordinary load
+        // before it issues an LDS-DMA, not the other way round): each wave's 64 x 16 bytes land lane-linear at its own 1 KB slot
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
+                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
+            w.step(g);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
@@ -666,6 +681,16 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     bool nan = false;
 #pragma unroll
     for (int j = 0; j < K; ++j) lane_acc<1>(v[j], mn, mx, nan);
+    if constexpr (KL > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            float t[4];
+            const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+            t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+            lane_acc<1>(t, mn, mx, nan);
+        }
+    }
     if (nan) { mn[0] = NAN; mx[0] = NAN; }
     float cmn, cmx;
     wg_minmax1(mn[0], mx[0], l_mn, l_mx, cmn, cmx);
@@ -756,6 +781,23 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         // the channel's values are inside qdq_fast_domain: the exact quotient without the divide, parameters in
         // scalar registers (one channel per workgroup)
         const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp);
+        if constexpr (KL > 0) {
+#pragma unroll
+            for (int l = 0; l < KL; ++l) {
+                const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                const float t[4] = {q.x, q.y, q.z, q.w};
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(t[e], s_sc, s_rs, s_zp, qm, cd[e]);
+                if constexpr (OUT == 2) {
+                    if (pkl > 1) sh_pk[l * 256 + tid] = pack4_of(cd);
+                    else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                } else {
+                    if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                }
+                w.step(g);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             float o[4], cd[4];
@@ -766,7 +808,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], s_sc, s_rs, s_zp, qm, cd[e]);
 #endif
             if constexpr (OUT == 2) {
-                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
+                if (pkl > 1) sh_pk[(KL + j) * 256 + tid] = pack4_of(cd);
                 else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
             } else {
                 if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
@@ -774,13 +816,30 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             w.step(g);
         }
     } else {
+        if constexpr (KL > 0) {
+#pragma unroll
+            for (int l = 0; l < KL; ++l) {
+                const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                const float t[4] = {q.x, q.y, q.z, q.w};
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = qdq1(t[e], sc, zp, qm, cd[e]);
+                if constexpr (OUT == 2) {
+                    if (pkl > 1) sh_pk[l * 256 + tid] = pack4_of(cd);
+                    else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                } else {
+                    if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                }
+                w.step(g);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             float o[4], cd[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
             if constexpr (OUT == 2) {
-                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
+                if (pkl > 1) sh_pk[(KL + j) * 256 + tid] = pack4_of(cd);
                 else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
             } else {
                 if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
@@ -795,11 +854,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         if (pkl > 1) {
             __syncthreads();
             if (flags & MMQ_FLAG_PK_PLAIN) {
-                if (pkl == 8) flat_pk_flush<K, 8, false>(g, sh_pk, pbb, f0, n_first, lim);
-                else flat_pk_flush<K, 4, false>(g, sh_pk, pbb, f0, n_first, lim);
+                if (pkl == 8) flat_pk_flush<K + KL, 8, false>(g, sh_pk, pbb, f0, n_first, lim);
+                else flat_pk_flush<K + KL, 4, false>(g, sh_pk, pbb, f0, n_first, lim);
             } else {
-                if (pkl == 8) flat_pk_flush<K, 8, true>(g, sh_pk, pbb, f0, n_first, lim);
-                else flat_pk_flush<K, 4, true>(g, sh_pk, pbb, f0, n_first, lim);
+                if (pkl == 8) flat_pk_flush<K + KL, 8, true>(g, sh_pk, pbb, f0, n_first, lim);
+                else flat_pk_flush<K + KL, 4, true>(g, sh_pk, pbb, f0, n_first, lim);
             }
         }
     }

@@ -539,7 +539,7 @@ int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
     GPlan p;
     const int rc = plan_group(N, C, HW, true, &p);
     if (rc) return rc;
-    const int32_t vals[8] = {p.v.A, p.K, p.g.mode, p.g.S, p.g.ncb, p.Gs, p.ngroups, p.g.S * p.g.ncb};
+    const int32_t vals[8] = {p.v.A, p.K + p.KL, p.g.mode, p.g.S, p.g.ncb, p.Gs, p.ngroups, p.g.S * p.g.ncb};
     for (int i = 0; i < 8; ++i) out[i] = vals[i];
     return 0;
 }
@@ -648,7 +648,7 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
     xo.packed = packed;
     const bool al = al16(x) && (packed ? true : al16(y));
     GPlan gp;
-    const bool group_ok = gws && plan_group(N, C, HW, al, &gp) == 0 && gp.ws_bytes <= gws_bytes;
+    const bool group_ok = gws && plan_group(N, C, HW, al, &gp, true, /*lds_rows=*/packed != nullptr) == 0 && gp.ws_bytes <= gws_bytes;
     WPlan wp;
     const bool whole_ok = plan_whole(N, C, HW, al, &wp) == 0;
     hipStream_t st = (hipStream_t)stream;

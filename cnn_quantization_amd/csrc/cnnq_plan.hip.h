@@ -252,7 +252,8 @@ struct GPlan {
     int ngroups;   // groups = arrival counters
     int gstride;   // 8-byte pairs per group block (a multiple of 16 = 128 bytes)
     size_t ws_bytes;
-    int flat;      // 1: k_mmq_flat (a group = one channel, members = flat tiles of 256*K float4), geometry in fg
+    int flat;      // 1: k_mmq_flat (a group = one channel, members = flat tiles of 256*(K+KL) float4), geometry in fg
+    int KL;        // steps of a flat tile that live in LDS (0, or 8 with K = 32: asked for by the packed output, or CNNQ_FLAT_KL)
     FGeo fg;
 };
 
@@ -266,7 +267,7 @@ constexpr int GRP_MAX_LINES = 16384;   // counter lines (4 MB)
 constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_LINES * GRP_CNT_STRIDE * 4;
 
 // flat tiles (k_mmq_flat) when a channel row is long enough that the row-piece tiling of k_mmq_group would idle lanes
-int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p) {
+int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     static const int allow = env_int("CNNQ_GRP_FLAT", 1);       // development knob
     static const int forceK = env_int("CNNQ_GRP_K", 0);
     static const int target = env_int("CNNQ_GRP_WGS", 1024);
@@ -283,13 +284,18 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p) {
             if (C * ((total + TPB * K - 1) / (TPB * K)) >= target) break;
     }
     while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
-    const int64_t Gs = (total + TPB * K - 1) / (TPB * K);
+    // round 4: eight more steps per tile in LDS (160 KB per workgroup).  Measured +1.5 % on the packed single launch (whose
+    // tile is held longest) and -1 % on the b512 step, so only the packed output asks for it; CNNQ_FLAT_KL = 8 / 0 forces it
+    static const int kl_knob = env_int("CNNQ_FLAT_KL", -1);
+    const int KL = (K == 32 && (kl_knob == 8 || (kl_knob < 0 && lds_rows))) ? 8 : 0;
+    const int64_t Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
     if (Gs > GRP_GS_MAX || Gs < 2) return CNNQ_ENOTSUP;
-    const int64_t rows = (TPB * K) / cpc + 3;                    // samples a tile can touch, with slack
+    const int64_t rows = (TPB * (K + KL)) / cpc + 3;             // samples a tile can touch, with slack
     if (rows * C * HW * 4 >= (int64_t)1 << 32) return CNNQ_ENOTSUP;
     const int64_t nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
     if (C * (nsub > 1 ? nsub + 1 : 1) > GRP_MAX_LINES) return CNNQ_ENOTSUP;
     p->flat = 1;
+    p->KL = KL;
     p->v = {4, 1, 1};
     p->K = K;
     p->Gs = (int)Gs;
@@ -313,22 +319,22 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p) {
     return 0;
 }
 
-int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat);
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, bool lds_rows);
 
 // plans are pure functions of their arguments (the development knobs are read once): the hot call asks for the same
 // handful of geometries over and over, so each host thread remembers the last 64
-int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true) {
+int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true, bool lds_rows = false) {
     struct Entry { int64_t N, C, HW; int key, rc; GPlan plan; };
     constexpr int SLOTS = 64;
     thread_local Entry cache[SLOTS];
     thread_local int used = 0, next = 0;
-    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0);
+    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0) | (lds_rows ? 4 : 0);
     for (int i = 0; i < used; ++i)
         if (cache[i].N == N && cache[i].C == C && cache[i].HW == HW && cache[i].key == key) {
             *p = cache[i].plan;
             return cache[i].rc;
         }
-    const int rc = plan_group_compute(N, C, HW, aligned16, p, allow_flat);
+    const int rc = plan_group_compute(N, C, HW, aligned16, p, allow_flat, lds_rows);
     Entry& e = cache[next];
     e.N = N; e.C = C; e.HW = HW; e.key = key; e.rc = rc; e.plan = *p;
     next = (next + 1) % SLOTS;
@@ -336,11 +342,11 @@ int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool 
     return rc;
 }
 
-int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat) {
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, bool lds_rows) {
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (!aligned16) return CNNQ_ENOTSUP;
     p->flat = 0;
-    if (allow_flat && plan_flat(N, C, HW, p) == 0) return 0;
+    if (allow_flat && plan_flat(N, C, HW, p, lds_rows) == 0) return 0;
     p->flat = 0;
     if (HW % 4 == 0) {
         p->v = {4, 1, 1};
@@ -414,7 +420,13 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)
-        if (p.K == 32) LAUNCH_F(32); else if (p.K == 16) LAUNCH_F(16); else LAUNCH_F(8);
+        if (p.K == 32 && p.KL == 8) {
+            if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_flat<32, 1, true, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr);
+            else if (xrank) hipLaunchKernelGGL((k_mmq_flat<32, 0, true, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr);
+            else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<32, 0, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
+            else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<32, 1, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
+            else hipLaunchKernelGGL((k_mmq_flat<32, 2, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
+        } else if (p.K == 32) LAUNCH_F(32); else if (p.K == 16) LAUNCH_F(16); else LAUNCH_F(8);
 #undef LAUNCH_F
         return launch_status();
     }
