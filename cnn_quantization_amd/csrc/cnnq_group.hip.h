@@ -302,6 +302,78 @@ __device__ __forceinline__ bool grp_arrive_last(unsigned* top, int member, int G
     return true;
 }
 
+// Departure that tells who was last (the slot meeting below): true in exactly one member per launch, after every other
+// member has departed; the departure words it went through are zero again.
+__device__ __forceinline__ bool grp_depart_last(unsigned* top, int member, int Gs) {
+    const int nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
+    const int si = member / GRP_SUB;
+    const unsigned m_i = (unsigned)min(GRP_SUB, Gs - si * GRP_SUB);
+    unsigned* line = (nsub > 1) ? top + (size_t)(1 + si) * GRP_CNT_STRIDE : top;
+    if (__hip_atomic_fetch_add(line + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != m_i) return false;
+    __hip_atomic_store(line + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nsub == 1) return true;
+    if (__hip_atomic_fetch_add(top + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nsub - 1u) return false;
+    __hip_atomic_store(top + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// ---- the slot meeting (round 4; MMQ_FLAG_SLOTS) ---------------------------------------------------------------------
+// The counter meeting above is a chain of four dependent memory round trips per member (pair stored and acknowledged ->
+// arrival counted -> counter polled -> pairs read), 1-2 us each under a streaming load.  Here a member's {min, max} pair
+// IS its arrival: slots are zero at rest, a member stores the complement of its pair (NaNs canonical, so the complement is
+// never zero) with ONE 8-byte store and nobody waits for the acknowledgement; every member then polls the group's slots
+// (lane m watches members m and m + 256) until none is zero - one round trip after the last store landed.  Departures are
+// counted (word [1] of the counter lines); whoever departs last zeroes the slots again: every launch leaves them zero.
+__device__ __forceinline__ unsigned long long slot_of(float mn, float mx) {
+    const bool nn = (mn != mn) || (mx != mx);
+    return ~pack_pair(nn ? NAN : mn, nn ? NAN : mx);
+}
+
+// Wave 0 of the member does the meeting (no barrier inside the wait: the other waves sit at the caller's barrier): lane l
+// watches members l, l + 64, ... (GRP_GS_MAX / 64 = 8 at most).  Returns 0, or 1 (a wait expired) / 2 (the test hook),
+// meaningful in thread 0; tn / tx: this lane's share of the fold (identities outside wave 0).
+__device__ __forceinline__ int slots_meet(unsigned long long* slots, int member, int Gs, float cmn, float cmx, unsigned flags,
+                                          long long timeout_ticks, float& tn, float& tx) {
+    static_assert(GRP_GS_MAX <= 8 * 64, "a lane of wave 0 watches at most 8 members");
+    const int tid = threadIdx.x;
+    tn = INFINITY;
+    tx = -INFINITY;
+    if (tid >= 64) return 0;
+    if (tid == 0) __hip_atomic_store(slots + member, slot_of(cmn, cmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (flags & MMQ_FLAG_TEST_HOOK) return 2;
+    unsigned pend = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pend |= (tid + 64 * i < Gs) ? (1u << i) : 0u;
+    const int rounds = (Gs + 63) >> 6;      // wave-uniform
+    long long t0 = 0;
+    for (int spins = 0;; ++spins) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < rounds) v[i] = ((pend >> i) & 1u) ? __hip_atomic_load(slots + tid + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < rounds && ((pend >> i) & 1u) && v[i]) {
+                float u, w;
+                unpack_pair(~v[i], u, w);
+                tn = pmin(tn, u);
+                tx = pmax(tx, w);
+                pend &= ~(1u << i);
+            }
+        if (__ballot(pend != 0u) == 0ull) return 0;
+        int expired = 0;
+        if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            expired = (now - t0 > timeout_ticks || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+        }
+        if (__builtin_amdgcn_readfirstlane(expired)) return 1;
+        if (spins < 2) __builtin_amdgcn_s_sleep(8);
+        else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 // ws: [0] status word, [256 ..) 16384 arrival/departure counters, one per group and per 256-byte line (a fixed
 // region, so that no geometry's pairs ever land on another geometry's counters), then one 128-byte-aligned block of 8-byte
 // {min, max} pairs per group: [member] (mode 1) or [member][k] (mode 2)
@@ -309,6 +381,7 @@ struct GWs {
     unsigned* status;
     unsigned* cnt;
     unsigned long long* part;
+    unsigned long long* slots;   // the slot meeting's region (zero at rest), blocks laid out like `part`
     int gstride;   // pairs per group block
 };
 
@@ -702,7 +775,19 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     if (tid == 0) sh_timed_out = 0;
     const float own_mn = cmn, own_mx = cmx;
 #else
-    if (tid == 0) {
+    const bool use_slots = (flags & MMQ_FLAG_SLOTS) != 0;
+    unsigned long long* slots = ws.slots + (size_t)c * ws.gstride;   // zero at rest
+    float sn = INFINITY, sx = -INFINITY;
+    if (use_slots) {
+        const long long tmo = (st0 & 1u) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS;      // lane 0's copy is the one consulted
+        GRP_STAMP(3);
+        const int timed_out = slots_meet(slots, member, g.Gs, cmn, cmx, flags, tmo, sn, sx);
+        if (tid == 0) {
+            if (timed_out) atomicOr(ws.status, (unsigned)timed_out);
+            sh_timed_out = timed_out;
+        }
+        GRP_STAMP(4);
+    } else if (tid == 0) {
         __hip_atomic_store(blk + member, pack_pair(cmn, cmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair has left the CU
         GRP_STAMP(3);
@@ -732,11 +817,16 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         tn = own_mn;
         tx = own_mx;
 #else
-        for (int m = tid; m < g.Gs; m += TPB) {
-            float a, b;
-            unpack_pair(__hip_atomic_load(blk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, b);
-            tn = pmin(tn, a);
-            tx = pmax(tx, b);
+        if (use_slots) {
+            tn = sn;
+            tx = sx;
+        } else {
+            for (int m = tid; m < g.Gs; m += TPB) {
+                float a, b;
+                unpack_pair(__hip_atomic_load(blk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a, b);
+                tn = pmin(tn, a);
+                tx = pmax(tx, b);
+            }
         }
 #endif
     }
@@ -864,7 +954,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     }
     GRP_STAMP(6);
 #if !(FLAT_ABL & 2)
-    if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);
+    if (use_slots) {
+        if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
+        __syncthreads();
+        if (sh_timed_out)      // the last member out re-arms the group's slots: every other member has read them
+            for (int m = tid; m < g.Gs; m += TPB) __hip_atomic_store(slots + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);
 #endif
 #ifdef GRP_TRACE
     if (g_grp_trace) {

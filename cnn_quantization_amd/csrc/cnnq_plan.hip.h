@@ -253,7 +253,7 @@ struct GPlan {
     int gstride;   // 8-byte pairs per group block (a multiple of 16 = 128 bytes)
     size_t ws_bytes;
     int flat;      // 1: k_mmq_flat (a group = one channel, members = flat tiles of 256*(K+KL) float4), geometry in fg
-    int KL;        // steps of a flat tile that live in LDS (0, or 8 with K = 32: asked for by the packed output, or CNNQ_FLAT_KL)
+    int KL;        // steps of a flat tile that live in LDS (0, or 8 with K = 32: development knob CNNQ_FLAT_KL)
     FGeo fg;
 };
 
@@ -264,7 +264,9 @@ struct GPlan {
 // counter lines and one {max key, inverted min key} record per row), zero whenever no launch is in flight
 constexpr size_t GRP_WS_HDR = 65536;
 constexpr int GRP_MAX_LINES = 16384;   // counter lines (4 MB)
-constexpr size_t GRP_WS_PAIRS = GRP_WS_HDR + (size_t)GRP_MAX_LINES * GRP_CNT_STRIDE * 4;
+constexpr size_t GRP_WS_SLOTS = GRP_WS_HDR + (size_t)GRP_MAX_LINES * GRP_CNT_STRIDE * 4;   // the slot meeting's slots: ZERO AT REST
+constexpr size_t GRP_WS_SLOT_BYTES = (size_t)16 * GRP_MAX_LINES * 8;   // 2 MB: groups * ceil16(members) <= 16 * GRP_MAX_LINES by the line bound
+constexpr size_t GRP_WS_PAIRS = GRP_WS_SLOTS + GRP_WS_SLOT_BYTES;      // pair blocks / records: written before read, may hold anything
 
 // flat tiles (k_mmq_flat) when a channel row is long enough that the row-piece tiling of k_mmq_group would idle lanes
 int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
@@ -273,7 +275,8 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     static const int target = env_int("CNNQ_GRP_WGS", 1024);
     if (!allow || HW % 4 != 0) return CNNQ_ENOTSUP;
     const int64_t cpc = HW / 4;
-    if (cpc < 128 || C * HW >= (int64_t)1 << 31 || N * cpc >= (int64_t)1 << 31) return CNNQ_ENOTSUP;
+    static const int mincpc = env_int("CNNQ_FLAT_MINCPC", 128);   // development knob
+    if (cpc < mincpc || C * HW >= (int64_t)1 << 31 || N * cpc >= (int64_t)1 << 31) return CNNQ_ENOTSUP;
     if (cpc % TPB == 0) return CNNQ_ENOTSUP;     // the row pieces already fill every lane
     const int64_t total = N * cpc;
     int K = 8;
@@ -284,9 +287,10 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
             if (C * ((total + TPB * K - 1) / (TPB * K)) >= target) break;
     }
     while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
-    // round 4: eight more steps per tile in LDS (160 KB per workgroup).  Measured +1.5 % on the packed single launch (whose
-    // tile is held longest) and -1 % on the b512 step, so only the packed output asks for it; CNNQ_FLAT_KL = 8 / 0 forces it
-    static const int kl_knob = env_int("CNNQ_FLAT_KL", -1);
+    // round 4: eight more steps per tile in LDS (160 KB per workgroup).  Measured +1.5 % on the packed single launch with the
+    // counter meeting, nothing with the slot meeting, -1 % on the b512 step: a development knob (CNNQ_FLAT_KL = 8), or a caller
+    // that asks for it (nobody does)
+    static const int kl_knob = env_int("CNNQ_FLAT_KL", 0);
     const int KL = (K == 32 && (kl_knob == 8 || (kl_knob < 0 && lds_rows))) ? 8 : 0;
     const int64_t Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
     if (Gs > GRP_GS_MAX || Gs < 2) return CNNQ_ENOTSUP;
@@ -301,6 +305,7 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     p->Gs = (int)Gs;
     p->ngroups = (int)C;
     p->gstride = (int)(((Gs + 15) / 16) * 16);
+    if ((size_t)C * p->gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
     p->ws_bytes = GRP_WS_PAIRS + (size_t)C * p->gstride * 8;
     FGeo& f = p->fg;
     f.N = (int)N; f.C = (int)C; f.HW = (int)HW; f.P = (int)(C * HW);
@@ -398,6 +403,7 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
     w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_SLOTS);
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
     if (p.flat) {
@@ -406,6 +412,10 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         if (out == 2 && (pk_narrow || ((uintptr_t)xo.packed & 15))) flags |= MMQ_FLAG_PK_NARROW;
         static const int pk_plain = env_int("CNNQ_PK_PLAIN", 0);
         if (out == 2 && pk_plain) flags |= MMQ_FLAG_PK_PLAIN;
+        // the slot meeting (cnnq_group.hip.h): +11 % on the packed output at b512 (nothing hides its waits there), +-0.5 % on the
+        // b512 / b64 steps with y to write; CNNQ_MEET_SLOTS = 0: the counter meeting (A/B)
+        static const int meet_slots = env_int("CNNQ_MEET_SLOTS", 1);
+        if (meet_slots) flags |= MMQ_FLAG_SLOTS;
         // With no y to write the launch is bound by what the resident workgroups hold for how long, not by the stores:
         // a channel's members dispatched in one burst (member fastest) wait 2-4 us for each other, blocks of 4 channels
         // ~9 us (a channel's members then start over four slot releases).  [512,256,56,56]: 464 -> 421 us (round 4).
@@ -453,6 +463,7 @@ int launch_minmax_group(const float* x, const GPlan& p, void* ws, float* out, hi
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
     w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_SLOTS);
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
 #define LAUNCH_MG(A, K) hipLaunchKernelGGL((k_minmax_group<A, K>), grid, block, 0, st, x, p.g, p.Gs, w, out)

@@ -299,7 +299,7 @@ def pc_qdq(x, N, C, HW, qp, want_codes=False, out=None, hist=None, reverse=False
 
 
 _GROUP_WS = {}
-GROUP_WS_BYTES = 16 << 20
+GROUP_WS_BYTES = 18 << 20
 
 
 _GROUP_POOL = {}

@@ -24,6 +24,7 @@ struct Args {
     long long delay;
     float sc, zp, qm;
     int alu;
+    int pk;              // 1: the packed regime - one float4 stored per 8 loaded (the arithmetic of all 8 feeds it)
     int w, nb, S;        // rows structure: lanes per piece, pieces per channel row, batch splits
 };
 
@@ -102,12 +103,16 @@ __device__ __forceinline__ void store_flat(const Args& a, int tile, const f4 (&v
     it.init(a, tile);
     f4* y4 = reinterpret_cast<f4*>(a.y);
     const float sc = a.sc + dep, zp = a.zp, qm = a.qm;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         f4 o;
         if (ALU) { o.x = qdq(v[j].x, sc, zp, qm); o.y = qdq(v[j].y, sc, zp, qm); o.z = qdq(v[j].z, sc, zp, qm); o.w = qdq(v[j].w, sc, zp, qm); }
         else o = v[j] * (1.0001f + dep);
-        if (it.valid(a)) __builtin_nontemporal_store(o, y4 + it.at(a));
+        if (a.pk) {
+            acc = (j & 7) ? acc + o : o;
+            if ((j & 7) == 7 && it.valid(a)) __builtin_nontemporal_store(acc, y4 + it.at(a));
+        } else if (it.valid(a)) __builtin_nontemporal_store(o, y4 + it.at(a));
         it.step(a);
     }
 }
@@ -193,11 +198,14 @@ static float timeit(F launch, int reps) {
 }
 
 // kind 0 rows, 1 flat, 2 pipe; K loads per lane and tile; occ = workgroups per CU the kernel is compiled for
+static int g_pk = 0;
+extern "C" void upipe_set_pk(int pk) { g_pk = pk; }
+
 extern "C" float upipe(int kind, int K, int occ, const void* x, void* y, int N, int C, int HW, int delay_ticks, int alu,
                        int reps) {
     Args a;
     a.x = (const float*)x; a.y = (float*)y; a.N = N; a.C = C; a.cpc = HW / 4; a.P4 = (long long)C * a.cpc;
-    a.total = (long long)N * a.cpc; a.delay = delay_ticks; a.sc = 0.37f; a.zp = 7.f; a.qm = 15.f; a.alu = alu;
+    a.total = (long long)N * a.cpc; a.delay = delay_ticks; a.sc = 0.37f; a.zp = 7.f; a.qm = 15.f; a.alu = alu; a.pk = g_pk;
     a.Tc = (int)((a.total + 256LL * K - 1) / (256LL * K));
     a.ntiles = a.Tc * C;
     a.nb = (a.cpc + 255) / 256; a.w = (a.cpc + a.nb - 1) / a.nb; a.S = (N + K - 1) / K;
@@ -217,6 +225,7 @@ extern "C" float upipe(int kind, int K, int occ, const void* x, void* y, int N, 
     } else {
         const int grid = cus * occ < a.ntiles ? cus * occ : a.ntiles;
         if (K == 16 && occ == 3) RUN2(k_pipe, 16, 3, grid);
+        if (K == 20 && occ == 3) RUN2(k_pipe, 20, 3, grid);
         if (K == 16 && occ == 2) RUN2(k_pipe, 16, 2, grid);
         if (K == 8 && occ == 6) RUN2(k_pipe, 8, 6, grid);
         if (K == 8 && occ == 4) RUN2(k_pipe, 8, 4, grid);
