@@ -74,6 +74,7 @@ SIGNATURES = {
     'cnnq_group_ws_status': (_I, [_P, ctypes.POINTER(ctypes.c_uint32)]),
     'cnnq_group_ws_status_clear': (_I, [_P]),
     'cnnq_pc_group_workspace': (ctypes.c_size_t, [_L, _L, _L]),
+    'cnnq_group_ws_at_rest': (_I, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     'cnnq_pc_group_describe': (_I, [_L, _L, _L, ctypes.POINTER(ctypes.c_int32)]),
     'cnnq_pc_minmax_qdq_group': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, _P, ctypes.c_uint32, _P]),
     'cnnq_pc_minmax_local': (_I, [_P, _L, _L, _L, _P, _P, _P]),

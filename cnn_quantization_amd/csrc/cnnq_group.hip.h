@@ -374,6 +374,64 @@ __device__ __forceinline__ int slots_meet(unsigned long long* slots, int member,
     }
 }
 
+// The slot meeting of k_mmq_group: `kk` pairs per member, slots [member][kk].  Lane (ch, j) = (tid / L, tid % L) watches channel
+// ch of members j, j + L, ...; L = the largest power of two <= min(64, 256 / kk), so a channel's watchers sit in one wave
+// and fold with shuffles.  Every wave polls on its own (no barrier inside the wait); a wave whose wait expired ORs 1 into
+// *sh_code.  Writes the group's extrema of channel ch < nch to sh_mn / sh_mx (kk > 1), or returns the lane's share in tn / tx
+// (whole_wg - mode 1, kk == 1: one channel, all 256 lanes watch).  The caller's barrier comes after.
+__device__ __forceinline__ void slots_meet_group(const unsigned long long* slots, int Gs, int kk, int nch, bool whole_wg, long long timeout_ticks,
+                                                 float* sh_mn, float* sh_mx, int* sh_code, float& tn, float& tx) {
+    const int tid = threadIdx.x;
+    int L = 1;
+    while (L < 64 && 2 * L * kk <= TPB) L <<= 1;
+    if (whole_wg) L = TPB;      // mode 1: one channel per group, the caller folds the 256 shares (kk == 1)
+    const int ch = tid / L, j = tid - ch * L;
+    const bool active = ch < nch;
+    tn = INFINITY;
+    tx = -INFINITY;
+    long long t0 = 0;
+    int spins = 0;
+    for (int w0 = 0; w0 * L < Gs; w0 += 8) {        // windows of 8 members per lane (one window unless Gs > 8 L)
+        unsigned pend = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pend |= (active && j + L * (w0 + i) < Gs) ? (1u << i) : 0u;
+        for (;; ++spins) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                v[i] = ((pend >> i) & 1u) ? __hip_atomic_load(slots + (size_t)(j + L * (w0 + i)) * kk + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (((pend >> i) & 1u) && v[i]) {
+                    float u, w;
+                    unpack_pair(~v[i], u, w);
+                    tn = pmin(tn, u);
+                    tx = pmax(tx, w);
+                    pend &= ~(1u << i);
+                }
+            if (__ballot(pend != 0u) == 0ull) break;
+            int expired = 0;
+            if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                expired = (now - t0 > timeout_ticks || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(expired)) {
+                if ((tid & 63) == 0) atomicOr(sh_code, 1);
+                return;
+            }
+            if (spins < 2) __builtin_amdgcn_s_sleep(8);
+            else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    if (!whole_wg) {
+        for (int m = L >> 1; m >= 1; m >>= 1) { tn = pmin(tn, shfl_xor_f(tn, m)); tx = pmax(tx, shfl_xor_f(tx, m)); }
+        if (active && j == 0) { sh_mn[ch] = tn; sh_mx[ch] = tx; }
+    }
+}
+
 // ws: [0] status word, [256 ..) 16384 arrival/departure counters, one per group and per 256-byte line (a fixed
 // region, so that no geometry's pairs ever land on another geometry's counters), then one 128-byte-aligned block of 8-byte
 // {min, max} pairs per group: [member] (mode 1) or [member][k] (mode 2)
@@ -446,18 +504,43 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     // ---- publish this workgroup's pairs (write-through), arrive, wait for the group
     unsigned long long* blk = ws.part + (size_t)rb.group * ws.gstride;
     const int kk = (g.mode == 1) ? 1 : g.k;
+    const bool use_slots = (flags & MMQ_FLAG_SLOTS) != 0;
+    unsigned long long* slots = ws.slots + (size_t)rb.group * ws.gstride;    // the slot meeting's blocks: zero at rest
+    if (use_slots) {
+        // a pair IS the arrival: stored once, nobody waits for the acknowledgement (sh_mn / sh_mx are read here and
+        // rewritten by the meeting: the barrier in between)
+        for (int ch = tid; ch < nch; ch += TPB)
+            __hip_atomic_store(slots + (size_t)rb.member * kk + ch, slot_of(sh_mn[ch], sh_mx[ch]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        // bit 1: the test hook; bit 2: a wait has expired on this workspace before (thread 0 asked): the short timeout
+        if (tid == 0) sh_timed_out = ((flags & MMQ_FLAG_TEST_HOOK) ? 2 : 0) | ((st0 & 1u) ? 4 : 0);
+        __syncthreads();
+        GRP_STAMP(3);
+    } else {
     for (int ch = tid; ch < nch; ch += TPB)
         __hip_atomic_store(blk + (size_t)rb.member * kk + ch, pack_pair(sh_mn[ch], sh_mx[ch]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its pairs have left the CU
     __syncthreads();
     GRP_STAMP(3);
+    }
+    float sn = INFINITY, sx = -INFINITY;
 #if FLAT_ABL & 2
     if (tid == 0) sh_timed_out = 0;
     __syncthreads();
     if (true) {
     } else
 #else
+    if (use_slots) {
+        const int c0 = sh_timed_out;
+        if (!(c0 & 2)) slots_meet_group(slots, Gs, kk, nch, g.mode == 1, (c0 & 4) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS, sh_mn, sh_mx, &sh_timed_out, sn, sx);
+        __syncthreads();
+        if (tid == 0) {
+            const int code = sh_timed_out & 3;
+            if (code) atomicOr(ws.status, (unsigned)code);
+            GRP_STAMP(4);
+        }
+    } else {
     if (tid == 0) {
         const int timed_out = grp_meet(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs, flags, [] {},
                                        (st0 & 1u) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS);
@@ -466,9 +549,15 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         GRP_STAMP(4);
     }
     __syncthreads();
+    }
 #endif
-    if (sh_timed_out) {
+    if (sh_timed_out & 3) {
         group_minmax_from_x<A>(x, g, b, l_mn, l_mx, sh_mn, sh_mx);
+    } else if (use_slots) {
+        if (g.mode == 1) {
+            const float one_n[1] = {sn}, one_x[1] = {sx};
+            wg_channel_minmax<1>(g, b, true, one_n, one_x, l_mn, l_mx, sh_mn, sh_mx);   // the one-channel reduction
+        }
     } else if (g.mode == 1) {
         float tn = INFINITY, tx = -INFINITY;
         for (int m = tid; m < Gs; m += TPB) {
@@ -572,7 +661,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     //      counter line re-arms it for the next launch
     GRP_STAMP(6);
 #if !(FLAT_ABL & 2)
-    if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
+    if (use_slots) {
+        if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
+        __syncthreads();
+        if (sh_timed_out)      // the last member out re-arms the group's slots: every other member has read them
+            for (int m = tid; m < Gs * kk; m += TPB) __hip_atomic_store(slots + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
 #endif
 #ifdef GRP_TRACE
     if (g_grp_trace) {

@@ -31,6 +31,7 @@
 
 #include <string.h>
 
+#include <vector>
 #include "cnnq_common.hip.h"
 #include "cnnq_stats.hip.h"
 #include "cnnq_params.hip.h"
@@ -524,6 +525,19 @@ int cnnq_group_ws_status_clear(void* ws) {
     if (!ws) return CNNQ_EINVAL;
     const uint32_t zero = 0;
     return (int)hipMemcpy(ws, &zero, sizeof(uint32_t), hipMemcpyHostToDevice);   // synchronises, like the read
+}
+
+// tests: the regions every launch must leave zero - the header after the status word, the counter lines, the slots -
+// copied to the host (synchronising) and counted: *nonzero_words_host = the 32-bit words that are not zero
+int cnnq_group_ws_at_rest(const void* ws, uint64_t* nonzero_words_host) {
+    if (!ws || !nonzero_words_host) return CNNQ_EINVAL;
+    std::vector<uint32_t> h(GRP_WS_PAIRS / 4);
+    const hipError_t e = hipMemcpy(h.data(), ws, GRP_WS_PAIRS, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    uint64_t n = 0;
+    for (size_t i = 1; i < h.size(); ++i) n += h[i] != 0u;
+    *nonzero_words_host = n;
+    return 0;
 }
 
 #ifdef GRP_TRACE

@@ -305,7 +305,6 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     p->Gs = (int)Gs;
     p->ngroups = (int)C;
     p->gstride = (int)(((Gs + 15) / 16) * 16);
-    if ((size_t)C * p->gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
     p->ws_bytes = GRP_WS_PAIRS + (size_t)C * p->gstride * 8;
     FGeo& f = p->fg;
     f.N = (int)N; f.C = (int)C; f.HW = (int)HW; f.P = (int)(C * HW);
@@ -406,16 +405,16 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     w.slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_SLOTS);
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
+    // the slot meeting (cnnq_group.hip.h): +11 % on the packed output at b512 (nothing hides its waits there), +-0.5 % on the
+    // b512 / b64 steps with y to write; CNNQ_MEET_SLOTS = 0: the counter meeting (A/B)
+    static const int meet_slots = env_int("CNNQ_MEET_SLOTS", 1);
+    if (meet_slots && (size_t)p.ngroups * p.gstride * 8 <= GRP_WS_SLOT_BYTES) flags |= MMQ_FLAG_SLOTS;
     if (p.flat) {
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
         static const int pk_narrow = env_int("CNNQ_PK_NARROW", 0);          // development knob: the 2-byte stores of round 3
         if (out == 2 && (pk_narrow || ((uintptr_t)xo.packed & 15))) flags |= MMQ_FLAG_PK_NARROW;
         static const int pk_plain = env_int("CNNQ_PK_PLAIN", 0);
         if (out == 2 && pk_plain) flags |= MMQ_FLAG_PK_PLAIN;
-        // the slot meeting (cnnq_group.hip.h): +11 % on the packed output at b512 (nothing hides its waits there), +-0.5 % on the
-        // b512 / b64 steps with y to write; CNNQ_MEET_SLOTS = 0: the counter meeting (A/B)
-        static const int meet_slots = env_int("CNNQ_MEET_SLOTS", 1);
-        if (meet_slots) flags |= MMQ_FLAG_SLOTS;
         // With no y to write the launch is bound by what the resident workgroups hold for how long, not by the stores:
         // a channel's members dispatched in one burst (member fastest) wait 2-4 us for each other, blocks of 4 channels
         // ~9 us (a channel's members then start over four slot releases).  [512,256,56,56]: 464 -> 421 us (round 4).

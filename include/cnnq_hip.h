@@ -266,8 +266,10 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
 
 /* Config 2 in ONE launch and ONE read of x for tensors whose channels span several workgroups (csrc/cnnq_group.hip.h):
  * every workgroup keeps its tile of x in registers; the workgroups that hold pieces of the same channels exchange
- * their {min, max} pairs through `ws` (write-through stores, one arrival counter per channel group, a bounded wait
- * that falls back to recomputing the extrema from x - never a deadlock, never different bits).
+ * their {min, max} pairs through `ws` (round 4, the slot meeting: a member's pair is stored once into its zero-at-rest slot
+ * and IS its arrival, the members poll the group's slots, the last one to leave zeroes them; CNNQ_MEET_SLOTS=0: write-through
+ * stores and one arrival counter per channel group as in round 2; either way a bounded wait that falls back to recomputing
+ * the extrema from x - never a deadlock, never different bits).
  *   x, y must not overlap (both are read / written through __restrict__ pointers, and a workgroup whose bounded wait
  *        expires re-reads x after other workgroups may have stored y); the same holds for every single-launch entry point.
  *   ws   from cnnq_group_ws_alloc(bytes >= cnnq_pc_group_workspace(N, C, HW)): fine-grained (uncached) device
@@ -289,6 +291,9 @@ int cnnq_group_ws_alloc(size_t bytes, void** ws);   /* allocates + zeroes, synch
 int cnnq_group_ws_free(void* ws);
 int cnnq_group_ws_status(const void* ws, uint32_t* status_host);
 int cnnq_group_ws_status_clear(void* ws);
+/* tests: counts the 32-bit words that are not zero in the regions every launch leaves zero (everything below the pair
+ * blocks but the status word: counter lines, the slot meeting's slots); synchronises. */
+int cnnq_group_ws_at_rest(const void* ws, uint64_t* nonzero_words_host);
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              void* ws, float* qp, float* mm, unsigned flags, void* stream);

@@ -170,6 +170,47 @@ def test_group_rearms_and_replays_from_a_graph(ops):
     assert st == 0 and ops.group_status(x) == 0
 
 
+@pytest.mark.parametrize('slots', [1, 0])
+def test_workspace_is_zero_at_rest(slots):
+    """Counters and slots are zero whenever no launch is in flight - after launches of every tile shape on ONE workspace,
+    normal and with the recompute path forced - so no launch can meet another launch's arrivals: with the slot meeting
+    (round 4) a stale non-zero slot WOULD be taken for a member's pair.  Runs in a process of its own so that the
+    meeting can be chosen (CNNQ_MEET_SLOTS is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from cnn_quantization_amd import _lib
+lib = _lib.load()
+ws = ctypes.c_void_p()
+_lib.check(lib.cnnq_group_ws_alloc(18 << 20, ctypes.byref(ws)), 'alloc')
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+shapes = [(40, 6, 56, 56), (300, 3, 56, 56), (66, 3, 112, 112), (260, 2, 112, 112), (70, 40, 7, 7), (64, 256, 14, 14),
+          (5, 3, 28, 28), (130, 20, 28, 28), (1, 1100, 2, 2), (600, 2, 8, 8), (64, 512, 7, 7), (512, 16, 56, 56)]
+n = ctypes.c_uint64(0)
+for flags in (0, 1, 0):
+    for (N, C, H, W) in shapes:
+        x = torch.randn(N, C, H, W, device='cuda') * 3
+        y = torch.empty_like(x)
+        qp = torch.empty(3, C, device='cuda')
+        mm = torch.empty(2, C, device='cuda')
+        rc = lib.cnnq_pc_minmax_qdq_group(x.data_ptr(), y.data_ptr(), N, C, H * W, 4, 0, ws, qp.data_ptr(), mm.data_ptr(), flags, st)
+        assert rc == 0, (rc, N, C, H, W)
+        _lib.check(lib.cnnq_group_ws_at_rest(ws, ctypes.byref(n)), 'at_rest')
+        assert n.value == 0, ('words not zero at rest', n.value, (N, C, H, W), flags)
+        assert torch.equal(mm[0], x.amin(dim=(0, 2, 3))) and torch.equal(mm[1], x.amax(dim=(0, 2, 3))), (N, C, H, W)
+s = ctypes.c_uint32(0)
+_lib.check(lib.cnnq_group_ws_status(ws, ctypes.byref(s)), 'status')
+assert s.value == 2, s.value          # the test hook reported itself; no wait expired
+print('ok')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNNQ_MEET_SLOTS=str(slots))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-3000:]
+
+
 @pytest.mark.parametrize('shape,half', [((512, 64, 112, 112), True), ((512, 256, 56, 56), False),
                                         ((512, 2048, 7, 7), False), ((64, 64, 112, 112), True),
                                         ((512, 512, 28, 28), False), ((64, 64, 56, 56), True),
