@@ -971,8 +971,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
                 const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
                 const float t[4] = {q.x, q.y, q.z, q.w};
                 float o[4], cd[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(t[e], s_sc, s_rs, s_zp, qm, cd[e]);
+                qdq4_fast(t, s_sc, s_rs, s_zp, qm, o, cd);
                 if constexpr (OUT == 2) {
                     if (pkl > 1) sh_pk[l * 256 + tid] = pack4_of(cd);
                     else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
@@ -985,11 +984,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             float o[4], cd[4];
-#pragma unroll
 #if FLAT_ABL & 8
+#pragma unroll
             for (int e = 0; e < 4; ++e) { o[e] = v[j][e]; cd[e] = 0.f; }
 #else
-            for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], s_sc, s_rs, s_zp, qm, cd[e]);
+            qdq4_fast(v[j], s_sc, s_rs, s_zp, qm, o, cd);
 #endif
             if constexpr (OUT == 2) {
                 if (pkl > 1) sh_pk[(KL + j) * 256 + tid] = pack4_of(cd);
