@@ -341,37 +341,42 @@ __device__ __forceinline__ int slots_meet(unsigned long long* slots, int member,
     if (tid >= 64) return 0;
     if (tid == 0) __hip_atomic_store(slots + member, slot_of(cmn, cmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (flags & MMQ_FLAG_TEST_HOOK) return 2;
-    unsigned pend = 0u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) pend |= (tid + 64 * i < Gs) ? (1u << i) : 0u;
-    const int rounds = (Gs + 63) >> 6;      // wave-uniform
     long long t0 = 0;
-    for (int spins = 0;; ++spins) {
-        unsigned long long v[8];
+    int spins = 0;
+    // windows of 4 members per lane (the tile's registers are live across the wait: 8 values in flight per lane cost the
+    // K = 16 / 8 kernels a wave of occupancy); one window unless the group has more than 256 members
+    for (int w0 = 0; w0 * 64 < Gs; w0 += 4) {
+        const unsigned long long* p = slots + tid + 64 * w0;
+        unsigned pend = 0u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < rounds) v[i] = ((pend >> i) & 1u) ? __hip_atomic_load(slots + tid + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (int i = 0; i < 4; ++i) pend |= (tid + 64 * (w0 + i) < Gs) ? (1u << i) : 0u;
+        for (;; ++spins) {
+            unsigned long long v[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < rounds && ((pend >> i) & 1u) && v[i]) {
-                float u, w;
-                unpack_pair(~v[i], u, w);
-                tn = pmin(tn, u);
-                tx = pmax(tx, w);
-                pend &= ~(1u << i);
+            for (int i = 0; i < 4; ++i) v[i] = ((pend >> i) & 1u) ? __hip_atomic_load(p + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (((pend >> i) & 1u) && v[i]) {
+                    float u, w;
+                    unpack_pair(~v[i], u, w);
+                    tn = pmin(tn, u);
+                    tx = pmax(tx, w);
+                    pend &= ~(1u << i);
+                }
+            if (__ballot(pend != 0u) == 0ull) break;
+            int expired = 0;
+            if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                expired = (now - t0 > timeout_ticks || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
             }
-        if (__ballot(pend != 0u) == 0ull) return 0;
-        int expired = 0;
-        if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            expired = (now - t0 > timeout_ticks || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(expired)) return 1;
+            if (spins < 2) __builtin_amdgcn_s_sleep(8);
+            else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(64);
         }
-        if (__builtin_amdgcn_readfirstlane(expired)) return 1;
-        if (spins < 2) __builtin_amdgcn_s_sleep(8);
-        else if (spins < 6) __builtin_amdgcn_s_sleep(32);
-        else __builtin_amdgcn_s_sleep(64);
     }
+    return 0;
 }
 
 // The slot meeting of k_mmq_group: `kk` pairs per member, slots [member][kk].  Lane (ch, j) = (tid / L, tid % L) watches channel
@@ -379,6 +384,7 @@ __device__ __forceinline__ int slots_meet(unsigned long long* slots, int member,
 // and fold with shuffles.  Every wave polls on its own (no barrier inside the wait); a wave whose wait expired ORs 1 into
 // *sh_code.  Writes the group's extrema of channel ch < nch to sh_mn / sh_mx (kk > 1), or returns the lane's share in tn / tx
 // (whole_wg - mode 1, kk == 1: one channel, all 256 lanes watch).  The caller's barrier comes after.
+template <int W>
 __device__ __forceinline__ void slots_meet_group(const unsigned long long* slots, int Gs, int kk, int nch, bool whole_wg, long long timeout_ticks,
                                                  float* sh_mn, float* sh_mx, int* sh_code, float& tn, float& tx) {
     const int tid = threadIdx.x;
@@ -391,18 +397,19 @@ __device__ __forceinline__ void slots_meet_group(const unsigned long long* slots
     tx = -INFINITY;
     long long t0 = 0;
     int spins = 0;
-    for (int w0 = 0; w0 * L < Gs; w0 += 8) {        // windows of 8 members per lane (one window unless Gs > 8 L)
+    for (int w0 = 0; w0 * L < Gs; w0 += W) {        // windows of W members per lane (one window unless Gs > W L)
+        const unsigned long long* p = slots + (unsigned)((j + L * w0) * kk + ch);
+        const unsigned step = (unsigned)(L * kk);
         unsigned pend = 0u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pend |= (active && j + L * (w0 + i) < Gs) ? (1u << i) : 0u;
+        for (int i = 0; i < W; ++i) pend |= (active && j + L * (w0 + i) < Gs) ? (1u << i) : 0u;
         for (;; ++spins) {
-            unsigned long long v[8];
+            unsigned long long v[W];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                v[i] = ((pend >> i) & 1u) ? __hip_atomic_load(slots + (size_t)(j + L * (w0 + i)) * kk + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                          : 0ull;
+            for (int i = 0; i < W; ++i)
+                v[i] = ((pend >> i) & 1u) ? __hip_atomic_load(p + i * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < W; ++i)
                 if (((pend >> i) & 1u) && v[i]) {
                     float u, w;
                     unpack_pair(~v[i], u, w);
@@ -533,7 +540,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
 #else
     if (use_slots) {
         const int c0 = sh_timed_out;
-        if (!(c0 & 2)) slots_meet_group(slots, Gs, kk, nch, g.mode == 1, (c0 & 4) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS, sh_mn, sh_mx, &sh_timed_out, sn, sx);
+        if (!(c0 & 2)) slots_meet_group<(K >= 32 ? 4 : 2)>(slots, Gs, kk, nch, g.mode == 1, (c0 & 4) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS, sh_mn, sh_mx, &sh_timed_out, sn, sx);
         __syncthreads();
         if (tid == 0) {
             const int code = sh_timed_out & 3;
