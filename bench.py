@@ -88,149 +88,7 @@ def run_step(ops, layers, group):
         ops.act_qdq_per_channel(L['x'], 4, positive=L['half'], group=group, out=L['y'])
 
 
-def time_kernel_classes(layers, single_launch=True):
-    """Device time per kernel class, measured live with HIP events recorded on the launch stream inside ONE pass that
-    issues exactly the sequence the product path issues (so cache state is the real one).  On the single-launch routes an
-    event is recorded only where the kernel class CHANGES from one tensor to the next (five events per pass: the
-    layers come grouped by shape), so the pass runs at the speed of the timed step - with one event per launch boundary
-    (round 2) the instrumented pass was 1.5 % slower than the step it explained.  A class's time is the sum of its runs,
-    launch gaps inside a run included, exactly as the step pays them.  Returns {class: [seconds, launches, elements]}.
-    single_launch=False: the three-launch chain (what runs with several ranks, where the cross-rank exchange sits
-    between the statistics and the Q/DQ pass), one event per launch boundary."""
-    import ctypes
-    from cnn_quantization_amd import _lib, ops
-    lib = _lib.load()
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    resident_ok = single_launch and os.environ.get('CNNQ_RESIDENT', '1') != '0'
-    gws = ops._group_workspace(layers[0]['x']) if resident_ok else None
-    d = (ctypes.c_int32 * 8)()
-    # classify first (no launches), allocate the small tables
-    plan = []
-    for L in layers:
-        N, C, HW = L['N'], L['C'], L['HW']
-        group_ok = resident_ok and 0 < lib.cnnq_pc_group_workspace(N, C, HW) <= ops.GROUP_WS_BYTES
-        if resident_ok and lib.cnnq_pc_resident_describe(N, C, HW, d) == 0 and not (group_ok and d[6] < 192):
-            cls = 'k_mmq_whole'
-        elif group_ok:
-            cls = 'k_mmq_flat' if (lib.cnnq_pc_group_describe(N, C, HW, d) == 0 and d[2] == 3) else 'k_mmq_group'
-        else:
-            cls = 'chain'
-        G = lib.cnnq_pc_groups(N, C, HW, 1)
-        plan.append((L, cls, torch.empty((3, C), dtype=torch.float32, device=L['x'].device),
-                     torch.empty((G, 2, C), dtype=torch.float32, device=L['x'].device) if cls == 'chain' else None, G))
-    runs, recs = [], []          # single-launch runs: (class, start event, end event, launches, elements); chain records
-    cur = None
-    for L, cls, qp, pmm, G in plan:
-        x, y, N, C, HW = L['x'], L['y'], L['N'], L['C'], L['HW']
-        n = x.numel()
-        if cls == 'chain':
-            if cur is not None:
-                cur[2] = torch.cuda.Event(enable_timing=True); cur[2].record(); runs.append(cur); cur = None
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
-            _lib.check(lib.cnnq_pc_minmax(x.data_ptr(), N, C, HW, pmm.data_ptr(), st), 'minmax')
-            e[1].record()
-            _lib.check(lib.cnnq_pc_minmax_params(pmm.data_ptr(), G, C, 4, int(L['half']), qp.data_ptr(), st), 'params')
-            e[2].record()
-            _lib.check(lib.cnnq_pc_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, qp.data_ptr(), None, None, 1, st), 'qdq')
-            e[3].record()
-            recs.append((n, [('k_minmax', e[0], e[1]), ('k_minmax_params', e[1], e[2]), ('k_qdq', e[2], e[3])]))
-            continue
-        if cur is None or cur[0] != cls:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            if cur is not None:
-                cur[2] = ev
-                runs.append(cur)
-            cur = [cls, ev, None, 0, 0]
-        if cls == 'k_mmq_whole':
-            _lib.check(lib.cnnq_pc_minmax_qdq_resident(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']),
-                                                       qp.data_ptr(), None, st), 'resident')
-        else:
-            _lib.check(lib.cnnq_pc_minmax_qdq_group(x.data_ptr(), y.data_ptr(), N, C, HW, 4, int(L['half']), gws,
-                                                    qp.data_ptr(), None, 0, st), 'group')
-        cur[3] += 1
-        cur[4] += n
-    if cur is not None:
-        cur[2] = torch.cuda.Event(enable_timing=True); cur[2].record(); runs.append(cur)
-    torch.cuda.synchronize()
-    out = {}
-    for cls, a, b, launches, elems in runs:
-        o = out.setdefault(cls, [0., 0, 0])
-        o[0] += a.elapsed_time(b) * 1e-3
-        o[1] += launches
-        o[2] += elems
-    for n, evs in recs:
-        for name, a, b in evs:
-            o = out.setdefault(name, [0., 0, 0])
-            o[0] += a.elapsed_time(b) * 1e-3
-            o[1] += 1
-            o[2] += n
-    return out
-
-
-KERNEL_BYTES = {'k_qdq': (BYTES_QDQ, 'fused per-channel Q/DQ pass, 8 algorithmic B/elem'),
-                'k_minmax': (BYTES_STATS, 'per-channel exact min/max pass, 4 B/elem'),
-                'k_mmq_whole': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, whole channels per workgroup, '
-                                           '8 algorithmic B/elem'),
-                'k_mmq_group': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, extrema exchanged between the '
-                                           'workgroups of a channel group (row-piece / whole-channel tiles), 8 algorithmic B/elem'),
-                'k_mmq_flat': (BYTES_QDQ, 'register-resident min/max + Q/DQ in one launch, extrema exchanged between the '
-                                          'workgroups of a channel, flat tiles of 256*K consecutive float4 of the channel, '
-                                          '8 algorithmic B/elem'),
-                'k_minmax_params': (0, 'per-channel parameter table (latency-bound, a few KB)')}
-
-
-def roofline_objects(layers, batch, world, single_launch=True):
-    time_kernel_classes(layers, single_launch)        # warm
-    kcs = [time_kernel_classes(layers, single_launch) for _ in range(3)]
-    objs = {}
-    for name in kcs[0]:
-        t = min(k[name][0] for k in kcs)
-        launches, elems = kcs[0][name][1], kcs[0][name][2]
-        by, what = KERNEL_BYTES[name]
-        gbs = elems * by / t / 1e9
-        objs[name] = {'bound': 'hbm', 'kernel': '%s (%s)' % (name, what), 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                      'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None, 'launches_per_step': launches,
-                      'avg_launch_ms': t * 1e3 / launches, 'bytes_per_launch': elems * by / launches,
-                      'time_per_step_ms': t * 1e3}
-    # HBM bytes from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command and
-    # committed under profiles/ (never measured inside a timed run); attached only to the configuration they
-    # were measured on
-    pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as f:
-                rec = json.load(f)
-            for name, o in objs.items():
-                k = '%s@b%d' % (name, batch)
-                if world == 1 and k in rec.get('bytes_per_launch', {}):
-                    o['traffic'] = rec['bytes_per_launch'][k]
-                    o['traffic_unit'] = 'bytes per launch'
-                    o['traffic_source'] = rec.get('source', 'profiles/' + os.path.basename(pmc))
-        except (OSError, ValueError):
-            pass
-    # the same kernel's average duration under `rocprofv3 --kernel-trace --stats` of this command, committed with the box
-    # it was measured on (profiles/r04_rocprof_headline.json): next to the live figure so the two can be paired
-    rp = os.path.join(ROOT, 'profiles', 'r04_rocprof_headline.json')
-    if os.path.exists(rp) and world == 1:
-        try:
-            with open(rp) as f:
-                rec = json.load(f)
-            for name, o in objs.items():
-                k = '%s@b%d' % (name, batch)
-                if k in rec.get('avg_launch_us', {}):
-                    us = rec['avg_launch_us'][k]
-                    o['frac_rocprof'] = o['bytes_per_launch'] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-                    o['rocprof_avg_launch_us'] = us
-                    o['rocprof_box'] = rec.get('box')
-                    o['rocprof_source'] = rec.get('source')
-        except (OSError, ValueError):
-            pass
-    dominant = max((n for n in objs if KERNEL_BYTES[n][0]), key=lambda n: objs[n]['time_per_step_ms'])
-    return dominant, objs
+from bench_roofline import roofline_objects  # noqa: E402  (the `roofline` keys: live HIP-event timing per kernel class)
 
 
 def verify_outputs(ops, layers, group=None, world=1):
@@ -456,14 +314,42 @@ def main():
                 run_step(ops, layers, group)
         torch.cuda.current_stream().wait_stream(side)
         step = graph.replay
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_run():
+        # every rank reaches both barriers whatever happens in between: a wait of the in-launch exchange that expired
+        # surfaces as CnnqError at that exchange's next host check, on one rank first
+        ok = True
+        try:
+            for _ in range(args.warmup):
+                step()
+        except _lib.CnnqError:
+            ok = False
+        barrier()
+        t0 = time.perf_counter()
+        if ok:
+            try:
+                for _ in range(args.steps):
+                    step()
+            except _lib.CnnqError:
+                ok = False
+        barrier()
+        return time.perf_counter() - t0, ok
+
+    dt, ok = timed_run()
+    xrank_info = None
+    if (world > 1 or args.force_exchange) and D.xrank_exchange(group) is not None:
+        # CNNQ_XRANK=auto / 1 and verified at first use: the job ran through the in-launch exchange.  If a peer wait expired
+        # anywhere, every rank drops to the collective together and the job is timed again
+        ok = ok and bool(D.xrank_exchange(group).healthy())
+        if world > 1:
+            v = torch.tensor([1 if ok else 0], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            ok = bool(int(v.item()))
+        xrank_info = {'used': ok, 'healthy': ok, 'fell_back': not ok}
+        if not ok:
+            D.disable_xrank(group)
+            ops.release_plans()
+            dt, ok = timed_run()
+    assert ok, 'the timed region failed outside the in-launch exchange'
     total_elems = elems
     per_rank_ms = [dt * 1e3 / args.steps]
     if world > 1:
@@ -482,7 +368,7 @@ def main():
         exchange_name = 'none (1 GPU)'
     elif D.xrank_exchange(group) is not None:
         xr = D.xrank_exchange(group)
-        exchange_name = ('in-launch exchange of the per-channel {min, max} through hipIpc windows (CNNQ_XRANK=1, verified against '
+        exchange_name = ('in-launch exchange of the per-channel {min, max} through hipIpc windows (CNNQ_XRANK=%s, verified against ' % D.xrank_mode() +
                          'the collective; x is read once)%s' % (' (forced on a 1-rank group)' if args.force_exchange else ''))
         if not xr.healthy():
             exchange_name += ' - UNHEALTHY: a wait for a peer expired, results of this run are invalid'
@@ -521,7 +407,7 @@ def main():
                                'per-channel int4 dynamic min/max quantize+dequantize (-pcq_a --qtype int4)' % (
                                    args.batch * (world if args.scaling == 'weak' else 1), total_elems / 1e9, elems / 1e9),
                    'per_gpu_batch': per_rank, 'global_batch': args.batch * (world if args.scaling == 'weak' else 1),
-                   'parallelism': 'batch-sharded dp%d, per-channel stats all_gather' % world,
+                   'parallelism': 'batch-sharded dp%d, %s' % (world, 'per-channel extrema exchanged inside the launch' if (xrank_info or {}).get('used') else 'per-channel stats all_gather'),
                    'exchange': exchange_name, 'launch': 'hip graph replay' if args.graph else 'eager'},
         'verified': verified, 'group_status': group_status, 'xrank': None, 'box': box_id(dev_index),
         'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
@@ -531,13 +417,7 @@ def main():
         'roofline': objs[dominant],
         'roofline_other_kernels': {k: v for k, v in objs.items() if k != dominant},
     }
-    # The in-launch cross-rank exchange (csrc/cnnq_xrank.hip.h) is opt-in: `CNNQ_XRANK=1 ... bench.py --gpus N` runs the
-    # whole job through it (config.exchange then names it; `xrank` reports whether it stayed healthy).  It is never
-    # attempted next to the default run: a hang there must surface as a failing run of its own, not behind a printed line.
-    xrank_info = None
-    if D.xrank_exchange(group) is not None:
-        xrank_info = {'used': True, 'healthy': bool(D.xrank_exchange(group).healthy())}
-    out['xrank'] = xrank_info
+    out['xrank'] = xrank_info       # None: the collective from the start (1 GPU, ranks sharing a GPU, CNNQ_XRANK=0, not verified)
     if rank == 0:
         if world == 1 and not args.force_exchange:
             if not args.no_other_configs:

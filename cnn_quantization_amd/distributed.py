@@ -235,6 +235,8 @@ class XRankExchange(P2PExchange):
         ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
         self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
         self.seq_dev = None                             # the device-side sequence word (allocated at the first launch)
+        fa = os.environ.get('CNNQ_XRANK_TEST_FAIL_AT')    # tests: rank 0 reports an expired wait at its n-th launch
+        self.fail_at = int(fa) if (fa and self.rank == 0) else 0
 
     def _alloc_window(self, own, handle):
         import ctypes
@@ -262,6 +264,8 @@ class XRankExchange(P2PExchange):
         self.calls += 1
         if not capturing and self.calls % self.CHECK_EVERY == 0 and not self.healthy():      # periodic host check (synchronises)
             raise self.L.CnnqError('XRankExchange: a wait for a peer expired; results since the last check are invalid')
+        if self.fail_at and self.calls == self.fail_at:
+            raise self.L.CnnqError('XRankExchange: CNNQ_XRANK_TEST_FAIL_AT (test hook)')
         rc = self.lib.cnnq_pc_minmax_qdq_xrank_dev(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
                                                    ws_ptr, gws, gws_bytes, self.windows.data_ptr(), self.rank, self.world,
                                                    self.CMAX, self.seq_dev.data_ptr(), self.status.data_ptr(), self.timeout,
@@ -294,13 +298,25 @@ _P2P = {}
 _XRANK = {}
 
 
-def xrank_exchange(group=None):
-    """The process-wide XRankExchange of `group` when CNNQ_XRANK=1 and it verified against the collective path; else None.
-    World size 1 only under CNNQ_FORCE_EXCHANGE=1 (timing the protocol on a 1-GPU box)."""
+def xrank_mode():
+    """CNNQ_XRANK: '0' never; '1' whenever a group exchanges (also ranks that share a GPU, also a forced 1-rank exchange);
+    'auto' (default, round 4): when the group has several ranks and one GPU per rank (backend nccl = RCCL) - ranks that
+    share a device cannot count on their launches running together."""
     import os
-    if os.environ.get('CNNQ_XRANK', '0') != '1' or not (dist.is_available() and dist.is_initialized()):
+    m = os.environ.get('CNNQ_XRANK', 'auto')
+    return m if m in ('0', '1') else 'auto'
+
+
+def xrank_exchange(group=None):
+    """The process-wide XRankExchange of `group` when CNNQ_XRANK allows it (xrank_mode) and it verified against the collective
+    path on every rank; else None (the collective).  World size 1 only with CNNQ_XRANK=1 under CNNQ_FORCE_EXCHANGE=1 (timing
+    the protocol on a 1-GPU box)."""
+    mode = xrank_mode()
+    if mode == '0' or not (dist.is_available() and dist.is_initialized()):
         return None
-    if world_size(group) == 1 and not forced_exchange():
+    if world_size(group) == 1 and not (mode == '1' and forced_exchange()):
+        return None
+    if mode == 'auto' and dist.get_backend(group) != 'nccl':
         return None
     key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
     if key not in _XRANK:
@@ -315,12 +331,22 @@ def xrank_exchange(group=None):
     return _XRANK[key]
 
 
+def disable_xrank(group=None):
+    """Every rank of `group` calls this together (after a wait for a peer expired, say): the group's in-launch exchange is
+    closed and the collective path serves the group from now on."""
+    key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    ex = _XRANK.get(key)
+    if ex is not None:
+        ex.close()
+    _XRANK[key] = None
+
+
 def p2p_exchange(group=None):
     """The process-wide P2PExchange of `group` when CNNQ_P2P_EXCHANGE=1 and it verified; else None (RCCL)."""
     import os
     # CNNQ_XRANK=1 implies it (round 4): a sharded run that exchanges config 2's extrema inside the launch moves the moment
     # records of the statistics passes (configs 3 / 4 / 5) through the same kind of window - no collective launch anywhere
-    if (os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' and os.environ.get('CNNQ_XRANK', '0') != '1') or world_size(group) == 1:
+    if (os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' and os.environ.get('CNNQ_XRANK', 'auto') != '1') or world_size(group) == 1:
         return None
     # keyed by the group's membership, not by id(group): a new group object may reuse a collected one's id
     key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))

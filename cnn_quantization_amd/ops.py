@@ -45,7 +45,7 @@ def _dev_f32(x, what='tensor'):
 # review); reload_switches() re-reads them for callers that change the environment afterwards (tests, tools)
 def reload_switches():
     global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED, _XRANK_ON
-    _XRANK_ON = os.environ.get('CNNQ_XRANK', '0') == '1'              # 1: sharded config 2 exchanges INSIDE the single launch (opt-in)
+    _XRANK_ON = os.environ.get('CNNQ_XRANK', 'auto') != '0'           # sharded config 2 exchanges INSIDE the single launch when D.xrank_exchange says so (auto: one GPU per rank, verified)
     _PT_FUSED = os.environ.get('CNNQ_PT_FUSED', '0') == '1'           # 1: config 1 in one launch (slower: see ops.minmax_qdq_per_tensor)
     _RESIDENT = os.environ.get('CNNQ_RESIDENT', '1') != '0'            # 0: never take a single-launch kernel
     _SINGLE_CODES = os.environ.get('CNNQ_SINGLE_CODES', '1') != '0'    # 0: codes / entropy requests take the chain
@@ -525,7 +525,7 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
             L.check(rc, 'cnnq_pc_minmax_qdq_auto')
         return y
     if exchanging and _xrank is not False and (_xrank is not None or _XRANK_ON) and not ((want_codes or want_entropy) and num_bits > 8):
-        # opt-in (CNNQ_XRANK=1, verified against the collective at first use): the exchange happens INSIDE the single
+        # CNNQ_XRANK=auto / 1 (D.xrank_mode; verified against the collective at first use): the exchange happens INSIDE the single
         # launch - x is read once (csrc/cnnq_xrank.hip.h); every rank takes this branch or none does.  Round 4: also with
         # the codes / the entropy of the codes / the parameters wanted (the ranks' code counts are summed afterwards)
         xr = _xrank if _xrank is not None else D.xrank_exchange(group)

@@ -75,3 +75,21 @@ def test_eight_ranks_on_one_gpu():
     elems = sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 64
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - elems) / elems < 1e-6
     assert d['box'].startswith('gpu-')
+
+
+def test_in_launch_exchange_falls_back_to_the_collective():
+    """CNNQ_XRANK=1 with two ranks on the one GPU: the job starts through the in-launch exchange.  Two processes on one GPU
+    cannot count on their launches running together at these sizes, so a wait for the peer may really expire - and with the
+    test hook one is reported for sure: every rank then drops to the collective together, the job is timed again and the line
+    is verified.  The default (auto) never starts the in-launch exchange between ranks that share a GPU."""
+    env = {'CNNQ_BENCH_BACKEND': 'gloo', 'CNNQ_XRANK': '1', 'CNNQ_XRANK_TIMEOUT_MS': '1000'}
+    d = run_bench('--gpus', '2', '--batch', '16', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', env=env)
+    assert d['verified'] is True and d['xrank'] is not None and d['xrank']['used'] == (not d['xrank']['fell_back'])
+    assert ('in-launch exchange' in d['config']['exchange']) == d['xrank']['used']
+    d = run_bench('--gpus', '2', '--batch', '16', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                  env=dict(env, CNNQ_XRANK_TEST_FAIL_AT='70'))
+    assert d['verified'] is True and d['xrank'] == {'used': False, 'healthy': False, 'fell_back': True}
+    assert 'in-launch exchange' not in d['config']['exchange']      # the records move by all_gather (or, with CNNQ_XRANK=1, by peer stores)
+    d = run_bench('--gpus', '2', '--batch', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                  env={'CNNQ_BENCH_BACKEND': 'gloo'})
+    assert d['verified'] is True and d['xrank'] is None and 'all_gather' in d['config']['exchange']
