@@ -336,9 +336,10 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
                               uint8_t* packed, void* stream);
 int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
 
-/* Config 2 in ONE launch and ONE read of x when the batch is sharded over `world` GPUs of one node (opt-in;
- * csrc/cnnq_xrank.hip.h; the default multi-GPU form is cnnq_pc_minmax_local_auto -> all_gather -> cnnq_pc_gathered_qdq,
- * which reads x twice).  The reference has no counterpart (its DataParallel replicas use their own sub-batch's range,
+/* Config 2 in ONE launch and ONE read of x when the batch is sharded over `world` GPUs of one node
+ * (csrc/cnnq_xrank.hip.h; the Python host uses it by default when every rank has its own GPU and it reproduced the collective
+ * form's bits at first use; the collective form is cnnq_pc_minmax_local_auto -> all_gather -> cnnq_pc_gathered_qdq, which
+ * reads x twice).  The reference has no counterpart (its DataParallel replicas use their own sub-batch's range,
  * inference_sim.py:196-200); this reproduces the single-GPU result of int_quantizer.py:409-451,557-603 on the global batch.
  *   windows  device array [world] of pointers: entry r is rank r's window (cnnq_xrank_alloc on rank r, opened here with
  *            cnnq_p2p_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels.
