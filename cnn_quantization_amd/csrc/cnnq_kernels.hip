@@ -562,7 +562,7 @@ int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int
                              void* ws, float* qp, float* mm, unsigned flags, void* stream) {
     if (!x || !y || !ws || !qp || num_bits < 1 || num_bits > 32 || ((uintptr_t)ws & 127)) return CNNQ_EINVAL;
     GPlan p;
-    const int rc = plan_group(N, C, HW, al16(x) && al16(y), &p);
+    const int rc = plan_group(N, C, HW, al16(x) && al16(y), &p, true, flat_lds_rows(0, false));
     if (rc) return rc;
     return launch_group(x, y, p, num_bits, positive ? 1 : 0, ws, qp, mm, flags, (hipStream_t)stream);
 }
@@ -662,7 +662,7 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
     xo.packed = packed;
     const bool al = al16(x) && (packed ? true : al16(y));
     GPlan gp;
-    const bool group_ok = gws && plan_group(N, C, HW, al, &gp, true, /*lds_rows=*/packed != nullptr) == 0 && gp.ws_bytes <= gws_bytes;
+    const bool group_ok = gws && plan_group(N, C, HW, al, &gp, true, flat_lds_rows(out, false)) == 0 && gp.ws_bytes <= gws_bytes;
     WPlan wp;
     const bool whole_ok = plan_whole(N, C, HW, al, &wp) == 0;
     hipStream_t st = (hipStream_t)stream;

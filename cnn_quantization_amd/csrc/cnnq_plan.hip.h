@@ -287,11 +287,9 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
             if (C * ((total + TPB * K - 1) / (TPB * K)) >= target) break;
     }
     while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
-    // round 4: eight more steps per tile in LDS (160 KB per workgroup).  Measured +1.5 % on the packed single launch with the
-    // counter meeting, nothing with the slot meeting, -1 % on the b512 step: a development knob (CNNQ_FLAT_KL = 8), or a caller
-    // that asks for it (nobody does)
-    static const int kl_knob = env_int("CNNQ_FLAT_KL", 0);
-    const int KL = (K == 32 && (kl_knob == 8 || (kl_knob < 0 && lds_rows))) ? 8 : 0;
+    // round 4: eight more steps per tile in LDS (160 KB per workgroup; flat_lds_rows() below: a development knob).  Measured +1.5 %
+    // on the packed single launch with the counter meeting, nothing with the slot meeting, -1 % on the b512 step
+    const int KL = (K == 32 && lds_rows) ? 8 : 0;
     const int64_t Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
     if (Gs > GRP_GS_MAX || Gs < 2) return CNNQ_ENOTSUP;
     const int64_t rows = (TPB * (K + KL)) / cpc + 3;             // samples a tile can touch, with slack
@@ -324,6 +322,13 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
 }
 
 int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, bool lds_rows);
+
+// CNNQ_FLAT_KL=8 (development knob): the flat tiles of the plain and the packed output take eight more steps in LDS
+// (k_mmq_flat<32, 0 / 2, false, 8>; the codes output and the cross-rank stage have no such instance)
+inline bool flat_lds_rows(int out, bool xrank) {
+    static const int kl_knob = env_int("CNNQ_FLAT_KL", 0);
+    return kl_knob == 8 && out != 1 && !xrank;
+}
 
 // plans are pure functions of their arguments (the development knobs are read once): the hot call asks for the same
 // handful of geometries over and over, so each host thread remembers the last 64
@@ -430,10 +435,8 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)
         if (p.K == 32 && p.KL == 8) {
-            if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_flat<32, 1, true, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr);
-            else if (xrank) hipLaunchKernelGGL((k_mmq_flat<32, 0, true, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr);
-            else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<32, 0, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
-            else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<32, 1, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
+            if (xrank || out == 1) return CNNQ_EINVAL;      // flat_lds_rows() never plans these
+            if (out == 0) hipLaunchKernelGGL((k_mmq_flat<32, 0, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
             else hipLaunchKernelGGL((k_mmq_flat<32, 2, false, 8>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);
         } else if (p.K == 32) LAUNCH_F(32); else if (p.K == 16) LAUNCH_F(16); else LAUNCH_F(8);
 #undef LAUNCH_F
