@@ -15,7 +15,8 @@
 // Nothing is pushed after something is waited for, so no rank can wait for a record whose producer waits for it: the
 // ranks need the co-residency the local exchange needs and nothing more.  Sequence numbers come from the host (one per
 // launch, the same on every rank: the ranks issue the same launches in the same order on ONE stream each; round 4: or from a
-// device word that a one-thread kernel advances behind every launch, which makes the launch capturable); two parities
+// device word that the launch's last unit - or a one-thread kernel behind the launch - advances, which makes the launch
+// capturable); two parities
 // suffice because a rank can start launch s + 2 only after it has received every rank's records of launch s + 1, which
 // a rank pushes only after its launch s has completed.  A wait gives up after `timeout` ticks of the 100 MHz clock:
 // the channel's outputs are then NaN and bit 2 of the status word is raised (a peer that never launches would otherwise
@@ -38,6 +39,9 @@ struct XRank {
     unsigned seq;              // 1, 2, 3, ... (host-side numbering: seq_dev == nullptr)
     const unsigned* seq_dev;   // device-side numbering (round 4): the launch's number is *seq_dev + 1; k_xr_bump advances the
                                // word behind the launch, so a captured graph replays with fresh numbers
+    unsigned* done;            // device-side numbering, in-kernel advance (round 4): seq_dev + 1, a count of finished units
+                               // (workgroups / groups) that is zero between launches; whoever finishes last zeroes it and
+                               // advances *seq_dev - no one-thread kernel behind the launch.  nullptr: k_xr_bump does it
     int cmax;                  // channels a window holds per (parity, rank)
     unsigned* status;          // |= XR_STATUS_PEER_TIMEOUT
     long long timeout;         // ticks of the 100 MHz clock
@@ -104,8 +108,20 @@ __device__ __forceinline__ bool xr_merge(const XRank& xr_in, int c, bool push, f
     return ok;
 }
 
-// device-side sequence numbers: one thread, enqueued behind every exchanging launch
+// device-side sequence numbers: one thread, enqueued behind an exchanging launch whose kernels cannot advance the word
+// themselves (the two-pass form, the counter meeting)
 __global__ void k_xr_bump(unsigned* seq_dev) { *seq_dev += 1u; }
+
+// in-kernel advance: called by ONE thread of every unit (a workgroup of k_mmq_whole, the last member out of a group of
+// k_mmq_group / k_mmq_flat) after the unit's last xr_merge; `units` of them per launch.  Every reader of *seq_dev belongs to
+// a unit that has not reported yet, so the word changes only after its last reader of this launch.
+__device__ __forceinline__ void xr_unit_done(const XRank& xr, unsigned units) {
+    if (!xr.done) return;
+    if (__hip_atomic_fetch_add(xr.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == units - 1u) {
+        __hip_atomic_store(xr.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(const_cast<unsigned*>(xr.seq_dev), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // the exchange alone, for a rank whose shard has no single-launch kernel: mm[2][C] local extrema in, folded extrema out
 __global__ void __launch_bounds__(TPB) k_xr_exchange(float* __restrict__ mm, const int C, const XRank xr) {

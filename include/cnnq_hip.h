@@ -357,9 +357,11 @@ int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int
                              float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
                              uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream);
 /* The same with DEVICE-side sequence numbers and the optional outputs of cnnq_pc_minmax_qdq_single (round 4):
- *   seq_dev   device word (zero at start, one per rank): the launch's number is *seq_dev + 1 and a one-thread kernel
- *             enqueued behind the launch advances the word - nothing about the call changes from launch to launch, so it
- *             can be captured into a HIP graph and replayed (every rank replays the same graph the same number of times).
+ *   seq_dev   TWO device words (zero at start, one pair per rank): the launch's number is seq_dev[0] + 1; seq_dev[1] counts
+ *             the launch's finished workgroups / groups, and whichever finishes last zeroes it and advances seq_dev[0]
+ *             (the two-pass form and the counter meeting enqueue a one-thread kernel behind the launch instead) - nothing
+ *             about the call changes from launch to launch, so it can be captured into a HIP graph and replayed (every rank
+ *             replays the same graph the same number of times).
  *   codes / hist_rep   as for cnnq_pc_minmax_qdq_single (num_bits <= 8): this rank's codes, and this rank's code counts in
  *             the replica tables - fold them with cnnq_hist_replicas_fold, sum the folded tables over the ranks, then
  *             cnnq_entropy gives the entropy of the global batch's codes (iq.py:586-587).
