@@ -322,7 +322,8 @@ __device__ __forceinline__ bool grp_depart_last(unsigned* top, int member, int G
 // arrival counted -> counter polled -> pairs read), 1-2 us each under a streaming load.  Here a member's {min, max} pair
 // IS its arrival: slots are zero at rest, a member stores the complement of its pair (NaNs canonical, so the complement is
 // never zero) with ONE 8-byte store and nobody waits for the acknowledgement; every member then polls the group's slots
-// (lane m watches members m and m + 256) until none is zero - one round trip after the last store landed.  Departures are
+// (wave 0 in k_mmq_flat, every wave its share in k_mmq_group; a few slots in flight per lane) until none is zero - one
+// round trip after the last store landed.  Departures are
 // counted (word [1] of the counter lines); whoever departs last zeroes the slots again: every launch leaves them zero.
 __device__ __forceinline__ unsigned long long slot_of(float mn, float mx) {
     const bool nn = (mn != mn) || (mx != mx);
