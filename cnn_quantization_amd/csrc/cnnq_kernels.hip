@@ -48,7 +48,7 @@
 
 extern "C" {
 
-const char* cnnq_version(void) { return "cnnq-hip 0.3 gfx950"; }
+const char* cnnq_version(void) { return "cnnq-hip 0.4 gfx950"; }
 
 int cnnq_pc_groups(int64_t N, int64_t C, int64_t HW, int aligned16) {
     Variant v;
