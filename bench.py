@@ -314,12 +314,12 @@ def main():
                 run_step(ops, layers, group)
         torch.cuda.current_stream().wait_stream(side)
         step = graph.replay
-    def timed_run():
+    def region(warm, steps):
         # every rank reaches both barriers whatever happens in between: a wait of the in-launch exchange that expired
         # surfaces as CnnqError at that exchange's next host check, on one rank first
         ok = True
         try:
-            for _ in range(args.warmup):
+            for _ in range(warm):
                 step()
         except _lib.CnnqError:
             ok = False
@@ -327,28 +327,49 @@ def main():
         t0 = time.perf_counter()
         if ok:
             try:
-                for _ in range(args.steps):
+                for _ in range(steps):
                     step()
             except _lib.CnnqError:
                 ok = False
         barrier()
         return time.perf_counter() - t0, ok
 
-    dt, ok = timed_run()
+    def agreed(flag, secs=()):
+        """group-wide AND of a flag and MAX of some times: every rank takes the same decision"""
+        if world == 1:
+            return flag, list(secs)
+        t = torch.tensor([0. if flag else 1.] + list(secs), device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()) == 0., [float(v) for v in t[1:].tolist()]
+
     xrank_info = None
-    if (world > 1 or args.force_exchange) and D.xrank_exchange(group) is not None:
-        # CNNQ_XRANK=auto / 1 and verified at first use: the job ran through the in-launch exchange.  If a peer wait expired
-        # anywhere, every rank drops to the collective together and the job is timed again
-        ok = ok and bool(D.xrank_exchange(group).healthy())
-        if world > 1:
-            v = torch.tensor([1 if ok else 0], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
-            dist.all_reduce(v, op=dist.ReduceOp.MIN)
-            ok = bool(int(v.item()))
-        xrank_info = {'used': ok, 'healthy': ok, 'fell_back': not ok}
+    exchanging = world > 1 or args.force_exchange
+    if exchanging and D.xrank_mode() == 'auto' and D.xrank_exchange(group) is not None:
+        # untimed, before the warm-up: which exchange is faster on THIS machine?  Two steps through the in-launch exchange
+        # (verified at first use, just now), two through the collective; the slower one is not used for the timed steps
+        tx, okx = region(1, 2)
+        okx = okx and bool(D.xrank_exchange(group).healthy())
+        ops._XRANK_ON = False
+        ops.release_plans()
+        tc, okc = region(1, 2)
+        ops._XRANK_ON = True
+        ops.release_plans()
+        okx, (tx, tc) = agreed(okx and okc, (tx, tc))
+        xrank_info = {'probe_ms_in_launch': tx / 2 * 1e3, 'probe_ms_collective': tc / 2 * 1e3}
+        if not okx or tc < tx:
+            D.disable_xrank(group)
+    dt, ok = region(args.warmup, args.steps)
+    if exchanging and D.xrank_exchange(group) is not None:
+        # the job ran through the in-launch exchange (CNNQ_XRANK=auto / 1).  If a peer wait expired anywhere, every rank
+        # drops to the collective together and the job is timed again
+        ok, _ = agreed(ok and bool(D.xrank_exchange(group).healthy()))
+        xrank_info = dict(xrank_info or {}, used=ok, healthy=ok, fell_back=not ok)
         if not ok:
             D.disable_xrank(group)
             ops.release_plans()
-            dt, ok = timed_run()
+            dt, ok = region(args.warmup, args.steps)
+    elif xrank_info is not None:
+        xrank_info.update(used=False, healthy=True, fell_back=False)      # probed, and the collective was faster (or a probe failed)
     assert ok, 'the timed region failed outside the in-launch exchange'
     total_elems = elems
     per_rank_ms = [dt * 1e3 / args.steps]

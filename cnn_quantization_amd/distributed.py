@@ -329,13 +329,14 @@ def xrank_exchange(group=None):
     """The process-wide XRankExchange of `group` when CNNQ_XRANK allows it (xrank_mode) and it verified against the collective
     path on every rank; else None (the collective).  World size 1 only with CNNQ_XRANK=1 under CNNQ_FORCE_EXCHANGE=1 (timing
     the protocol on a 1-GPU box)."""
+    import os
     mode = xrank_mode()
     if mode == '0' or not (dist.is_available() and dist.is_initialized()):
         return None
     if world_size(group) == 1 and not (mode == '1' and forced_exchange()):
         return None
-    if mode == 'auto' and dist.get_backend(group) != 'nccl':
-        return None
+    if mode == 'auto' and dist.get_backend(group) != 'nccl' and os.environ.get('CNNQ_XRANK_SHARED_OK', '0') != '1':
+        return None                                       # (CNNQ_XRANK_SHARED_OK=1: tests of the auto path on a one-GPU rig)
     key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
     if key not in _XRANK:
         ex = XRankExchange(group)                       # collective; never raises for a local failure

@@ -93,3 +93,11 @@ def test_in_launch_exchange_falls_back_to_the_collective():
     d = run_bench('--gpus', '2', '--batch', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
                   env={'CNNQ_BENCH_BACKEND': 'gloo'})
     assert d['verified'] is True and d['xrank'] is None and 'all_gather' in d['config']['exchange']
+    # auto, with the one-GPU rig declared eligible: both exchanges are probed (untimed), the timed steps take the faster one
+    # that stayed healthy - whichever that is here, the line is verified and says what was measured
+    d = run_bench('--gpus', '2', '--batch', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                  env={'CNNQ_BENCH_BACKEND': 'gloo', 'CNNQ_XRANK_SHARED_OK': '1', 'CNNQ_XRANK_TIMEOUT_MS': '1000'})
+    assert d['verified'] is True and d['xrank'] is not None
+    assert d['xrank']['probe_ms_collective'] > 0 and d['xrank']['probe_ms_in_launch'] > 0
+    assert ('in-launch exchange' in d['config']['exchange']) == d['xrank']['used']
+
