@@ -98,22 +98,23 @@ def test_exchange_on_two_streams_at_once(ops):
         assert st & ~ops.GROUP_WAIT_EXPIRED == 0
 
 
-def test_two_processes_share_the_gpu():
-    """Beside another PROCESS at bench size: two bench.py jobs at batch 64 on the one GPU at the same
-    time.  Kernels of two processes need not run together, so a group's members may be kept off the CUs by the other process's
+@pytest.mark.parametrize('batch', [64, 512])
+def test_two_processes_share_the_gpu(batch):
+    """Beside another PROCESS at bench size: two bench.py jobs (batch 64, and the full batch 512: 45 GB
+    each) on the one GPU at the same time.  Kernels of two processes need not run together, so a group's members may be kept off the CUs by the other process's
     workgroups: waits may expire (bit 0 of the status word, reported in the line and recorded), the bits may not change."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--batch', '64', '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--batch', str(batch), '--steps', '6', '--warmup', '2', '--no-cpu-baseline',
            '--no-other-configs']
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root, env=env) for _ in range(2)]
     outs = [p.communicate(timeout=900) for p in procs]
     for i, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, se[-2000:]
         d = json.loads([l for l in so.splitlines() if l.strip()][-1])
-        record('two processes at batch 64, process %d' % i, d['group_status'])
+        record('two processes at batch %d, process %d' % (batch, i), d['group_status'])
         assert d['verified'] is True
         assert d['group_status'] & ~1 == 0          # nothing but "a wait expired" may ever be raised here
