@@ -672,12 +672,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     if (use_slots) {
         if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
         __syncthreads();
-        if (sh_timed_out) {    // the last member out re-arms the group's slots: every other member has read them
+        if (sh_timed_out)      // the last member out re-arms the group's slots: every other member has read them
             for (int m = tid; m < Gs * kk; m += TPB) __hip_atomic_store(slots + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if constexpr (XR) {
-                if (tid == 0) xr_unit_done(xr, gridDim.x / (unsigned)Gs);      // ... and done with every cross-rank merge
-            }
-        }
     } else if (tid == 0) grp_depart(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs);
 #endif
 #ifdef GRP_TRACE
@@ -1062,12 +1058,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     if (use_slots) {
         if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
         __syncthreads();
-        if (sh_timed_out) {    // the last member out re-arms the group's slots: every other member has read them
+        if (sh_timed_out)      // the last member out re-arms the group's slots: every other member has read them
             for (int m = tid; m < g.Gs; m += TPB) __hip_atomic_store(slots + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if constexpr (XR) {
-                if (tid == 0) xr_unit_done(xr, (unsigned)g.C);      // ... and done with every cross-rank merge
-            }
-        }
     } else if (tid == 0) grp_depart(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs);
 #endif
 #ifdef GRP_TRACE

@@ -687,7 +687,7 @@ int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64
     const size_t bytes = xr_window_bytes(world, cmax);
     hipError_t e = hipExtMallocWithFlags(window, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) return (int)e;
-    e = hipMemset(*window, 0, bytes);                  // sequence numbers start at 1
+    e = hipMemset(*window, 0, bytes);                  // an empty slot is zero
     hipIpcMemHandle_t h;
     if (e == hipSuccess) e = hipIpcGetMemHandle(&h, *window);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -717,7 +717,6 @@ static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t 
     xr.world = world;
     xr.seq = seq;
     xr.seq_dev = seq_dev;
-    xr.done = seq_dev ? seq_dev + 1 : nullptr;
     xr.cmax = cmax;
     xr.status = status;
     xr.timeout = timeout_ticks;
@@ -733,13 +732,10 @@ static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t 
     const bool whole_ok = plan_whole(N, C, HW, al, &wp) == 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    bool bumped = seq_dev != nullptr;                      // the single-launch kernels advance the sequence word themselves
     if (whole_ok && !(group_ok && wp.wgs < RES_MIN_WGS)) rc = launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, out, xo, 0u, &xr);
-    else if (group_ok) rc = launch_group(x, y, gp, num_bits, positive ? 1 : 0, gws, qp, mm, 0u, st, out, xo, &xr, &bumped);
+    else if (group_ok) rc = launch_group(x, y, gp, num_bits, positive ? 1 : 0, gws, qp, mm, 0u, st, out, xo, &xr);
     else if (whole_ok) rc = launch_whole(x, y, wp, num_bits, positive ? 1 : 0, qp, mm, st, out, xo, 0u, &xr);
     else {
-        bumped = false;
-        xr.done = nullptr;
         // no single-launch kernel for this rank's shard (the ranks' shards may differ by a sample, and so may their plans):
         // the same window protocol around two passes - local extrema, one thread per channel pushes / waits / folds, Q/DQ
         // with the folded extrema as the only "gathered" record (codes / histogram: the parameter kernel + the fused Q/DQ,
@@ -756,11 +752,10 @@ static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t 
         }
     }
     if (rc) return rc;
-    if (seq_dev && !bumped) {
-        hipLaunchKernelGGL(k_xr_bump, dim3(1), dim3(1), 0, st, seq_dev);
-        rc = launch_status();
-    }
-    return rc;
+    // behind the launch: the slots of its parity back to zero (every reader of this rank is done), the device-side launch
+    // number advanced
+    hipLaunchKernelGGL(k_xr_finish, dim3(1), dim3(1024), 0, st, windows, rank, world, cmax, (int)C, seq, seq_dev);
+    return launch_status();
 }
 
 int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,

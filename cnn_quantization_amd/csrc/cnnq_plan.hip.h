@@ -220,7 +220,7 @@ int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int pos
     flags |= mmq_env_flags();
     const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: the cross-rank stage of cnnq_xrank.hip.h (y, or y + codes / histogram)
     if (xrank && out == 2) return CNNQ_ENOTSUP;
-    const XRank xr = xrank ? *xrp : XRank{};          // xr.done: every workgroup reports, the last one advances the sequence word
+    const XRank xr = xrank ? *xrp : XRank{};
 #define LAUNCH_W(A, T, K)                                                                                                     \
     do {                                                                                                                      \
         if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
@@ -398,12 +398,11 @@ int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* 
 }
 
 int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int positive, void* ws, float* qp, float* mm,
-                 unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}, const XRank* xrp = nullptr,
-                 bool* bumped_in_kernel = nullptr) {
+                 unsigned flags, hipStream_t st, int out = 0, const XOut& xo = XOut{}, const XRank* xrp = nullptr) {
     flags |= mmq_env_flags();
     const bool xrank = xrp && xrp->world > 0;
     if (xrank && out == 2) return CNNQ_ENOTSUP;
-    XRank xr = xrank ? *xrp : XRank{};
+    const XRank xr = xrank ? *xrp : XRank{};
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
@@ -415,10 +414,6 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     // b512 / b64 steps with y to write; CNNQ_MEET_SLOTS = 0: the counter meeting (A/B)
     static const int meet_slots = env_int("CNNQ_MEET_SLOTS", 1);
     if (meet_slots && (size_t)p.ngroups * p.gstride * 8 <= GRP_WS_SLOT_BYTES) flags |= MMQ_FLAG_SLOTS;
-    // the in-kernel advance of the cross-rank sequence word rides on the slot meeting's "last member out"; with the counter
-    // meeting the caller's one-thread kernel does it (bumped_in_kernel tells)
-    if (!(flags & MMQ_FLAG_SLOTS)) xr.done = nullptr;
-    if (bumped_in_kernel) *bumped_in_kernel = xrank && xr.done != nullptr;
     if (p.flat) {
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
         static const int pk_narrow = env_int("CNNQ_PK_NARROW", 0);          // development knob: the 2-byte stores of round 3

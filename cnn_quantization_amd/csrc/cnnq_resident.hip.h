@@ -210,9 +210,6 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, 1 << (num_bits < 8 ? num_bits : 8), zp, nzp);
     }
-    if constexpr (XR) {
-        if (tid == 0) xr_unit_done(xr, gridDim.x);      // behind the barrier that followed this workgroup's merges
-    }
 }
 
 }  // namespace

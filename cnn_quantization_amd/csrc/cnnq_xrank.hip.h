@@ -5,43 +5,36 @@
 // The single-launch kernels (k_mmq_whole / k_mmq_group / k_mmq_flat) hold their tile of x in registers between the
 // statistics and the Q/DQ.  With the batch sharded, a channel's extrema are the fold of the W ranks' extrema; the one
 // thread that finishes a channel's LOCAL extrema
-//   push   stores {min, max}, drains the stores, and then stores the launch's sequence number into the record
+//   push   stores the COMPLEMENT of its {min, max} pair (NaNs canonical: never zero) into the slot
 //          [parity][own rank][channel] of EVERY rank's window - fine-grained device memory exported with hipIpc and mapped
 //          by all peers, the windows of cnnq_p2p.hip.h's kind (only the workgroup that is member 0 of the channel's
-//          group pushes; every member knows the same local extrema);
-//   wait   polls the W records [parity][0..W)[channel] of its OWN window until they carry the sequence number,
-//          folds them in rank order (NaN-propagating min / max: exact, the same bits on every rank and as on one GPU
-//          holding the whole batch), and goes on to scale / zero point and the Q/DQ out of the registers.
-// Nothing is pushed after something is waited for, so no rank can wait for a record whose producer waits for it: the
-// ranks need the co-residency the local exchange needs and nothing more.  Sequence numbers come from the host (one per
-// launch, the same on every rank: the ranks issue the same launches in the same order on ONE stream each; round 4: or from a
-// device word that the launch's last unit - or a one-thread kernel behind the launch - advances, which makes the launch
-// capturable); two parities
-// suffice because a rank can start launch s + 2 only after it has received every rank's records of launch s + 1, which
-// a rank pushes only after its launch s has completed.  A wait gives up after `timeout` ticks of the 100 MHz clock:
-// the channel's outputs are then NaN and bit 2 of the status word is raised (a peer that never launches would otherwise
-// hang the device); once raised, later waits give up at once.  The host checks the word at its next synchronisation
-// point and falls back to the collective.
+//          group pushes; every member knows the same local extrema).  One 8-byte store per destination and nothing to
+//          wait for: the pair IS the signal (round 4, as in the local slot meeting; round 3 sent pair -> drain -> sequence
+//          number, one more remote round trip per launch);
+//   wait   polls the W slots [parity][0..W)[channel] of its OWN window until none is zero, folds them in rank order
+//          (NaN-propagating min / max: exact, the same bits on every rank and as on one GPU holding the whole batch), and
+//          goes on to scale / zero point and the Q/DQ out of the registers.
+// Nothing is pushed after something is waited for, so no rank can wait for a slot whose producer waits for it: the
+// ranks need the co-residency the local exchange needs and nothing more.  The slots of a launch's parity are zeroed by a
+// small kernel enqueued BEHIND the launch (k_xr_finish: every reader of this rank is done by then), which also advances
+// the device-side launch number.  Two parities suffice: a rank can push for launch s + 2 only after it completed launch
+// s + 1, for which it needed this rank's push of launch s + 1, which this rank's launch s + 1 issued after its k_xr_finish
+// of launch s had zeroed the slots.  The parity comes from the launch number: the host's (one per launch, the same on every
+// rank: the ranks issue the same launches in the same order on ONE stream each) or a device word (the launch is then
+// capturable).  A wait gives up after `timeout` ticks of the 100 MHz clock: the channel's outputs are then NaN and bit 2 of
+// the status word is raised (a peer that never launches would otherwise hang the device); once raised, later waits give up
+// at once.  The host checks the word (periodically, without synchronising) and falls back to the collective.
 #pragma once
 #include "cnnq_common.hip.h"
 
 namespace {
 
-struct XRec {
-    unsigned long long pair;   // {min, max} as two fp32
-    unsigned seq;              // written last, after the pair has been acknowledged
-    unsigned pad;
-};
-
 struct XRank {
     void* const* windows;      // [world] device pointers, the own window at [rank]; world == 0: no cross-rank stage
     int rank, world;
     unsigned seq;              // 1, 2, 3, ... (host-side numbering: seq_dev == nullptr)
-    const unsigned* seq_dev;   // device-side numbering (round 4): the launch's number is *seq_dev + 1; k_xr_bump advances the
+    const unsigned* seq_dev;   // device-side numbering (round 4): the launch's number is *seq_dev + 1; k_xr_finish advances the
                                // word behind the launch, so a captured graph replays with fresh numbers
-    unsigned* done;            // device-side numbering, in-kernel advance (round 4): seq_dev + 1, a count of finished units
-                               // (workgroups / groups) that is zero between launches; whoever finishes last zeroes it and
-                               // advances *seq_dev - no one-thread kernel behind the launch.  nullptr: k_xr_bump does it
     int cmax;                  // channels a window holds per (parity, rank)
     unsigned* status;          // |= XR_STATUS_PEER_TIMEOUT
     long long timeout;         // ticks of the 100 MHz clock
@@ -49,33 +42,31 @@ struct XRank {
 
 constexpr unsigned XR_STATUS_PEER_TIMEOUT = 4u;
 
-__host__ __device__ inline size_t xr_window_bytes(int world, int cmax) { return (size_t)2 * world * cmax * sizeof(XRec); }
+__host__ __device__ inline size_t xr_window_bytes(int world, int cmax) { return (size_t)2 * world * cmax * sizeof(unsigned long long); }
 
-__device__ __forceinline__ unsigned long long xr_pack(float mn, float mx) {
-    return (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
+// the slot's content: the complement of {min, max} as two fp32 (NaNs canonical, so a published slot is never zero)
+__device__ __forceinline__ unsigned long long xr_slot_of(float mn, float mx) {
+    const bool nn = (mn != mn) || (mx != mx);
+    const float a = nn ? NAN : mn, b = nn ? NAN : mx;
+    return ~((unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32));
 }
 
-__device__ __forceinline__ XRec* xr_rec(void* win, const XRank& xr, int r, int c) {
-    return reinterpret_cast<XRec*>(win) + ((size_t)((int)(xr.seq & 1u) * xr.world + r) * (size_t)xr.cmax + (size_t)c);
+__device__ __forceinline__ unsigned long long* xr_slot(void* win, unsigned parity, int world, int cmax, int r, int c) {
+    return reinterpret_cast<unsigned long long*>(win) + ((size_t)((int)parity * world + r) * (size_t)cmax + (size_t)c);
 }
 
 // One thread per channel: push the local extrema (if `push`), then wait for every rank's and fold them.  Returns false
 // when a wait expired (mn / mx are NaN then and the status word is raised).
-__device__ __forceinline__ bool xr_merge(const XRank& xr_in, int c, bool push, float& mn, float& mx) {
-    XRank xr = xr_in;
-    // the word is only written by k_xr_bump, between launches of one stream: every thread of a launch reads the same value
-    if (xr.seq_dev) xr.seq = __hip_atomic_load(xr.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+__device__ __forceinline__ bool xr_merge(const XRank& xr, int c, bool push, float& mn, float& mx) {
+    // the word is only written by k_xr_finish, between launches of one stream: every thread of a launch reads the same value
+    const unsigned seq = xr.seq_dev ? __hip_atomic_load(xr.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : xr.seq;
+    const unsigned par = seq & 1u;
     if (push) {
-        const unsigned long long pr = xr_pack(mn, mx);
-        // The windows are uncached (fine-grained) memory: every access goes to the owner's memory, so ordering is a
-        // matter of ISSUE order - no release / acquire fences, which at system scope write back and invalidate the
-        // whole L2 (measured: the b512 forward 2.3 ms slower).  All pairs first, drained (the stores have been
-        // acknowledged by their destinations), then the sequence numbers.
+        // The windows are uncached (fine-grained) memory: every access goes to the owner's memory - no release / acquire
+        // fences, which at system scope write back and invalidate the whole L2 (measured: the b512 forward 2.3 ms slower)
+        const unsigned long long v = xr_slot_of(mn, mx);
         for (int r = 0; r < xr.world; ++r)
-            __hip_atomic_store(&xr_rec(xr.windows[r], xr, xr.rank, c)->pair, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int r = 0; r < xr.world; ++r)
-            __hip_atomic_store(&xr_rec(xr.windows[r], xr, xr.rank, c)->seq, xr.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(xr_slot(xr.windows[r], par, xr.world, xr.cmax, xr.rank, c), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     void* own = xr.windows[xr.rank];
     float a = INFINITY, b = -INFINITY;
@@ -83,17 +74,16 @@ __device__ __forceinline__ bool xr_merge(const XRank& xr_in, int c, bool push, f
     bool ok = !(__hip_atomic_load(xr.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & XR_STATUS_PEER_TIMEOUT);
     const long long t0 = wall_clock64();
     for (int r = 0; r < xr.world && ok; ++r) {
-        const XRec* s = xr_rec(own, xr, r, c);
+        const unsigned long long* s = xr_slot(own, par, xr.world, xr.cmax, r, c);
+        unsigned long long v;
         int polls = 0;
-        while (__hip_atomic_load(&s->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xr.seq) {
+        while ((v = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0ull) {
             if ((++polls & 31) == 0 && wall_clock64() - t0 > xr.timeout) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         if (ok) {
-            // issued after the sequence number has been SEEN (the loop above consumed its value): the pair was in
-            // the window before the number was
-            const unsigned long long pr = __hip_atomic_load(&s->pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const float p = __uint_as_float((unsigned)(pr & 0xffffffffull)), q = __uint_as_float((unsigned)(pr >> 32));
+            v = ~v;
+            const float p = __uint_as_float((unsigned)(v & 0xffffffffull)), q = __uint_as_float((unsigned)(v >> 32));
             a = pmin(a, p);
             b = pmax(b, q);
         }
@@ -108,19 +98,18 @@ __device__ __forceinline__ bool xr_merge(const XRank& xr_in, int c, bool push, f
     return ok;
 }
 
-// device-side sequence numbers: one thread, enqueued behind an exchanging launch whose kernels cannot advance the word
-// themselves (the two-pass form, the counter meeting)
-__global__ void k_xr_bump(unsigned* seq_dev) { *seq_dev += 1u; }
-
-// in-kernel advance: called by ONE thread of every unit (a workgroup of k_mmq_whole, the last member out of a group of
-// k_mmq_group / k_mmq_flat) after the unit's last xr_merge; `units` of them per launch.  Every reader of *seq_dev belongs to
-// a unit that has not reported yet, so the word changes only after its last reader of this launch.
-__device__ __forceinline__ void xr_unit_done(const XRank& xr, unsigned units) {
-    if (!xr.done) return;
-    if (__hip_atomic_fetch_add(xr.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == units - 1u) {
-        __hip_atomic_store(xr.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(const_cast<unsigned*>(xr.seq_dev), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// enqueued behind every exchanging launch (ONE workgroup): every reader of this rank is done, so the slots of the
+// launch's parity are zeroed for the launch after next, and the device-side launch number (if any) advances
+__global__ void __launch_bounds__(1024) k_xr_finish(void* const* windows, const int rank, const int world, const int cmax, const int C,
+                                                    const unsigned seq, unsigned* seq_dev) {
+    void* own = windows[rank];
+    const unsigned par = (seq_dev ? *seq_dev + 1u : seq) & 1u;
+    __syncthreads();                                   // everybody has read the word before thread 0 advances it
+    for (int i = (int)threadIdx.x; i < world * C; i += (int)blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        __hip_atomic_store(xr_slot(own, par, world, cmax, r, c), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (seq_dev && threadIdx.x == 0) *seq_dev += 1u;
 }
 
 // the exchange alone, for a rank whose shard has no single-launch kernel: mm[2][C] local extrema in, folded extrema out

@@ -277,7 +277,7 @@ class XRankExchange(P2PExchange):
         if self.seq_dev is None:
             if capturing:
                 raise self.L.CnnqError('XRankExchange: run one launch eagerly before capturing (the sequence word is allocated at first use)')
-            self.seq_dev = torch.zeros(2, dtype=torch.int32, device=self.device)      # [launch number, finished units of the launch in flight]
+            self.seq_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq += 1                                   # launches ENQUEUED here (a replayed graph advances the device word, not this)
         self.calls += 1
         if not capturing and self.calls % self.CHECK_EVERY == 0 and not self.healthy_so_far():      # periodic host check (no synchronisation)

@@ -342,7 +342,10 @@ int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
  * reads x twice).  The reference has no counterpart (its DataParallel replicas use their own sub-batch's range,
  * inference_sim.py:196-200); this reproduces the single-GPU result of int_quantizer.py:409-451,557-603 on the global batch.
  *   windows  device array [world] of pointers: entry r is rank r's window (cnnq_xrank_alloc on rank r, opened here with
- *            cnnq_p2p_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels.
+ *            cnnq_p2p_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels: one 8-byte
+ *            slot per (parity, source rank, channel), zero when empty - a rank stores the complement of its {min, max}
+ *            pair into every window and polls its own (round 4: the pair is the signal; a small kernel behind the launch
+ *            zeroes the launch's parity again).
  *   seq      1, 2, 3, ...: the same on every rank for the same launch; the ranks issue the same launches in the same
  *            order, each on ONE stream.  Not capturable into a graph (the number is a kernel argument; see _xrank_dev).
  *   status   device word: bit 2 is raised when a wait for a peer's record expired after timeout_ticks of the 100 MHz
@@ -357,11 +360,9 @@ int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int
                              float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
                              uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream);
 /* The same with DEVICE-side sequence numbers and the optional outputs of cnnq_pc_minmax_qdq_single (round 4):
- *   seq_dev   TWO device words (zero at start, one pair per rank): the launch's number is seq_dev[0] + 1; seq_dev[1] counts
- *             the launch's finished workgroups / groups, and whichever finishes last zeroes it and advances seq_dev[0]
- *             (the two-pass form and the counter meeting enqueue a one-thread kernel behind the launch instead) - nothing
- *             about the call changes from launch to launch, so it can be captured into a HIP graph and replayed (every rank
- *             replays the same graph the same number of times).
+ *   seq_dev   device word (zero at start, one per rank): the launch's number is *seq_dev + 1 and the small kernel
+ *             enqueued behind the launch advances the word - nothing about the call changes from launch to launch, so it
+ *             can be captured into a HIP graph and replayed (every rank replays the same graph the same number of times).
  *   codes / hist_rep   as for cnnq_pc_minmax_qdq_single (num_bits <= 8): this rank's codes, and this rank's code counts in
  *             the replica tables - fold them with cnnq_hist_replicas_fold, sum the folded tables over the ranks, then
  *             cnnq_entropy gives the entropy of the global batch's codes (iq.py:586-587).

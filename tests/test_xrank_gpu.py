@@ -187,7 +187,7 @@ def _graph(rank, world, port, tmp):
         with torch.cuda.stream(side):
             for x, y in zip(xs, ys):                     # eagerly once on this stream: workspaces and the sequence word exist
                 ops.act_qdq_per_channel(x, 4, out=y)
-            seq_before = int(ex.seq_dev[0].item())
+            seq_before = int(ex.seq_dev.item())
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 for x, y in zip(xs, ys):
@@ -199,7 +199,7 @@ def _graph(rank, world, port, tmp):
                 side.synchronize()
                 replays += 1
                 same = same and all(bool(torch.equal(y, r)) for y, r in zip(ys, refs))
-            same = same and int(ex.seq_dev[0].item()) == seq_before + 3 * len(xs)     # the device word advanced once per replayed launch
+            same = same and int(ex.seq_dev.item()) == seq_before + 3 * len(xs)     # the device word advanced once per replayed launch
             same = same and ex.healthy()
         torch.cuda.current_stream().wait_stream(side)
     torch.save({'ok': ok, 'same': same, 'replays': replays}, os.path.join(tmp, 'graph.pt'))
