@@ -358,6 +358,8 @@ def disable_xrank(group=None):
     if ex is not None:
         ex.close()
     _XRANK[key] = None
+    from . import ops
+    ops.release_plans()                                  # the hot call's cached plans hold the exchange
 
 
 def p2p_exchange(group=None):

@@ -528,8 +528,29 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         # CNNQ_XRANK=auto / 1 (D.xrank_mode; verified against the collective at first use): the exchange happens INSIDE the single
         # launch - x is read once (csrc/cnnq_xrank.hip.h); every rank takes this branch or none does.  Round 4: also with
         # the codes / the entropy of the codes / the parameters wanted (the ranks' code counts are summed afterwards)
-        xr = _xrank if _xrank is not None else D.xrank_exchange(group)
         st = _raw_stream(x.device.index)
+        if _xrank is None and resident and not (want_codes or want_entropy or want_parts):
+            # the sharded hot call: everything that does not change from call to call is looked up once (the exchange of the
+            # group, the workspaces); D.disable_xrank / release_plans() drop the plans
+            key = ('xr', id(group), x.device.index, st, N, C, HW)
+            plan = _XPLAN.get(key)
+            if plan is None and not torch.cuda.is_current_stream_capturing():    # (a capture-time scratch buffer is never cached)
+                xr = D.xrank_exchange(group)
+                plan = False
+                if xr is not None and xr.fits(C):
+                    wplan = _WS_BYTES.get((N, C, HW))
+                    nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+                    if nbytes == 0:
+                        L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+                    plan = (xr, group, _scratch(x, 'cfg2', nbytes, st), _group_workspace(x, st))
+                _XPLAN[key] = plan
+            if plan:
+                y = _out_like(x, out)
+                plan[0].minmax_qdq(x, y, N, C, HW, num_bits, positive, plan[2].data_ptr(), plan[3], GROUP_WS_BYTES, st)
+                return y
+            xr = None if plan is False else D.xrank_exchange(group)
+        else:
+            xr = _xrank if _xrank is not None else D.xrank_exchange(group)
         hist_rep = _hist_replicas(x, st) if (want_entropy and xr is not None) else None
         if xr is not None and xr.fits(C) and not (want_entropy and hist_rep is None):
             wplan = _WS_BYTES.get((N, C, HW))
