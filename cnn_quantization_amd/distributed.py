@@ -232,6 +232,8 @@ class P2PExchange:
         for cache in (_P2P, _XRANK):                     # a closed exchange must not be handed out again
             for k in [k for k, v in cache.items() if v is self]:
                 del cache[k]
+        from . import ops
+        ops.release_plans()                              # ... nor stay in a cached plan of the hot call
 
 
 class XRankExchange(P2PExchange):
