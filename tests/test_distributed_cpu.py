@@ -82,6 +82,13 @@ def _worker(rank, world, port, tmp):
     m = D.merge_row_minmax(st, rows, True, None)
     assert m.shape == (7, 10)
     assert torch.equal(m[0], per_sample_min) and torch.equal(m[1], per_sample_max)
+    # the exchange selection (round 4): auto never starts the in-launch exchange on a backend whose ranks may share a GPU,
+    # '0' never starts it at all; both without touching a device
+    for mode in ('auto', '0', 'bogus'):
+        os.environ['CNNQ_XRANK'] = mode
+        assert D.xrank_mode() == ('0' if mode == '0' else 'auto')
+        assert D.xrank_exchange(None) is None
+    os.environ.pop('CNNQ_XRANK')
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, 'ok%d' % rank), 'w').write('ok')
@@ -104,3 +111,16 @@ def test_shard_batch_partitions():
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
     assert D.world_size() == 1 and D.rank() == 0
+
+
+
+def test_xrank_mode_without_a_process_group(monkeypatch):
+    """No process group: every mode answers None (the collective / single-GPU paths), nothing is imported or allocated."""
+    sys.path.insert(0, ROOT)
+    from cnn_quantization_amd import distributed as D
+    for mode, want in (('auto', 'auto'), ('1', '1'), ('0', '0'), ('', 'auto')):
+        monkeypatch.setenv('CNNQ_XRANK', mode)
+        assert D.xrank_mode() == want
+        assert D.xrank_exchange(None) is None
+    monkeypatch.delenv('CNNQ_XRANK')
+    assert D.xrank_mode() == 'auto'
