@@ -53,3 +53,38 @@ extern "C" int scat_alloc(size_t bytes, size_t chunk, int order, unsigned seed, 
     *out = va;
     return 0;
 }
+
+// The SAME physical chunks mapped several times: `nviews` virtual ranges over one set of `chunk`-byte allocations, view v in
+// the order given by perm[v * nch + i] (physical chunk of virtual chunk i).  out[v] receives the views' addresses.
+extern "C" int scat_views(size_t bytes, size_t chunk, int nviews, const uint32_t* perm, void** out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    const size_t nch = (bytes + chunk - 1) / chunk;
+    std::vector<hipMemGenericAllocationHandle_t> h(nch);
+    for (size_t i = 0; i < nch; ++i) {
+        const hipError_t e = hipMemCreate(&h[i], chunk, &prop, 0);
+        if (e != hipSuccess) return 1000 + (int)e;
+    }
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = dev;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (int v = 0; v < nviews; ++v) {
+        void* va = nullptr;
+        hipError_t e = hipMemAddressReserve(&va, nch * chunk, chunk, nullptr, 0);
+        if (e != hipSuccess) return 4000 + (int)e;
+        for (size_t i = 0; i < nch; ++i) {
+            e = hipMemMap(reinterpret_cast<char*>(va) + i * chunk, chunk, 0, h[perm[(size_t)v * nch + i]], 0);
+            if (e != hipSuccess) return 2000 + (int)e;
+        }
+        e = hipMemSetAccess(va, nch * chunk, &acc, 1);
+        if (e != hipSuccess) return 3000 + (int)e;
+        out[v] = va;
+    }
+    for (size_t i = 0; i < nch; ++i) (void)hipMemRelease(h[i]);
+    return 0;
+}
