@@ -87,6 +87,9 @@ SIGNATURES = {
     'cnnq_entropy_replicas': (_I, [_P, _P, _P]),
     'cnnq_pc_aciq_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_aciq_qdq': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P]),
+    'cnnq_pc_aciq_qdq_single': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P,
+                                     ctypes.c_uint32, _P]),
+    'cnnq_pc_aciq_qdq_auto': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),
     'cnnq_pc_bcorr_sums': (_I, [_P, _P, _L, _L, _L, _I, _P, _P]),
     'cnnq_pc_qdq_bcorr_sums': (_I, [_P, _L, _L, _L, _P, _I, _P, _P]),

@@ -1,0 +1,633 @@
+// cnnq_aciq.hip.h - the ACIQ (Laplace clipping, optional bit allocation) path of config 3 with the register-resident
+// tiles of cnnq_group.hip.h: pass B (sum |x - mean|), the parameter derivation and the Q/DQ in ONE launch and ONE read of
+// x - 12 instead of 16 bytes per element for iq.py:327-352 -> :227-253, 284-300, 393-407 -> :409-451, 557-603.
+// Part of the single translation unit cnnq_kernels.hip.
+//
+// What a channel's clipping value needs is b = mean |x - mean| (iq.py:545: the mean first, hence two passes), and with
+// -baa the bit allocation, which couples ALL channels through sum std^(2/3) (iq.py:381-391).  So pass A stays a launch
+// of its own (k_moments: min / max / sum / sum of squares, 4 bytes per element at the read-streaming rate), a merge
+// (k_combine) and - with bit allocation on the default 'gaus' prior, which needs nothing but the std of pass A - the
+// one-workgroup k_bitalloc follow; then the kernels below do for pass B what k_mmq_flat / k_mmq_group do for the
+// extrema of config 2: a workgroup loads its tile of x into registers, reduces it to sum |x - mean| per channel, meets
+// the other workgroups that hold pieces of the same channels (the slot meeting: a member's partial sum IS its arrival),
+// derives the channel's alpha / delta / offset / scale / zero point with the arithmetic of k_params
+// (channel_params: the same function) and quantizes out of its registers.  A single launch for the whole of config 3
+// cannot exist: no parameter of any channel is known before every channel's std is, i.e. before all of x has been read
+// once, and 1.6 GB do not fit the register files.
+//
+// Sums, unlike extrema, depend on the order of the additions.  Everything here adds in an order that is a function of
+// the geometry alone: a lane adds its steps in order (fp64 accumulation of fp32 |x - mean|, as k_absdev), lanes fold by
+// a fixed xor tree, waves in index order, and the members' partial sums are added in MEMBER order by every member -
+// only after all of them have arrived, never in arrival order - so all members of a group hold the same b, bit for
+// bit, run after run.  The cold path (a wait expired / the test hook) recomputes the partial sum of EVERY member with
+// that member's own lane mapping and folds them the same way: the same bits again, which the min / max kernels get for
+// free from exactness.
+#pragma once
+#include "cnnq_common.hip.h"
+#include "cnnq_group.hip.h"
+#include "cnnq_params.hip.h"
+#include "cnnq_qdq.hip.h"
+
+namespace {
+
+// a partial sum in a slot: the complement of its bits, NaNs made canonical first (a stored word is never zero: zero
+// means "not arrived"; the sum 0.0 of a dead channel becomes all ones)
+__device__ __forceinline__ unsigned long long slot_of_sum(double s) {
+    const unsigned long long b = (s != s) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(s);
+    return ~b;
+}
+__device__ __forceinline__ double sum_of_slot(unsigned long long v) { return __longlong_as_double((long long)~v); }
+
+struct AciqArgs {
+    float* stats;            // [CNNQ_NSTAT][C]: rows MIN, MAX, MEAN, STD from pass A; row B is written here
+    const float* bits;       // [C] allocated widths (k_bitalloc), or null: cfg.num_bits everywhere
+    float* qp;               // [CNNQ_NQP][C] out
+    float* diag;             // [CNNQ_NDIAG][C] out, may be null
+    cnnq_params_cfg cfg;
+    double count;            // N * H*W: elements per channel
+};
+
+// the four |x - mean| of one float4 of ONE channel added to the lane's sum (steps past the tile add nothing)
+__device__ __forceinline__ void absdev_step(const float (&v)[4], float mean, bool valid, double& sa) {
+    double t = (double)fabsf(v[0] - mean);
+    t += (double)fabsf(v[1] - mean);
+    t += (double)fabsf(v[2] - mean);
+    t += (double)fabsf(v[3] - mean);
+    sa += valid ? t : 0.;
+}
+
+// the workgroup's sum of one value per lane: xor tree per wave, the four waves in index order; every lane gets it
+__device__ __forceinline__ double wg_sum1(double v, double* l_s) {
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    __syncthreads();                     // l_s may still be read from a previous call
+    if (lane == 0) l_s[wv] = v;
+    __syncthreads();
+    return ((l_s[0] + l_s[1]) + l_s[2]) + l_s[3];
+}
+
+// The slot meeting of k_aciq_flat (slots_meet of cnnq_group.hip.h for sums): wave 0 stores the member's partial sum and
+// polls the group's slots; lane l watches members l, l + 64, ... in windows of 4 and adds a window's values in member
+// order once the whole window has arrived.  Returns 0, or 1 (a wait expired) / 2 (the test hook), meaningful in thread 0;
+// tsum: the lane's share (0 outside wave 0).
+__device__ __forceinline__ int slots_meet_sum(unsigned long long* slots, int member, int Gs, double msum, unsigned flags,
+                                              long long timeout_ticks, double& tsum) {
+    const int tid = threadIdx.x;
+    tsum = 0.;
+    if (tid >= 64) return 0;
+    if (tid == 0) __hip_atomic_store(slots + member, slot_of_sum(msum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (flags & MMQ_FLAG_TEST_HOOK) return 2;
+    long long t0 = 0;
+    int spins = 0;
+    for (int w0 = 0; w0 * 64 < Gs; w0 += 4) {
+        const unsigned long long* p = slots + tid + 64 * w0;
+        unsigned pend = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pend |= (tid + 64 * (w0 + i) < Gs) ? (1u << i) : 0u;
+        const unsigned mine = pend;
+        unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+        for (;; ++spins) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((pend >> i) & 1u) {
+                    v[i] = __hip_atomic_load(p + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v[i]) pend &= ~(1u << i);
+                }
+            if (__ballot(pend != 0u) == 0ull) break;
+            int expired = 0;
+            if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                expired = (now - t0 > timeout_ticks || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(expired)) return 1;
+            if (spins < 2) __builtin_amdgcn_s_sleep(8);
+            else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((mine >> i) & 1u) tsum += sum_of_slot(v[i]);      // member order, whatever the arrival order was
+    }
+    return 0;
+}
+
+// the same fold over member sums that sit in LDS (the cold path): identical order of additions
+__device__ __forceinline__ double fold_member_sums(const double* ms, int Gs) {
+    const int tid = threadIdx.x;
+    double tsum = 0.;
+    if (tid < 64)
+        for (int w0 = 0; w0 * 64 < Gs; w0 += 4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tid + 64 * (w0 + i) < Gs) tsum += ms[tid + 64 * (w0 + i)];
+    return tsum;
+}
+
+// ---- flat tiles (the geometry of k_mmq_flat: a group is ONE channel, a member 256 K consecutive float4 of it) --------
+template <int K, int OUT = 0>
+__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_flat(
+    const float* __restrict__ x, float* __restrict__ y, const FGeo g, const GWs ws, const AciqArgs aa, const unsigned flags,
+    const XOut xo = XOut{}) {
+    static_assert(TPB == 256, "wg_sum1 folds four waves");
+    __shared__ double l_s[TPB / 64];
+    __shared__ double sh_ms[GRP_GS_MAX];      // cold path only: every member's partial sum
+    __shared__ double sh_tot;
+    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    const cnnq_params_cfg& cfg = aa.cfg;
+    const bool ba = cfg.bit_alloc && cfg.num_bits <= 4;
+    const int nbins = ba ? 256 : 1 << (cfg.num_bits < 8 ? cfg.num_bits : 8);
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_zero(sh_hist, nbins);      // ordered before the first count by the barriers of the exchange
+    }
+    __shared__ int sh_timed_out;
+    const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const int tid = threadIdx.x;
+    int c, member;
+    if (g.cb <= 1) {
+        c = (int)blockIdx.x / g.Gs;
+        member = (int)blockIdx.x - c * g.Gs;
+    } else {
+        const int per = g.cb * g.Gs, blk = (int)blockIdx.x / per, r = (int)blockIdx.x - blk * per;
+        const int c0 = blk * g.cb, cbl = min(g.cb, g.C - c0);
+        member = r / cbl;
+        c = c0 + (r - member * cbl);
+    }
+    // the channel's statistics of pass A (uniform addresses: scalar loads), in flight next to the tile
+    const float vmin = aa.stats[(size_t)CNNQ_STAT_MIN * g.C + c], vmax = aa.stats[(size_t)CNNQ_STAT_MAX * g.C + c];
+    const float vmean = aa.stats[(size_t)CNNQ_STAT_MEAN * g.C + c], vstd = aa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
+    const float bits = ba ? aa.bits[c] : (float)cfg.num_bits;
+
+    const unsigned f0 = (unsigned)member * (256u * K);   // < total
+    const unsigned n_first = f0 / g.cpc;
+    const unsigned u = f0 + (unsigned)tid;
+    const unsigned n = u / g.cpc;
+    FWalk w0;
+    w0.ro = (n - n_first) * g.rs;
+    w0.co = (u - n * g.cpc) * 16u;
+    const unsigned long long lim64 = (unsigned long long)((unsigned)g.N - n_first) * g.rs;
+    const unsigned lim = lim64 > 0xffffffffull ? 0xffffffffu : (unsigned)lim64;   // row offsets below it are inside the batch
+    const size_t base = ((size_t)n_first * (size_t)g.P + (size_t)c * (size_t)g.HW) * 4;
+    const char* xb = reinterpret_cast<const char*>(x) + base;
+    char* yb = reinterpret_cast<char*>(y) + base;
+    uint8_t* cbb = (OUT == 1 && xo.codes) ? xo.codes + base / 4 : nullptr;
+
+    // ---- the tile: K 16-byte loads per lane, back to back (k_mmq_flat's walk)
+    float v[K][4];
+    FWalk w = w0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+        ldv_nt<4>(reinterpret_cast<const float*>(xb + off), v[j]);
+        w.step(g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // steps of this lane inside the channel: u + 256 j < total
+    const int nvalid = u < g.total ? (int)((g.total - u + 255u) / 256u) : 0;
+    double sa = 0.;
+#pragma unroll
+    for (int j = 0; j < K; ++j) absdev_step(v[j], vmean, j < nvalid, sa);
+    const double msum = wg_sum1(sa, l_s);
+
+    // ---- the meeting: the member's sum is its arrival
+    unsigned long long* slots = ws.slots + (size_t)c * ws.gstride;   // zero at rest
+    double tsum;
+    {
+        const long long tmo = (st0 & 1u) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS;      // lane 0's copy is the one consulted
+        const int timed_out = slots_meet_sum(slots, member, g.Gs, msum, flags, tmo, tsum);
+        if (tid == 0) {
+            if (timed_out) atomicOr(ws.status, (unsigned)timed_out);
+            sh_timed_out = timed_out;
+        }
+    }
+    __syncthreads();
+    if (sh_timed_out) {
+        // cold path: every member's partial sum from x with that member's own lane mapping, then the same fold
+        for (int m = 0; m < g.Gs; ++m) {
+            const unsigned mf0 = (unsigned)m * (256u * K), mu = mf0 + (unsigned)tid;
+            const int mvalid = mu < g.total ? (int)((g.total - mu + 255u) / 256u) : 0;
+            double s2 = 0.;
+            for (int j = 0; j < K; ++j) {
+                const unsigned e = mu + 256u * (unsigned)j;
+                const bool in = j < mvalid;
+                const unsigned ee = in ? e : mf0;
+                const unsigned nn = ee / g.cpc;
+                float t[4];
+                ldv<4>(x + (size_t)nn * (size_t)g.P + (size_t)c * (size_t)g.HW + (size_t)(ee - nn * g.cpc) * 4, t);
+                absdev_step(t, vmean, in, s2);
+            }
+            const double ms = wg_sum1(s2, l_s);
+            if (tid == 0) sh_ms[m] = ms;
+        }
+        __syncthreads();
+        tsum = fold_member_sums(sh_ms, g.Gs);
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) tsum += shfl_xor_d(tsum, m);
+        if (tid == 0) sh_tot = tsum;
+    }
+    __syncthreads();
+
+    // ---- b, clipping range, scale / zero point: every lane derives the same values from the same inputs
+    const float vb = (float)(sh_tot / aa.count);
+    const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, vmean, vstd, vb);
+    const float sc = cp.scale, zp = cp.zp, qm = cp.qmax;
+    const bool fast = qdq_fast_domain(vmin, vmax, sc) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
+    if (member == 0 && tid == 0) {
+        aa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
+        aa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
+        aa.qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
+        aa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
+        if (aa.diag) {
+            if (!ba) aa.diag[(size_t)CNNQ_DIAG_BITS * g.C + c] = bits;      // with bit allocation the row IS aa.bits
+            aa.diag[(size_t)CNNQ_DIAG_ALPHA * g.C + c] = cp.alpha;
+            aa.diag[(size_t)CNNQ_DIAG_DELTA * g.C + c] = cp.delta;
+            aa.diag[(size_t)CNNQ_DIAG_OFFSET * g.C + c] = cp.offset;
+        }
+    }
+
+    // ---- Q/DQ out of the registers (the walk repeated and hidden from the optimiser, as in k_mmq_flat)
+    w = w0;
+    asm volatile("" : "+v"(w.ro), "+v"(w.co));
+    const float zpa[1] = {zp};
+    unsigned nzp[1] = {0u};
+    if (__builtin_amdgcn_readfirstlane((int)fast)) {
+        const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp), s_qm = uniform_f(qm);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float o[4], cd[4];
+            qdq4_fast(v[j], s_sc, s_rs, s_zp, s_qm, o, cd);
+            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            w.step(g);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float o[4], cd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
+            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            w.step(g);
+        }
+    }
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, nbins, zpa, nzp);
+    }
+    // ---- leave the group; the last member out re-arms the group's slots
+    if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
+    __syncthreads();
+    if (sh_timed_out)
+        for (int m = tid; m < g.Gs; m += TPB) __hip_atomic_store(slots + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- row-piece tiles (the geometry of k_mmq_group: a member is <= 256 float4 columns x <= K samples) ----------------
+// (group, member) -> tile, for any workgroup (the cold path walks every member of its group)
+__device__ __forceinline__ RBlk rblk_at(const Geo& g, int group, int member) {
+    RBlk r;
+    r.group = group;
+    r.member = member;
+    int s;
+    if (g.mode == 1) {
+        const int cpc = g.HW / 4;
+        s = member / g.nb;
+        const int bb = member - s * g.nb;
+        const int c = g.cbeg + group;
+        r.b.c0 = c;
+        r.b.c1 = c + 1;
+        r.b.col0 = c * cpc + bb * g.w;
+        r.b.col1 = min(r.b.col0 + g.w, (c + 1) * cpc);
+    } else {
+        s = member;
+        r.b.c0 = g.cbeg + group * g.k;
+        r.b.c1 = min(g.cbeg + g.Cn, r.b.c0 + g.k);
+        r.b.col0 = (int)(((int64_t)r.b.c0 * g.HW) / 4);
+        r.b.col1 = (int)(((int64_t)r.b.c1 * g.HW) / 4);
+    }
+    r.b.n0 = (int)(((int64_t)s * g.N) / g.S);
+    r.b.n1 = (int)(((int64_t)(s + 1) * g.N) / g.S);
+    r.b.grp = s;
+    return r;
+}
+
+// per-lane sums -> per-channel sums of the workgroup's tile in sh_sum[c1 - c0], in a fixed order (the layout of
+// wg_channel_minmax: mode 1 - one channel, all lanes; mode 2 - epc LDS entries per channel)
+template <int A>
+__device__ __forceinline__ void wg_channel_sums(const Geo& g, const Blk& b, bool ok, const double (&sa)[A], double* l_a,
+                                                double* sh_sum) {
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    __syncthreads();                     // l_a / sh_sum may still be read from a previous call
+    if (g.mode == 1) {
+        double t = ok ? sa[0] : 0.;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t += shfl_xor_d(t, m);
+        if (lane == 0) l_a[wv] = t;
+        __syncthreads();
+        if (tid == 0) sh_sum[0] = ((l_a[0] + l_a[1]) + l_a[2]) + l_a[3];
+        __syncthreads();
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) l_a[tid * A + a] = ok ? sa[a] : 0.;
+    __syncthreads();
+    const int epc = g.HW * A / 4;   // LDS entries per channel
+    if (epc <= 16) {
+        for (int ch = tid; ch < b.c1 - b.c0; ch += TPB) {
+            double t = 0.;
+            for (int e = ch * epc; e < (ch + 1) * epc; ++e) t += l_a[e];
+            sh_sum[ch] = t;
+        }
+    } else {
+        for (int ch = wv; ch < b.c1 - b.c0; ch += TPB / 64) {
+            double t = 0.;
+            for (int e = ch * epc + lane; e < (ch + 1) * epc; e += 64) t += l_a[e];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) t += shfl_xor_d(t, m);
+            if (lane == 0) sh_sum[ch] = t;
+        }
+    }
+    __syncthreads();
+}
+
+// The group's sums from its members' partial sums, [member][kk] 8-byte words at `src`: slots (POLL: complemented, zero =
+// not arrived) or plain doubles (the cold path's recomputed table).  Lane (ch, j) = (tid / L, tid % L) adds the values of
+// channel ch of members j, j + L, ... in member order, window by window and only once a window is complete; the L lanes
+// of a channel sit in one wave and fold by a fixed xor tree.  Writes sh_sum[ch] (kk > 1), or returns the lane's share in
+// tsum (whole_wg: one channel, all 256 lanes take part; the caller folds).  A wave whose wait expired ORs 1 into *sh_code.
+template <int W, bool POLL>
+__device__ __forceinline__ void group_fold_sums(const unsigned long long* src, int Gs, int kk, int nch, bool whole_wg,
+                                                long long timeout_ticks, double* sh_sum, int* sh_code, double& tsum) {
+    const int tid = threadIdx.x;
+    int L = 1;
+    while (L < 64 && 2 * L * kk <= TPB) L <<= 1;
+    if (whole_wg) L = TPB;
+    const int ch = tid / L, j = tid - ch * L;
+    const bool active = ch < nch;
+    tsum = 0.;
+    long long t0 = 0;
+    int spins = 0;
+    for (int w0 = 0; w0 * L < Gs; w0 += W) {
+        const unsigned long long* p = src + (unsigned)((j + L * w0) * kk + ch);
+        const unsigned step = (unsigned)(L * kk);
+        unsigned pend = 0u;
+#pragma unroll
+        for (int i = 0; i < W; ++i) pend |= (active && j + L * (w0 + i) < Gs) ? (1u << i) : 0u;
+        const unsigned mine = pend;
+        unsigned long long v[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) v[i] = 0ull;
+        if constexpr (POLL) {
+            for (;; ++spins) {
+#pragma unroll
+                for (int i = 0; i < W; ++i)
+                    if ((pend >> i) & 1u) {
+                        v[i] = __hip_atomic_load(p + i * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v[i]) pend &= ~(1u << i);
+                    }
+                if (__ballot(pend != 0u) == 0ull) break;
+                int expired = 0;
+                if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    expired = (now - t0 > timeout_ticks || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+                }
+                if (__builtin_amdgcn_readfirstlane(expired)) {
+                    if ((tid & 63) == 0) atomicOr(sh_code, 1);
+                    return;
+                }
+                if (spins < 2) __builtin_amdgcn_s_sleep(8);
+                else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+                else __builtin_amdgcn_s_sleep(64);
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i)
+                if ((mine >> i) & 1u) tsum += sum_of_slot(v[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < W; ++i)
+                if ((mine >> i) & 1u)
+                    tsum += __longlong_as_double((long long)__hip_atomic_load(p + i * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+    if (!whole_wg) {
+        for (int m = L >> 1; m >= 1; m >>= 1) tsum += shfl_xor_d(tsum, m);
+        if (active && j == 0) sh_sum[ch] = tsum;
+    }
+}
+
+template <int A, int K, int OUT = 0>
+__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_group(
+    const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const GWs ws, const AciqArgs aa,
+    const unsigned flags, const XOut xo = XOut{}) {
+    __shared__ double l_a[TPB * A];
+    __shared__ double sh_sum[MAXCH];
+    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    const cnnq_params_cfg& cfg = aa.cfg;
+    const bool ba = cfg.bit_alloc && cfg.num_bits <= 4;
+    const int nbins = ba ? 256 : 1 << (cfg.num_bits < 8 ? cfg.num_bits : 8);
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_zero(sh_hist, nbins);
+    }
+    __shared__ float sh_mean[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH], sh_rs[MAXCH], sh_qm[MAXCH];
+    __shared__ int sh_timed_out, sh_slow;
+    if (threadIdx.x == 0) sh_slow = 0;      // the barriers of the reduction and of the exchange come before its writers
+    const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const RBlk rb = rblk_of(g, Gs);
+    const Blk& b = rb.b;
+    const int tid = threadIdx.x;
+    const int nch = b.c1 - b.c0;
+    const int col = b.col0 + tid;
+    const bool ok = col < b.col1;
+    const unsigned colc = (unsigned)(ok ? col : b.col0);   // idle lanes re-read the block's first column; results discarded
+    const int nrows = b.n1 - b.n0;        // 1 .. K
+    const size_t base = (size_t)b.n0 * (size_t)g.P + (size_t)colc * 4;
+    // the means of the block's channels (one per lane, issued in front of the tile; MAXCH <= TPB)
+    static_assert(MAXCH <= TPB, "one staging lane per channel");
+    const float r_mean = tid < nch ? aa.stats[(size_t)CNNQ_STAT_MEAN * g.C + b.c0 + tid] : 0.f;
+
+    // ---- the tile: K 16-byte loads per lane, issued back to back (rows past the tile re-read its last row)
+    float v[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int r = j < nrows ? j : nrows - 1;
+        ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < nch) sh_mean[tid] = r_mean;
+    __syncthreads();
+    float mean[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) mean[a] = sh_mean[(int)((colc * 4u + (unsigned)a) / (unsigned)g.HW) - b.c0];
+    double sa[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) sa[a] = 0.;
+    // (a uniform branch per step, not a select: 32 lane masks held in scalar registers next to the tile made the
+    //  allocator spill the tile itself)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < nrows) {
+            if constexpr (A == 1) {
+                absdev_step(v[j], mean[0], true, sa[0]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa[e] += (double)fabsf(v[j][e] - mean[e]);
+            }
+        }
+    }
+    wg_channel_sums<A>(g, b, ok, sa, l_a, sh_sum);
+
+    // ---- publish this workgroup's sums (a sum IS the arrival), wait for the group
+    const int kk = (g.mode == 1) ? 1 : g.k;
+    unsigned long long* slots = ws.slots + (size_t)rb.group * ws.gstride;    // zero at rest
+    for (int ch = tid; ch < nch; ch += TPB)
+        __hip_atomic_store(slots + (size_t)rb.member * kk + ch, slot_of_sum(sh_sum[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) sh_timed_out = ((flags & MMQ_FLAG_TEST_HOOK) ? 2 : 0) | ((st0 & 1u) ? 4 : 0);
+    __syncthreads();      // sh_sum is read above and rewritten by the meeting
+    double ts = 0.;
+    {
+        const int c0 = sh_timed_out;
+        if (!(c0 & 2))
+            group_fold_sums<(K >= 32 ? 4 : 2), true>(slots, Gs, kk, nch, g.mode == 1, (c0 & 4) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS,
+                                                     sh_sum, &sh_timed_out, ts);
+        __syncthreads();
+        if (tid == 0) {
+            const int code = sh_timed_out & 3;
+            if (code) atomicOr(ws.status, (unsigned)code);
+        }
+    }
+    if (sh_timed_out & 3) {
+        // cold path: every member's per-channel sums from x, with that member's own lane mapping, into the group's block
+        // of the pair region (unused by the slot meeting; every workgroup that lands here writes the same values), then
+        // the same fold over the table
+        unsigned long long* tab = ws.part + (size_t)rb.group * ws.gstride;
+        for (int m = 0; m < Gs; ++m) {
+            const RBlk mb = rblk_at(g, rb.group, m);
+            const int mcol = mb.b.col0 + tid;
+            const bool mok = mcol < mb.b.col1;
+            const int mcolc = mok ? mcol : mb.b.col0;
+            const int mrows = mb.b.n1 - mb.b.n0;
+            float mmean[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) mmean[a] = sh_mean[(int)(((unsigned)mcolc * 4u + (unsigned)a) / (unsigned)g.HW) - mb.b.c0];
+            double s2[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) s2[a] = 0.;
+            for (int j = 0; j < K; ++j) {
+                const int r = j < mrows ? j : mrows - 1;
+                float t[4];
+                ldv<4>(x + ((size_t)(mb.b.n0 + r) * (size_t)g.P + (size_t)mcolc * 4), t);
+                if (j < mrows) {
+                    if constexpr (A == 1) {
+                        absdev_step(t, mmean[0], true, s2[0]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s2[e] += (double)fabsf(t[e] - mmean[e]);
+                    }
+                }
+            }
+            wg_channel_sums<A>(g, mb.b, mok, s2, l_a, sh_sum);
+            for (int ch = tid; ch < nch; ch += TPB)
+                __hip_atomic_store(tab + (size_t)m * kk + ch, (unsigned long long)__double_as_longlong(sh_sum[ch]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        group_fold_sums<(K >= 32 ? 4 : 2), false>(tab, Gs, kk, nch, g.mode == 1, 0, sh_sum, &sh_timed_out, ts);
+        __syncthreads();
+    }
+    if (g.mode == 1) {
+        // one channel, 256 shares: the fixed fold of wg_channel_sums
+        const double one[1] = {ts};
+        wg_channel_sums<1>(g, b, true, one, l_a, sh_sum);
+    }
+
+    // ---- b, clipping range, scale / zero point of the owned channels: identical in every member
+    for (int ch = tid; ch < nch; ch += TPB) {
+        const int c = b.c0 + ch;
+        const float vmin = aa.stats[(size_t)CNNQ_STAT_MIN * g.C + c], vmax = aa.stats[(size_t)CNNQ_STAT_MAX * g.C + c];
+        const float vstd = aa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
+        const float bits = ba ? aa.bits[c] : (float)cfg.num_bits;
+        const float vb = (float)(sh_sum[ch] / aa.count);
+        const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, sh_mean[ch], vstd, vb);
+        sh_sc[ch] = cp.scale;
+        sh_zp[ch] = cp.zp;
+        sh_qm[ch] = cp.qmax;
+        sh_rs[ch] = 1.0f / cp.scale;
+        if (!qdq_fast_domain(vmin, vmax, cp.scale) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
+        if (rb.member == 0) {
+            aa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = cp.scale;
+            aa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = cp.zp;
+            aa.qp[(size_t)CNNQ_QP_QMAX * g.C + c] = cp.qmax;
+            aa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
+            if (aa.diag) {
+                if (!ba) aa.diag[(size_t)CNNQ_DIAG_BITS * g.C + c] = bits;      // with bit allocation the row IS aa.bits
+                aa.diag[(size_t)CNNQ_DIAG_ALPHA * g.C + c] = cp.alpha;
+                aa.diag[(size_t)CNNQ_DIAG_DELTA * g.C + c] = cp.delta;
+                aa.diag[(size_t)CNNQ_DIAG_OFFSET * g.C + c] = cp.offset;
+            }
+        }
+    }
+    __syncthreads();
+    // the lane's channel indices again, hidden from the optimiser: kept alive across the meeting next to the tile they
+    // cost registers the K = 32 tile does not leave (spills)
+    int tidq = threadIdx.x;
+    asm volatile("" : "+v"(tidq));
+    const bool okq = b.col0 + tidq < b.col1;
+    const unsigned colq = (unsigned)(okq ? b.col0 + tidq : b.col0);
+    const size_t baseq = (size_t)b.n0 * (size_t)g.P + (size_t)colq * 4;
+    int chl[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) chl[a] = (int)((colq * 4u + (unsigned)a) / (unsigned)g.HW) - b.c0;
+    float sc[A], zp[A], qm[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        sc[a] = sh_sc[chl[a]];
+        zp[a] = sh_zp[chl[a]];
+        qm[a] = sh_qm[chl[a]];
+    }
+
+    // ---- Q/DQ out of the registers
+    unsigned nzp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) nzp[a] = 0u;
+    if (!__builtin_amdgcn_readfirstlane(sh_slow)) {
+        float rs[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) rs[a] = sh_rs[chl[a]];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < nrows) {
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = qdq1_fast(v[j][e], sc[A == 1 ? 0 : e], rs[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
+                if (okq)
+                    xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, nullptr, (baseq + (size_t)j * (size_t)g.P) * 4, o, cd, sh_hist,
+                                   zp, nzp);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < nrows) {
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
+                if (okq)
+                    xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, nullptr, (baseq + (size_t)j * (size_t)g.P) * 4, o, cd, sh_hist,
+                                   zp, nzp);
+            }
+        }
+    }
+    if constexpr (OUT == 1) {
+        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, nbins, zp, nzp);
+    }
+    // ---- leave the group; the last member out re-arms the group's slots
+    if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
+    __syncthreads();
+    if (sh_timed_out)
+        for (int m = tid; m < Gs * kk; m += TPB) __hip_atomic_store(slots + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace

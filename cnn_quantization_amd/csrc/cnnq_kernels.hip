@@ -837,6 +837,68 @@ int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW,
     return cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, /*reverse=*/need_b ? 0 : 1, stream);
 }
 
+// Config 3 with pass B, the parameters and the Q/DQ in ONE launch (cnnq_aciq.hip.h): pass A -> merge -> (bit allocation)
+// -> k_aciq_flat / k_aciq_group: 12 instead of 16 bytes per element, four launches.  Laplace clipping on the per-channel
+// route (clip == 1, no direct_range), bit allocation on the 'gaus' prior only (the 'laplace' prior IS b, which only exists
+// inside the last launch).  CNNQ_ENOTSUP - nothing enqueued - for every other configuration, for shapes without a
+// single-launch plan and for a `gws` too small: the caller takes cnnq_pc_aciq_qdq.  ws: part[G][CNNQ_NMOM][C] doubles
+// (cnnq_pc_aciq_workspace covers it); stats [CNNQ_NSTAT][C] is written completely (KURT, STD_POS: zero).
+int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                            void* gws, size_t gws_bytes, float* stats, float* qp, float* diag, uint8_t* codes,
+                            uint64_t* hist_rep, unsigned flags, void* stream) {
+    if (!x || !y || !cfg || !ws || !stats || !qp || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
+    if (cfg->num_bits < 1 || cfg->num_bits > 32 || cfg->clip < 0 || cfg->clip > 3) return CNNQ_EINVAL;
+    if ((cfg->clip == 1 || cfg->clip == 2) && cfg->num_bits > 8) return CNNQ_EINVAL;
+    if (((uintptr_t)codes & 3) || ((uintptr_t)hist_rep & 7) || (gws && ((uintptr_t)gws & 127))) return CNNQ_EINVAL;
+    const bool use_ba = cfg->bit_alloc && cfg->num_bits <= 4;
+    if (use_ba && !diag) return CNNQ_EINVAL;                     // the bit table lives in diag
+    if (cfg->clip != 1 || cfg->direct_range || (use_ba && cfg->prior_is_b) || !gws) return CNNQ_ENOTSUP;
+    GPlan gp;
+    if (plan_group(N, C, HW, al16(x) && al16(y), &gp) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    if ((size_t)gp.ngroups * gp.gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = cnnq_pc_moments(x, N, C, HW, 0, part, stream);
+    if (rc) return rc;
+    rc = cnnq_pc_combine(part, G, C, 0, nullptr, stats, stream);
+    if (rc) return rc;
+    float* bits = nullptr;
+    if (use_ba) {
+        bits = diag + (size_t)CNNQ_DIAG_BITS * C;
+        const int threads = (int)(C >= PTPB ? PTPB : ((C + 63) / 64) * 64);
+        hipLaunchKernelGGL(k_bitalloc, dim3(1), dim3(threads), 0, st, stats + (size_t)CNNQ_STAT_STD * C, (int)C, *cfg, bits);
+        rc = launch_status();
+        if (rc) return rc;
+    }
+    AciqArgs aa;
+    aa.stats = stats;
+    aa.bits = bits;
+    aa.qp = qp;
+    aa.diag = diag;
+    aa.cfg = *cfg;
+    aa.count = (double)N * (double)HW;
+    XOut xo;
+    xo.codes = codes;
+    xo.hist = reinterpret_cast<unsigned long long*>(hist_rep);
+    xo.packed = nullptr;
+    return launch_aciq(x, y, gp, aa, gws, flags, st, (codes || hist_rep) ? 1 : 0, xo);
+}
+
+// ... behind ONE call with the chain as the fallback: ws as cnnq_pc_aciq_qdq (cnnq_pc_aciq_workspace bytes); the
+// statistics table is the one inside ws either way
+int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                          void* gws, size_t gws_bytes, float* qp, float* diag, void* stream) {
+    if (!x || !y || !cfg || !ws || !qp || ((uintptr_t)ws & 7)) return CNNQ_EINVAL;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    float* stats = reinterpret_cast<float*>(reinterpret_cast<double*>(ws) + ((size_t)G * CNNQ_NMOM + CNNQ_NMOM + (size_t)G * CNNQ_NDEV) * C);
+    const int rc = cnnq_pc_aciq_qdq_single(x, y, N, C, HW, cfg, ws, gws, gws_bytes, stats, qp, diag, nullptr, nullptr, 0u, stream);
+    if (rc != CNNQ_ENOTSUP) return rc;
+    return cnnq_pc_aciq_qdq(x, y, N, C, HW, cfg, ws, qp, diag, stream);
+}
+
 int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_w, const float* stats_q, int vcorr,
                            int bcorr, void* stream) {
     if (!wq || !stats_w || !stats_q || C <= 0 || HW <= 0 || C > 65535 * 1024 || HW >= ((int64_t)1 << 31))

@@ -5,6 +5,7 @@
 #include "cnnq_common.hip.h"
 #include "cnnq_resident.hip.h"
 #include "cnnq_group.hip.h"
+#include "cnnq_aciq.hip.h"
 
 namespace {
 
@@ -355,8 +356,10 @@ int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* 
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (!aligned16) return CNNQ_ENOTSUP;
     p->flat = 0;
+    p->KL = 0;
     if (allow_flat && plan_flat(N, C, HW, p, lds_rows) == 0) return 0;
     p->flat = 0;
+    p->KL = 0;
     if (HW % 4 == 0) {
         p->v = {4, 1, 1};
     } else if ((C * HW) % 4 == 0) {
@@ -456,6 +459,44 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         if (p.K == 32) LAUNCH_G(1, 32); else if (p.K == 16) LAUNCH_G(1, 16); else if (p.K == 8) LAUNCH_G(1, 8); else LAUNCH_G(1, 4);
     }
 #undef LAUNCH_G
+    return launch_status();
+}
+
+// the single-launch ACIQ kernels (cnnq_aciq.hip.h) on the plan and the workspace of launch_group; slot meeting only
+int launch_aciq(const float* x, float* y, const GPlan& p, const AciqArgs& aa, void* ws, unsigned flags, hipStream_t st, int out,
+                const XOut& xo) {
+    if ((size_t)p.ngroups * p.gstride * 8 > GRP_WS_SLOT_BYTES || p.KL) return CNNQ_ENOTSUP;
+    flags |= mmq_env_flags();
+    GWs w;
+    w.status = reinterpret_cast<unsigned*>(ws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
+    w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_SLOTS);
+    w.gstride = p.gstride;
+    const dim3 block(TPB);
+    if (p.flat) {
+        const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
+#define LAUNCH_AF(K)                                                                                            \
+    do {                                                                                                        \
+        if (out == 1) hipLaunchKernelGGL((k_aciq_flat<K, 1>), fgrid, block, 0, st, x, y, p.fg, w, aa, flags, xo);  \
+        else hipLaunchKernelGGL((k_aciq_flat<K, 0>), fgrid, block, 0, st, x, y, p.fg, w, aa, flags, xo);           \
+    } while (0)
+        if (p.K == 32) LAUNCH_AF(32); else if (p.K == 16) LAUNCH_AF(16); else LAUNCH_AF(8);
+#undef LAUNCH_AF
+        return launch_status();
+    }
+    const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb));
+#define LAUNCH_AG(A, K)                                                                                                 \
+    do {                                                                                                                \
+        if (out == 1) hipLaunchKernelGGL((k_aciq_group<A, K, 1>), grid, block, 0, st, x, y, p.g, p.Gs, w, aa, flags, xo);  \
+        else hipLaunchKernelGGL((k_aciq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, w, aa, flags, xo);           \
+    } while (0)
+    if (p.v.A == 4) {
+        if (p.K == 32) LAUNCH_AG(4, 32); else if (p.K == 16) LAUNCH_AG(4, 16); else if (p.K == 8) LAUNCH_AG(4, 8); else LAUNCH_AG(4, 4);
+    } else {
+        if (p.K == 32) LAUNCH_AG(1, 32); else if (p.K == 16) LAUNCH_AG(1, 16); else if (p.K == 8) LAUNCH_AG(1, 8); else LAUNCH_AG(1, 4);
+    }
+#undef LAUNCH_AG
     return launch_status();
 }
 

@@ -44,7 +44,8 @@ def _dev_f32(x, what='tensor'):
 # switches, read ONCE at import (the hot call used to look three of them up per tensor: weak #10 of the round-2
 # review); reload_switches() re-reads them for callers that change the environment afterwards (tests, tools)
 def reload_switches():
-    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED, _XRANK_ON
+    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED, _XRANK_ON, _ACIQ_SINGLE
+    _ACIQ_SINGLE = os.environ.get('CNNQ_ACIQ_SINGLE', '1') != '0'      # 0: the ACIQ path always takes the five-launch chain (A/B)
     _XRANK_ON = os.environ.get('CNNQ_XRANK', 'auto') != '0'           # sharded config 2 exchanges INSIDE the single launch when D.xrank_exchange says so (auto: one GPU per rank, verified)
     _PT_FUSED = os.environ.get('CNNQ_PT_FUSED', '0') == '1'           # 1: config 1 in one launch (slower: see ops.minmax_qdq_per_tensor)
     _RESIDENT = os.environ.get('CNNQ_RESIDENT', '1') != '0'            # 0: never take a single-launch kernel
@@ -455,6 +456,49 @@ def minmax_qdq_single(x, N, C, HW, num_bits, positive=False, want_codes=False, w
         stats[L.STAT_MIN] = qp[L.NQP]
         stats[L.STAT_MAX] = qp[L.NQP + 1]
         res.append(dict(stats=stats, qp=qp[:L.NQP], diag=None))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def aciq_qdq_single(x, N, C, HW, num_bits, positive=False, bit_alloc=False, target=None, round_mode=True, want_codes=False,
+                    want_entropy=False, want_parts=False, out=None, flags=0):
+    """Config 3 (Laplace clipping, dynamic statistics, optional bit allocation on the 'gaus' prior) with pass B, the
+    parameters and the Q/DQ in ONE launch and one read of x (cnnq_pc_aciq_qdq_single: pass A, merge, bit allocation, the
+    single launch).  Returns y [, codes] [, entropy] [, parts], or None when the shape has no single-launch plan (the
+    caller takes the chain)."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    st = _raw_stream(x.device.index)
+    gws = _group_workspace(x, st)
+    if gws is None:
+        return None
+    hist = _hist_replicas(x, st) if want_entropy else None
+    if want_entropy and hist is None:
+        return None
+    cfg = _params_cfg(num_bits, positive, 'laplace', bit_alloc, False, target, round_mode, False)
+    al = int(x.data_ptr() % 16 == 0)
+    key = ('aciq', N, C, HW, al)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WS_BYTES[key] = (lib.cnnq_pc_aciq_workspace(N, C, HW, al) + 15) // 16 * 16
+    ws = _scratch(x, 'aciq', nbytes + (L.NQP + L.NDIAG) * C * 4, st)
+    y = _out_like(x, out)
+    tabs = torch.empty((L.NSTAT + L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
+    stats, qp, diag = tabs[:L.NSTAT], tabs[L.NSTAT:L.NSTAT + L.NQP], tabs[L.NSTAT + L.NQP:]
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+    rc = lib.cnnq_pc_aciq_qdq_single(_ptr(x), _ptr(y), N, C, HW, ctypes.byref(cfg), ws.data_ptr(), gws, GROUP_WS_BYTES, _ptr(stats),
+                                     _ptr(qp), _ptr(diag), _ptr(codes), _ptr(hist), int(flags), st)
+    if rc == L.ENOTSUP:
+        return None
+    L.check(rc, 'cnnq_pc_aciq_qdq_single')
+    res = [y]
+    if want_codes:
+        res.append(codes)
+    if want_entropy:
+        ent = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_entropy_replicas(_ptr(hist), _ptr(ent), st), 'cnnq_entropy_replicas')
+        res.append(ent[0])
+    if want_parts:
+        res.append(dict(stats=stats, qp=qp, diag=diag))
     return res[0] if len(res) == 1 else tuple(res)
 
 
@@ -908,9 +952,14 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         if bcorr is not None:
             res = act_bias_correction_(x, res, bool(bcorr), group=None if group is False else group)
         return res
+    # Laplace clipping with dynamic statistics on one GPU: pass B, the parameters and the Q/DQ in ONE launch that reads
+    # x once (cnnq_pc_aciq_qdq_single: 12 instead of 16 bytes per element) when the shape has a single-launch plan
+    single = (_ACIQ_SINGLE and _RESIDENT and stats is None and world == 1 and bcorr is None and clip == 'laplace'
+              and not whole_tensor and not (use_ba and prior_is_b) and num_bits <= 8)
     if (stats is None and world == 1 and bcorr is None and not (want_codes or want_entropy or want_parts)):
-        # one host call for the whole chain (cnnq_pc_aciq_qdq): five launches, one cached workspace (statistics
-        # partials, then the parameter and diagnostic tables, which nobody outside the chain reads)
+        # one host call for the whole pipeline (cnnq_pc_aciq_qdq_auto: four launches through the single-launch kernel,
+        # else the five of the chain), one cached workspace (statistics partials, then the parameter and diagnostic
+        # tables, which nobody outside the call reads)
         lib = L.load()
         cfg = _params_cfg(num_bits, positive, clip, use_ba, prior_is_b, target, round_mode, whole_tensor)
         y = _out_like(x, out)
@@ -922,10 +971,20 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         st = _raw_stream(x.device.index)
         base = _scratch(x, 'aciq', nbytes + (L.NQP + L.NDIAG) * C * 4, st).data_ptr()
         qd = base + nbytes
-        rc = lib.cnnq_pc_aciq_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), base, qd, qd + L.NQP * C * 4, st)
+        gws = _group_workspace(x, st) if single else None
+        if gws is not None:
+            rc = lib.cnnq_pc_aciq_qdq_auto(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), base, gws, GROUP_WS_BYTES, qd,
+                                           qd + L.NQP * C * 4, st)
+        else:
+            rc = lib.cnnq_pc_aciq_qdq(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), base, qd, qd + L.NQP * C * 4, st)
         if rc:
             L.check(rc, 'cnnq_pc_aciq_qdq')
         return y
+    if single:
+        res = aciq_qdq_single(x, N, C, HW, num_bits, positive, use_ba, target, round_mode, want_codes, want_entropy, want_parts,
+                              out=out)
+        if res is not None:
+            return res
     if stats is None:
         need_b = (clip == 'laplace') or (use_ba and prior_is_b)
         stats, _ = pc_stats(x, N, C, HW, need_b=need_b, group=None if group is False else group,

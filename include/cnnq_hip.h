@@ -382,6 +382,23 @@ size_t cnnq_pc_aciq_workspace(int64_t N, int64_t C, int64_t HW, int aligned16);
 int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
                      float* qp, float* diag, void* stream);
 
+/* The same pipeline with pass B, the parameter derivation and the Q/DQ in ONE launch that reads x once (round 5; 12
+ * instead of 16 bytes per element, four launches: pass A, merge, bit allocation, the single launch): the register-resident
+ * tiles and the in-launch slot meeting of cnnq_pc_minmax_qdq_group, exchanging per-channel partial sums of |x - mean|
+ * (added in member order by every member: the same b, bit for bit, in all of them and run after run).  For Laplace
+ * clipping on the per-channel route (cfg->clip == 1, !direct_range), bit allocation on the 'gaus' prior only.  Returns
+ * CNNQ_ENOTSUP - nothing enqueued - for other configurations, shapes without a single-launch plan, or a group workspace
+ * `gws` (cnnq_group_ws_alloc, >= cnnq_pc_group_workspace bytes) that is NULL or too small.
+ * ws: >= cnnq_pc_aciq_workspace bytes; stats[CNNQ_NSTAT][C] out (every row written; KURT / STD_POS zero); qp, diag as
+ * cnnq_pc_params (diag required with bit allocation); codes / hist_rep (optional) as cnnq_pc_minmax_qdq_single;
+ * flags: 0 (tests: 1 = skip the wait and recompute, 2 = IEEE divide for every channel). */
+int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                            void* gws, size_t gws_bytes, float* stats, float* qp, float* diag, uint8_t* codes,
+                            uint64_t* hist_rep, unsigned flags, void* stream);
+/* cnnq_pc_aciq_qdq_single when it applies, else cnnq_pc_aciq_qdq: one call, same ws. */
+int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
+                          void* gws, size_t gws_bytes, float* qp, float* diag, void* stream);
+
 /* Weight bias / variance correction after quantization (iqm.py:374-391), in place on
  * wq[C][HW]: vcorr: wq = (wq - mean_q) * std_w/(std_q + 1e-8) + mean_q; bcorr: wq = wq - mean_q + mean_w
  * (mean_q is the pre-correction mean in both), with the reference's operation order.  stats_w /

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_rw.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_rw'))
 lib.urw.restype = ctypes.c_float
 lib.urw.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
 out = torch.zeros(16, device='cuda')

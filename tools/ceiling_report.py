@@ -19,7 +19,7 @@ import bench  # noqa: E402
 
 
 def load(name, fn, argtypes):
-    lib = ctypes.CDLL(os.path.join(here, name))
+    lib = ctypes.CDLL(__import__('_ubuild').so(name[:-3]) if name.endswith('.so') else os.path.join(here, name))
     f = getattr(lib, fn)
     f.restype = ctypes.c_float
     f.argtypes = argtypes

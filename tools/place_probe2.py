@@ -6,7 +6,7 @@ import torch
 import bench
 from cnn_quantization_amd import _lib
 lib = _lib.load()
-al = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ubench_rw.so'))
+al = ctypes.CDLL(__import__('_ubuild').so('ubench_rw'))
 al.urw_alloc.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
 hip = ctypes.CDLL('libamdhip64.so')
 dev = torch.device('cuda')

@@ -14,7 +14,7 @@ def other(path):
     l.cnnq_pc_minmax_qdq_group.argtypes = _lib.SIGNATURES['cnnq_pc_minmax_qdq_group'][1]
     return l
 ro, wo = other(os.path.join(here, 'alt', 'libcnnq_abl3.so')), other(os.path.join(here, 'alt', 'libcnnq_abl6.so'))
-rw = ctypes.CDLL(os.path.join(here, 'ubench_rw.so'))
+rw = ctypes.CDLL(__import__('_ubuild').so('ubench_rw'))
 rw.urw.restype = ctypes.c_float
 rw.urw.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
 dev = torch.device('cuda')

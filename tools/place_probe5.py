@@ -5,7 +5,7 @@ import torch
 import bench
 from cnn_quantization_amd import _lib
 lib = _lib.load()
-sa = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scatter_alloc.so'))
+sa = ctypes.CDLL(__import__('_ubuild').so('scatter_alloc'))
 sa.scat_alloc.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
 sa.scat_granularity.restype = ctypes.c_size_t
 hip = ctypes.CDLL('libamdhip64.so')

@@ -6,7 +6,7 @@ import torch
 import bench
 from cnn_quantization_amd import _lib
 lib = _lib.load()
-sa = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scatter_alloc.so'))
+sa = ctypes.CDLL(__import__('_ubuild').so('scatter_alloc'))
 hip = ctypes.CDLL('libamdhip64.so')
 dev = torch.device('cuda')
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

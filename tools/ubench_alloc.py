@@ -4,7 +4,7 @@ address translations) and eight pairs round-robin (26 GB: cold translations, as 
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_rw.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_rw'))
 P_, I_ = ctypes.c_void_p, ctypes.c_int
 lib.urw_multi.restype = ctypes.c_float
 lib.urw_multi.argtypes = [I_] * 4 + [ctypes.POINTER(P_)] * 2 + [I_, P_, I_, I_, I_]

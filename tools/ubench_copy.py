@@ -1,6 +1,6 @@
 import ctypes, os, itertools
 import torch
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ubench_copy.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_copy'))
 lib.ucopy.restype = ctypes.c_float
 lib.ucopy.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
 lib.umemcpy.restype = ctypes.c_float

@@ -13,10 +13,7 @@ import time
 import torch
 
 here = os.path.dirname(os.path.abspath(__file__))
-so = os.path.join(here, 'ubench_divide.so')
-if not os.path.exists(so):
-    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-shared', '-fPIC',
-                    os.path.join(here, 'ubench_divide.hip'), '-o', so], check=True)
+so = __import__('_ubuild').so('ubench_divide', extra=('-ffp-contract=off',))
 lib = ctypes.CDLL(so)
 lib.udivide.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
 NS = int(os.environ.get('NS', '384'))

@@ -3,7 +3,7 @@
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_mall.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_mall'))
 lib.umall_read.restype = ctypes.c_float
 lib.umall_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 lib.umall_two.restype = ctypes.c_float

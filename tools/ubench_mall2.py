@@ -1,5 +1,5 @@
 import ctypes, os, torch
-lib = ctypes.CDLL('tools/ubench_mall.so')
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_mall'))
 lib.umall_two.restype = ctypes.c_float
 lib.umall_two.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong] + [ctypes.c_int] * 4
 lib.umall_read.restype = ctypes.c_float

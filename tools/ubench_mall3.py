@@ -4,7 +4,7 @@ launches.  Prints us per tensor and TB/s on the 8 B/elem accounting (x bytes * 2
 import ctypes, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_mall3.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_mall3'))
 P_, I_, L_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 lib.um3_one.restype = ctypes.c_float
 lib.um3_one.argtypes = [P_] * 5 + [I_, L_, L_] + [I_] * 5

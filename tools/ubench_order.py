@@ -2,7 +2,7 @@
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_order.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_order'))
 lib.uord.restype = ctypes.c_float
 lib.uord.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 8
 for (N, C, hw) in ((512, 256, 56), (512, 1024, 14)):

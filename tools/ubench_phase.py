@@ -3,7 +3,7 @@ staggered (tools/ubench_phase.hip), on several (x, y) pairs of one process (plac
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_phase.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_phase'))
 lib.uphase.restype = ctypes.c_float
 lib.uphase.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
 N, C, hw = 512, 256, 56

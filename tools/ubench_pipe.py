@@ -4,7 +4,7 @@ exchange delay between a tile's loads and its stores and with / without the real
 import ctypes, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_pipe.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_pipe'))
 lib.upipe.restype = ctypes.c_float
 lib.upipe.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6
 VAR = [('rows', 0, 32, 3), ('rows', 0, 16, 6), ('flat', 1, 32, 3), ('flat', 1, 16, 6), ('flat', 1, 8, 8),

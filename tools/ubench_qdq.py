@@ -1,7 +1,7 @@
 import ctypes, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_qdq.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_qdq'))
 lib.ubench.restype = ctypes.c_float
 lib.ubench.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int]
 names = {0: 'cw div J4 u2', 1: 'cw COPY J4 u2', 2: 'cw rcp J4 u2', 3: 'cw div J4 ntS', 4: 'cw div J4 ntLS', 5: 'cw div J2 u2',

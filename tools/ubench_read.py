@@ -1,6 +1,6 @@
 import ctypes, os
 import torch
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ubench_copy.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_copy'))
 lib.uread.restype = ctypes.c_float
 lib.uread.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
 n = 512 * 64 * 112 * 112

@@ -2,7 +2,7 @@
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_stpol.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_stpol'))
 lib.ustpol.restype = ctypes.c_float
 lib.ustpol.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 6
 NAMES = ['plain', 'nt', 'sc0', 'sc1', 'sc0 sc1', 'sc0 nt', 'sc1 nt', 'sc0 sc1 nt']

@@ -2,7 +2,7 @@
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_ticket.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_ticket'))
 lib.utick.restype = ctypes.c_float
 lib.utick.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 8
 lib.utick_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]

@@ -3,7 +3,7 @@ as a function of rows x columns per workgroup and of the block -> tile order (to
 import ctypes, os, subprocess, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-so = os.path.join(here, 'ubench_tile.so')
+so = __import__('_ubuild').so('ubench_tile')
 lib = ctypes.CDLL(so)
 lib.utile.restype = ctypes.c_float
 lib.utile.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -5,7 +5,7 @@ are multiples of 64 KB apart collide on the same HBM channels / banks, an odd st
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_tile.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_tile'))
 lib.utile.restype = ctypes.c_float
 lib.utile.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 N = 512

@@ -4,7 +4,7 @@
 import ctypes, os
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_width.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_width'))
 lib.uwidth.restype = ctypes.c_float
 lib.uwidth.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
 for (N, C, hw) in ((512, 1024, 14), (512, 2048, 7)):

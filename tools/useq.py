@@ -1,7 +1,7 @@
 import ctypes, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'ubench_qdq.so'))
+lib = ctypes.CDLL(__import__('_ubuild').so('ubench_qdq'))
 lib.useq.restype = ctypes.c_float
 P = ctypes.c_void_p
 lib.useq.argtypes = [ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int]

@@ -6,7 +6,7 @@ import torch
 import bench
 from cnn_quantization_amd import _lib
 lib = _lib.load()
-tl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ubench_touch.so'))
+tl = ctypes.CDLL(__import__('_ubuild').so('ubench_touch'))
 tl.utouch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
 TOUCH = int(os.environ.get('TOUCH_KB', '0')) << 10          # 0: off; else one load per this many bytes of x and y before every launch
 dev = torch.device('cuda')
