@@ -239,7 +239,11 @@ def main():
                     help='strong: the one batch is sharded, batch/N per GPU (SURVEY 8 e1); weak: every GPU its own batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a HIP graph (single GPU only)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step from a HIP graph (also the sharded step, its exchange included: every rank captures '
+                         'and replays the same launches)')
+    ap.add_argument('--sustained-secs', type=float, default=2.0,
+                    help='after the timed K steps: keep stepping for about this long and report that rate too (0: skip)')
     ap.add_argument('--force-exchange', action='store_true',
                     help='single GPU: run the multi-GPU launch sequence with a 1-rank RCCL group (a self all_gather per '
                          'tensor) - measures what the collective costs on this box')
@@ -288,6 +292,12 @@ def main():
     from cnn_quantization_amd import ops, _lib
     from cnn_quantization_amd import distributed as D
     _lib.load()                                         # fail loudly if the HIP library is missing
+    if 'CNNQ_XRANK' not in os.environ:
+        # The library's default for a sharded run is the collective route.  This program opts into 'auto' - with one GPU per
+        # rank, try the in-launch exchange first - because it implements what that takes: both routes are probed before the
+        # warm-up and the faster one is kept, and if a wait for a peer expires all ranks drop to the collective together and
+        # the job is timed again (below).
+        D.set_xrank_mode('auto')
     if args.scaling == 'strong':
         n0, n1 = D.shard_batch(args.batch, rank, world)
         per_rank = n1 - n0
@@ -302,18 +312,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = lambda: run_step(ops, layers, group)       # noqa: E731
+    eager_step = lambda: run_step(ops, layers, group)       # noqa: E731
+    launch_form = 'eager'
     if args.graph:
-        assert world == 1 and not args.force_exchange, '--graph is a single-GPU option'
+        # everything runs on ONE side stream - the exchange windows and the workspaces are bound to the stream of their
+        # first launch, and a capture needs a stream other than the default one
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            run_step(ops, layers, group)               # workspaces of this stream exist before the capture
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                run_step(ops, layers, group)
-        torch.cuda.current_stream().wait_stream(side)
-        step = graph.replay
+        torch.cuda.set_stream(side)
+
+    def make_step():
+        """the step as the timed region runs it: eager, or a graph captured with the exchange route in force NOW"""
+        nonlocal launch_form
+        if not args.graph:
+            return eager_step
+        eager_step()                                   # workspaces (and the exchange's sequence word) exist before the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=torch.cuda.current_stream()):
+            eager_step()
+        launch_form = 'hip graph replay'
+        return graph.replay
+
+    step = eager_step
     def region(warm, steps):
         # every rank reaches both barriers whatever happens in between: a wait of the in-launch exchange that expired
         # surfaces as CnnqError at that exchange's next host check, on one rank first
@@ -358,6 +379,7 @@ def main():
         xrank_info = {'probe_ms_in_launch': tx / 2 * 1e3, 'probe_ms_collective': tc / 2 * 1e3}
         if not okx or tc < tx:
             D.disable_xrank(group)
+    step = make_step()
     dt, ok = region(args.warmup, args.steps)
     if exchanging and D.xrank_exchange(group) is not None:
         # the job ran through the in-launch exchange (CNNQ_XRANK=auto / 1).  If a peer wait expired anywhere, every rank
@@ -367,6 +389,7 @@ def main():
         if not ok:
             D.disable_xrank(group)
             ops.release_plans()
+            step = make_step()                           # a graph captured with the closed exchange is never replayed again
             dt, ok = region(args.warmup, args.steps)
     elif xrank_info is not None:
         xrank_info.update(used=False, healthy=True, fell_back=False)      # probed, and the collective was faster (or a probe failed)
@@ -385,6 +408,20 @@ def main():
         per_rank_ms = [float(v) for v in mine.tolist()]
         dt, total_elems = float(tmax[0].item()), int(t[1].item())
     ms_per_step = dt * 1e3 / args.steps
+    # the same step for about two more seconds: the 20-step region of a fresh box flatters by 2-4 % (the part warms up)
+    sustained = None
+    if args.sustained_secs > 0:
+        ksus = max(args.steps, int(math.ceil(args.sustained_secs / (dt / args.steps))))
+        dts, oks = region(0, ksus)
+        if world > 1:
+            tt = torch.tensor([dts], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt[0].item())
+        if oks:
+            sustained = {'steps': ksus, 'seconds': dts, 'ms_per_step': dts * 1e3 / ksus, 'value': total_elems * ksus / dts,
+                         'path_frac_hbm_peak_8B': total_elems / world * ksus / dts * BYTES_QDQ / 1e9 / HBM_PEAK_GBS,
+                         'note': 'the timed step repeated for ~%.0f s right after the timed region (max over ranks); '
+                                 'path_frac_hbm_peak_8B prices every element at the 8 bytes the single launch moves' % args.sustained_secs}
     if world == 1 and not args.force_exchange:
         exchange_name = 'none (1 GPU)'
     elif D.xrank_exchange(group) is not None:
@@ -393,10 +430,6 @@ def main():
                          'the collective; x is read once)%s' % (' (forced on a 1-rank group)' if args.force_exchange else ''))
         if not xr.healthy():
             exchange_name += ' - UNHEALTHY: a wait for a peer expired, results of this run are invalid'
-    elif D.p2p_exchange(group) is not None:
-        exchange_name = 'peer-to-peer stores over xGMI (CNNQ_P2P_EXCHANGE=1, verified against the collective)'
-        if not D.p2p_exchange(group).healthy():
-            exchange_name += ' - UNHEALTHY: a wait timed out, results of this run are invalid'
     else:
         from cnn_quantization_amd import rccl
         direct = backend == 'nccl' and rccl.direct_comm(group) is not None
@@ -429,8 +462,8 @@ def main():
                                    args.batch * (world if args.scaling == 'weak' else 1), total_elems / 1e9, elems / 1e9),
                    'per_gpu_batch': per_rank, 'global_batch': args.batch * (world if args.scaling == 'weak' else 1),
                    'parallelism': 'batch-sharded dp%d, %s' % (world, 'per-channel extrema exchanged inside the launch' if (xrank_info or {}).get('used') else 'per-channel stats all_gather'),
-                   'exchange': exchange_name, 'launch': 'hip graph replay' if args.graph else 'eager'},
-        'verified': verified, 'group_status': group_status, 'xrank': None, 'box': box_id(dev_index),
+                   'exchange': exchange_name, 'launch': launch_form},
+        'verified': verified, 'group_status': group_status, 'xrank': None, 'box': box_id(dev_index), 'sustained': sustained,
         'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
         'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
         'path_note': '12 B/elem is SURVEY 8(d3)\'s accounting (statistics read + Q/DQ read + write); layers that run '

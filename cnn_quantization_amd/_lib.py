@@ -103,12 +103,9 @@ SIGNATURES = {
     'cnnq_pt_setup': (_I, [ctypes.POINTER(_F), _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'cnnq_pt_qdq': (_I, [_P, _P, _L, _P, _P, _P]),
     'cnnq_pt_minmax_qdq_fused': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P, _P]),
-    'cnnq_p2p_window_bytes': (ctypes.c_size_t, [_I, _I]),
-    'cnnq_p2p_alloc': (_I, [_I, _I, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p]),
-    'cnnq_p2p_open': (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
-    'cnnq_p2p_close': (_I, [_P]),
-    'cnnq_p2p_free': (_I, [_P]),
-    'cnnq_p2p_all_gather': (_I, [_P, _I, _P, _I, _I, _I, ctypes.c_uint32, _P, _P, _P]),
+    'cnnq_xrank_open': (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
+    'cnnq_xrank_close': (_I, [_P]),
+    'cnnq_xrank_free': (_I, [_P]),
     'cnnq_kld_hist': (_I, [_P, _L, _L, _P, _P, _P]),
     'cnnq_kld_search': (_I, [_P, _L, _P, _P, _P, _P]),
 }

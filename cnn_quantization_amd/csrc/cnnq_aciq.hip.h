@@ -30,6 +30,17 @@
 
 namespace {
 
+// The bit allocation alone (the fixed-target iteration of k_params): what the single-launch kernels below need from the
+// whole table before they start.  (Tried and dropped: the merge of the pass-A records and this allocation in ONE launch -
+// every workgroup merges its channels, the last one to take a ticket allocates, Guideline-16 counter hand-off - ran the b512
+// forward in 13.28 / 13.55 / 13.56 ms against 13.39 / 13.32 / 13.31 ms for the two launches on one box: the release fence
+// and the serial tail cost what the launch boundary does.)
+__global__ void __launch_bounds__(PTPB) k_bitalloc(const float* __restrict__ prior, int C, const cnnq_params_cfg cfg,
+                                                   float* __restrict__ bits_ws) {
+    __shared__ double sh[PTPB / 64];
+    bit_alloc_block(prior, C, cfg, bits_ws, sh);
+}
+
 // a partial sum in a slot: the complement of its bits, NaNs made canonical first (a stored word is never zero: zero
 // means "not arrived"; the sum 0.0 of a dead channel becomes all ones)
 __device__ __forceinline__ unsigned long long slot_of_sum(double s) {

@@ -99,9 +99,22 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 // Cache, so the statistics passes use them only for tensors too large for the next pass to find
 // anything still cached (NT_BYTES).  The Q/DQ pass always uses them: x is read for the last time and
 // y is never re-read by this path.
+// Development knobs (kernel sweeps: tile heights, dispatch orders, ...) exist only in builds with -DCNNQ_DEV_KNOBS
+// (tools/build_alt.sh knobs -DCNNQ_DEV_KNOBS): the shipped library reads them as their defaults, compile-time constants.
+#ifdef CNNQ_DEV_KNOBS
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+#else
+constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
+
 constexpr int64_t NT_BYTES_DEFAULT = (int64_t)384 << 20;   // swept 0..1000 MB on the ResNet-50 set: flat optimum 250-400
-// CNNQ_NT_BYTES overrides it (read once): 0 forces the non-temporal template instances on every tensor, which is how
-// the parity tests reach the instances that otherwise only the > 384 MB layers of the benchmark select
+// CNNQ_NT_BYTES - the ONE environment variable the shipped library reads (once per process; documented in
+// include/cnnq_hip.h): the tensor size above which the read-only passes use non-temporal loads.  It is a property of the
+// part's Infinity Cache, not of the path, hence tunable at deployment; 0 forces the non-temporal template instances on every
+// tensor, which is also how the parity tests reach the instances that otherwise only the > 384 MB layers select.
 inline int64_t nt_bytes() {
     static const int64_t v = [] {
         const char* e = getenv("CNNQ_NT_BYTES");

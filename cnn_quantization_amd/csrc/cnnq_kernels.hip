@@ -44,7 +44,6 @@
 #include "cnnq_group.hip.h"
 #include "cnnq_plan.hip.h"
 #include "cnnq_kld.hip.h"
-#include "cnnq_p2p.hip.h"
 
 extern "C" {
 
@@ -870,8 +869,8 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
         const int threads = (int)(C >= PTPB ? PTPB : ((C + 63) / 64) * 64);
         hipLaunchKernelGGL(k_bitalloc, dim3(1), dim3(threads), 0, st, stats + (size_t)CNNQ_STAT_STD * C, (int)C, *cfg, bits);
         rc = launch_status();
-        if (rc) return rc;
     }
+    if (rc) return rc;
     AciqArgs aa;
     aa.stats = stats;
     aa.bits = bits;
@@ -883,7 +882,7 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
     xo.codes = codes;
     xo.hist = reinterpret_cast<unsigned long long*>(hist_rep);
     xo.packed = nullptr;
-    return launch_aciq(x, y, gp, aa, gws, flags, st, (codes || hist_rep) ? 1 : 0, xo);
+    return launch_aciq(x, y, gp, aa, gws, flags & 3u, st, (codes || hist_rep) ? 1 : 0, xo);
 }
 
 // ... behind ONE call with the chain as the fallback: ws as cnnq_pc_aciq_qdq (cnnq_pc_aciq_workspace bytes); the
@@ -1140,43 +1139,15 @@ int cnnq_kld_search(const uint32_t* hist, int64_t rows, const float* rowmm, doub
     return launch_status();
 }
 
-// ---- peer-to-peer statistics exchange (opt-in; the only entry points that allocate: explicit setup calls) ----
-size_t cnnq_p2p_window_bytes(int world, int slot_floats) {
-    return (world > 0 && slot_floats > 0) ? p2p_window_bytes(world, slot_floats) : 0;
-}
-
-int cnnq_p2p_alloc(int world, int slot_floats, void** window, unsigned char handle[64]) {
-    if (!window || !handle || world <= 0 || slot_floats <= 0) return CNNQ_EINVAL;
-    const size_t bytes = p2p_window_bytes(world, slot_floats);
-    hipError_t e = hipExtMallocWithFlags(window, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemset(*window, 0, bytes);
-    if (e != hipSuccess) return (int)e;
-    hipIpcMemHandle_t h;
-    e = hipIpcGetMemHandle(&h, *window);
-    if (e != hipSuccess) return (int)e;
-    memcpy(handle, &h, 64);
-    return (int)hipDeviceSynchronize();
-}
-
-int cnnq_p2p_open(const unsigned char handle[64], void** window) {
+// ---- the windows of the in-launch cross-rank exchange: a peer's window mapped from its hipIpc handle, unmapped, the own
+//      one released (with cnnq_xrank_alloc the only entry points of the multi-GPU path that allocate or synchronise)
+int cnnq_xrank_open(const unsigned char handle[64], void** window) {
     if (!handle || !window) return CNNQ_EINVAL;
     hipIpcMemHandle_t h;
     memcpy(&h, handle, 64);
     return (int)hipIpcOpenMemHandle(window, h, hipIpcMemLazyEnablePeerAccess);
 }
-
-int cnnq_p2p_close(void* window) { return window ? (int)hipIpcCloseMemHandle(window) : CNNQ_EINVAL; }
-int cnnq_p2p_free(void* window) { return window ? (int)hipFree(window) : CNNQ_EINVAL; }
-
-int cnnq_p2p_all_gather(const float* rec, int nfloat, void* const* windows, int rank, int world, int slot_floats,
-                        uint32_t seq, float* out, int* status, void* stream) {
-    if (!rec || !windows || !out || !status || nfloat <= 0 || nfloat > slot_floats || world <= 0 || rank < 0 ||
-        rank >= world || !seq)
-        return CNNQ_EINVAL;
-    hipLaunchKernelGGL(k_p2p_all_gather, dim3((unsigned)world), dim3(TPB), 0, (hipStream_t)stream, rec, nfloat, windows,
-                       rank, world, slot_floats, seq, out, status);
-    return launch_status();
-}
+int cnnq_xrank_close(void* window) { return window ? (int)hipIpcCloseMemHandle(window) : CNNQ_EINVAL; }
+int cnnq_xrank_free(void* window) { return window ? (int)hipFree(window) : CNNQ_EINVAL; }
 
 }  // extern "C"

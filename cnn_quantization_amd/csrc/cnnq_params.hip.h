@@ -30,7 +30,7 @@ __constant__ float c_gaus[9] = {0.f, 1.24f, 1.71f, 2.15f, 2.55f, 2.93f, 3.28f, 3
 __constant__ float c_gaus_pos[9] = {0.f, 1.71f, 2.15f, 2.55f, 2.93f, 3.28f, 3.61f, 3.92f, 4.2f};
 
 // Fixed-target bit allocation, iq.py:381-407 (fp32 tensor math, double target): `prior` [C] -> bits_ws [C].  One
-// workgroup (blockDim.x a multiple of 64, <= PTPB); ends with a barrier.  Shared by k_params and k_bitalloc.
+// workgroup (blockDim.x a multiple of 64, <= PTPB); ends with a barrier.  Shared by k_params and k_bitalloc (cnnq_aciq.hip.h).
 __device__ __forceinline__ void bit_alloc_block(const float* __restrict__ prior, int C, const cnnq_params_cfg& cfg,
                                                 float* __restrict__ bits_ws, double* sh) {
     const int tid = threadIdx.x;
@@ -156,14 +156,6 @@ __global__ void __launch_bounds__(PTPB) k_params(const float* __restrict__ stats
             diag[(size_t)CNNQ_DIAG_OFFSET * C + c] = r.offset;
         }
     }
-}
-
-// the bit allocation alone: what the single-launch ACIQ kernels need from the whole table before they start (the
-// allocation couples all channels through sum p; everything else of k_params is per channel)
-__global__ void __launch_bounds__(PTPB) k_bitalloc(const float* __restrict__ prior, int C, const cnnq_params_cfg cfg,
-                                                   float* __restrict__ bits_ws) {
-    __shared__ double sh[PTPB / 64];
-    bit_alloc_block(prior, C, cfg, bits_ws, sh);
 }
 
 }  // namespace

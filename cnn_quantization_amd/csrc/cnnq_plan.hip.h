@@ -14,12 +14,6 @@ namespace {
 // ------------------------------------------------------------------------------------------
 int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
-// development knobs (kernel sweeps) come from the environment
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
-
 constexpr int MAXG = 64;   // upper bound on batch splits S (partial groups per channel = S * nb)
 
 // Load shape for a tensor.  For the aligned float4 shape the loads per lane per sample (J) adapt
@@ -152,7 +146,12 @@ int launch_qdq(const float* x, float* y, const Geo& g, const Variant& v, const f
 // ------------------------------------------------------------------------------------------
 // the register-resident single-launch form of config 2 (cnnq_resident.hip.h)
 // ------------------------------------------------------------------------------------------
-constexpr int RES_MIN_WGS = 192;   // below this many workgroups the whole-channel form leaves CUs idle: prefer the group form
+// below this many workgroups the whole-channel form leaves CUs idle: prefer the group form
+inline int res_min_wgs() {
+    static const int v = env_int("CNNQ_RES_MIN_WGS", 192);   // development knob
+    return v;
+}
+#define RES_MIN_WGS res_min_wgs()
 
 struct WPlan {
     int A, T, K;   // parameter sets per float4, threads per workgroup, samples (16-byte loads) per lane
@@ -185,7 +184,8 @@ int plan_whole(int64_t N, int64_t C, int64_t HW, bool aligned16, WPlan* p) {
         if (p->A == 4 && T == 512) continue;   // not instantiated
         if (u > T) continue;
         // at least ~512 contiguous bytes per sample and workgroup when the layer has the channels for it
-        int64_t units = (32 + u - 1) / u;
+        static const int min_f4 = env_int("CNNQ_RES_UNITS", 32);   // development knob: float4 per sample and workgroup
+        int64_t units = (min_f4 + u - 1) / u;
         if (units > T / u) units = T / u;
         if (units * m > C) units = (C + m - 1) / m;
         if (units * m > MAXCH) units = MAXCH / m;
@@ -414,9 +414,8 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     w.gstride = p.gstride;
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
     // the slot meeting (cnnq_group.hip.h): +11 % on the packed output at b512 (nothing hides its waits there), +-0.5 % on the
-    // b512 / b64 steps with y to write; CNNQ_MEET_SLOTS = 0: the counter meeting (A/B)
-    static const int meet_slots = env_int("CNNQ_MEET_SLOTS", 1);
-    if (meet_slots && (size_t)p.ngroups * p.gstride * 8 <= GRP_WS_SLOT_BYTES) flags |= MMQ_FLAG_SLOTS;
+    // b512 / b64 steps with y to write; MMQ_FLAG_COUNTERS (tests, A/B): the counter meeting of round 2
+    if (!(flags & MMQ_FLAG_COUNTERS) && (size_t)p.ngroups * p.gstride * 8 <= GRP_WS_SLOT_BYTES) flags |= MMQ_FLAG_SLOTS;
     if (p.flat) {
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
         static const int pk_narrow = env_int("CNNQ_PK_NARROW", 0);          // development knob: the 2-byte stores of round 3

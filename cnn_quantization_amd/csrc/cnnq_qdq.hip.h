@@ -36,7 +36,8 @@ __device__ __forceinline__ float qdq1(float x, float scale, float zp, float qmax
 // quotient against the C divide; the -m gpu parity tests compare whole tensors with the CPU restatement bit for bit.
 constexpr unsigned MMQ_FLAG_TEST_HOOK = 1u;     // group kernels: skip the wait, recompute (tests)
 constexpr unsigned MMQ_FLAG_IEEE_DIVIDE = 2u;   // every channel through the hardware divide (tests, A/B: CNNQ_IEEE_DIVIDE=1)
-constexpr unsigned MMQ_FLAG_SLOTS = 16u;        // k_mmq_flat: the slot meeting (cnnq_group.hip.h; CNNQ_MEET_SLOTS)
+constexpr unsigned MMQ_FLAG_SLOTS = 16u;        // internal: the slot meeting (cnnq_group.hip.h), set by launch_group
+constexpr unsigned MMQ_FLAG_COUNTERS = 32u;     // public (tests, A/B): the counter meeting of round 2 instead of the slot meeting
 constexpr unsigned MMQ_FLAG_PK_PLAIN = 8u;      // OUT = 2 (development, CNNQ_PK_PLAIN=1): plain instead of non-temporal wide stores
 constexpr unsigned MMQ_FLAG_PK_NARROW = 4u;     // OUT = 2: the packed buffer is not 16-byte aligned (or CNNQ_PK_NARROW=1): one 2-byte store per float4
 

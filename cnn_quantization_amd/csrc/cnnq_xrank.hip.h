@@ -1,5 +1,5 @@
 // cnnq_xrank.hip.h - config 2 in ONE launch and ONE read of x when the batch is sharded over W GPUs (opt-in; the default
-// multi-GPU form stays statistics pass -> RCCL all_gather -> Q/DQ pass, 12 bytes per element).  Part of the single
+// multi-GPU form is statistics pass -> RCCL all_gather -> Q/DQ pass, 12 bytes per element).  Part of the single
 // translation unit cnnq_kernels.hip.
 //
 // The single-launch kernels (k_mmq_whole / k_mmq_group / k_mmq_flat) hold their tile of x in registers between the
@@ -7,7 +7,7 @@
 // thread that finishes a channel's LOCAL extrema
 //   push   stores the COMPLEMENT of its {min, max} pair (NaNs canonical: never zero) into the slot
 //          [parity][own rank][channel] of EVERY rank's window - fine-grained device memory exported with hipIpc and mapped
-//          by all peers, the windows of cnnq_p2p.hip.h's kind (only the workgroup that is member 0 of the channel's
+//          by all peers (cnnq_xrank_alloc / cnnq_xrank_open) - (only the workgroup that is member 0 of the channel's
 //          group pushes; every member knows the same local extrema).  One 8-byte store per destination and nothing to
 //          wait for: the pair IS the signal (round 4, as in the local slot meeting; round 3 sent pair -> drain -> sequence
 //          number, one more remote round trip per launch);

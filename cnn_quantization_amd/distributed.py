@@ -1,6 +1,8 @@
 """Multi-GPU layer: one process per GPU (torchrun), activations sharded along the batch, and ONE
 small exchange per statistics pass over RCCL/xGMI (torch.distributed backend "nccl" is RCCL on
-ROCm; the CPU tests drive the same code over gloo).
+ROCm; the CPU tests drive the same code over gloo).  Two routes for config 2, and only two: the collective (default:
+statistics launch -> ncclAllGather on the compute stream -> Q/DQ launch) and, opt-in, the exchange inside the single launch
+(XRankExchange: x is read once).
 
 The reference has no counterpart: its DataParallel replicas each quantize with the statistics
 of their own sub-batch (inference/inference_sim.py:196-200).  Here every rank ends up with the
@@ -42,17 +44,13 @@ def shard_batch(n, rank_, world):
 
 
 def all_gather_records(rec, group=None, out=None):
-    """rec [K, C] on every rank -> [W, K, C] in rank order (the G axis cnnq_pc_combine merges): the verified
-    peer-to-peer exchange when CNNQ_P2P_EXCHANGE=1 (or CNNQ_XRANK=1), otherwise the backend's all_gather.  `out`: optional
-    preallocated [W, K, C] result (collective path only)."""
-    ex = p2p_exchange(group)
-    if ex is not None and ex.fits(rec):
-        return ex.all_gather(rec)
+    """rec [K, C] on every rank -> [W, K, C] in rank order (the G axis cnnq_pc_combine merges): RCCL's all_gather enqueued
+    directly on the caller's stream when the backend is `nccl` (rccl.py), else torch.distributed's (gloo rigs).  `out`:
+    optional preallocated [W, K, C] result."""
     return collective_all_gather(rec, group, out)
 
 
 def collective_all_gather(rec, group=None, out=None):
-    """all_gather_records through torch.distributed (RCCL / gloo)."""
     w = world_size(group)
     rec = rec.contiguous()
     if out is None:
@@ -73,33 +71,32 @@ def collective_all_gather(rec, group=None, out=None):
     return out
 
 
-def all_gather_records_async(rec, group=None):
-    """Non-blocking all_gather_records: returns (out [W, K, C], work).  The collective runs on the backend's
-    own stream (RCCL) while the caller keeps enqueuing kernels; `work.wait()` orders the caller's stream
-    behind it."""
-    w = world_size(group)
-    rec = rec.contiguous()
-    out = torch.empty((w,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
-    try:
-        work = dist.all_gather_into_tensor(out.view(-1), rec.view(-1), group=group, async_op=True)
-    except RuntimeError:
-        work = dist.all_gather([out[i] for i in range(w)], rec, group=group, async_op=True)
-    return out, work
+class XRankExchange:
+    """The windows of the IN-LAUNCH cross-rank exchange of config 2 (csrc/cnnq_xrank.hip.h, cnnq_pc_minmax_qdq_xrank_dev): with
+    the batch sharded over the ranks of `group` (one process per GPU, one node), the single-launch kernels push their
+    channels' extrema into every rank's window and wait for the others' inside the launch - x is read once, 8 instead of
+    12 bytes per element.
 
-
-class P2PExchange:
-    """One-shot all-gather of small fp32 records over xGMI peer-to-peer stores (cnnq_p2p_*), an opt-in
-    alternative to the RCCL all_gather for the per-layer statistics exchange: one post kernel + one wait
-    kernel on the caller's stream, no collective launch, no stream hop.  One process per GPU, all ranks
-    of `group` on one node.  `verify()` cross-checks it against the group's own all_gather and must be
-    called once before use; on any failure the caller keeps RCCL."""
-    SLOT_FLOATS = 32768                                 # 128 KB: fp64 moment records [7][C] up to C = 2340
-    CHECK_EVERY = 4096                                  # exchanges between two host checks of the status word
+    OPT-IN (xrank_mode: CNNQ_XRANK=1 / auto, or set_xrank_mode): a rank that waits for a peer spins INSIDE the kernel, bounded
+    by `timeout` (default 60 s of the 100 MHz clock: the order of a collective's timeout, since host-side skew between the
+    ranks - a data loader, a checkpoint - turns into waiting time here); when the bound expires that rank's outputs of the
+    launch are NaN, the status word is raised and every later wait gives up at once.  The caller must then agree over the
+    group and fall back to the collective (disable_xrank, as bench.py does); minmax_qdq raises CnnqError at its periodic
+    check, and healthy() is the synchronising check to run at the program's own synchronisation points and AFTER REPLAYS
+    of a captured graph (a replay never passes through this class, so nothing else would notice).  `verify()` cross-checks
+    the exchange against the collective path on every rank and must pass before use.  One stream per group, every rank issues
+    the same launches in the same order.  Launches CAN be captured into a HIP graph (the sequence number is a device word);
+    the windows of an exchange whose launches were captured stay mapped after close() so that a stale replay cannot fault."""
+    CMAX = 4096                                         # channels per (parity, rank) record block: 1 MB at 8 ranks
+    TIMEOUT_TICKS = 6000000000                          # 60 s of the 100 MHz clock
+    CHECK_EVERY = 64                                    # launches between two host checks of the status word (about one per
+                                                        # ResNet-50 forward)
 
     def __init__(self, group=None):
         """Collective: every rank of `group` must call it.  Local failures (allocation, IPC export / import)
         never skip a collective step; `self.ok` is the group-wide verdict (all ranks agree on it)."""
         import ctypes
+        import os
         from . import _lib as L
         self.group, self.L, self.lib = group, L, L.load()
         self.world, self.rank = world_size(group), rank(group)
@@ -109,7 +106,7 @@ class P2PExchange:
         handle = ctypes.create_string_buffer(64)
         local_ok = True
         try:
-            self._alloc_window(own, handle)
+            L.check(self.lib.cnnq_xrank_alloc(self.world, self.CMAX, ctypes.byref(own), handle), 'cnnq_xrank_alloc')
             self.own = own
         except Exception as e:
             local_ok, self.why = False, str(e)
@@ -123,24 +120,26 @@ class P2PExchange:
                         ptrs.append(own.value)
                         continue
                     w = ctypes.c_void_p()
-                    L.check(self.lib.cnnq_p2p_open(ctypes.create_string_buffer(h, 64), ctypes.byref(w)), 'cnnq_p2p_open')
+                    L.check(self.lib.cnnq_xrank_open(ctypes.create_string_buffer(h, 64), ctypes.byref(w)), 'cnnq_xrank_open')
                     self.mapped.append(w)
                     ptrs.append(w.value)
             except Exception as e:
                 local_ok, self.why = False, str(e)
         else:
             local_ok = False
-        self.ok = self._all_agree(local_ok)             # also: every window is mapped before anyone posts
+        self.ok = self._all_agree(local_ok)             # also: every window is mapped before anyone pushes
         if self.ok:
             self.windows = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
         self.calls = 0
+        self.captured = 0                               # launches recorded into HIP graphs
         self.stream = None
-
-    def _alloc_window(self, own, handle):
-        import ctypes
-        self.L.check(self.lib.cnnq_p2p_alloc(self.world, self.SLOT_FLOATS, ctypes.byref(own), handle), 'cnnq_p2p_alloc')
+        ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
+        self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
+        self.seq_dev = None                             # the device-side sequence word (allocated at the first launch)
+        fa = os.environ.get('CNNQ_XRANK_TEST_FAIL_AT')    # tests: rank 0 reports an expired wait at its n-th launch
+        self.fail_at = int(fa) if (fa and self.rank == 0) else 0
 
     def _all_agree(self, flag):
         """Group-wide AND of a local boolean (a collective)."""
@@ -152,46 +151,18 @@ class P2PExchange:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(t.item()))
 
-    def fits(self, rec):
-        return rec.is_cuda and rec.element_size() % 4 == 0 and rec.numel() * rec.element_size() <= 4 * self.SLOT_FLOATS
-
-    def all_gather(self, rec):
-        """rec [K, C] (fp32 / fp64 / int32 / int64: moved as 32-bit words) on every rank -> [W, K, C] in rank
-        order; enqueued on the current stream."""
-        import ctypes
-        rec = rec.contiguous()
-        if not self.fits(rec):
-            raise self.L.CnnqError('P2PExchange carries device records of at most %d bytes' % (4 * self.SLOT_FLOATS))
-        n = rec.numel() * rec.element_size() // 4
-        cur = torch.cuda.current_stream(rec.device)
-        # the two-parity slot reuse is only safe for exchanges that are stream-ordered on every rank, and the
-        # sequence number is a host counter (a graph replay would freeze it): one stream, never under capture
-        if torch.cuda.is_current_stream_capturing():
-            raise self.L.CnnqError('P2PExchange cannot be captured into a HIP graph (host-side sequence number)')
-        if self.stream is None:
-            self.stream = cur.cuda_stream
-        elif self.stream != cur.cuda_stream:
-            raise self.L.CnnqError('P2PExchange is bound to the stream of its first exchange; use one stream per group')
-        out = torch.empty((self.world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
-        self.seq += 1
-        self.calls += 1
-        if self.calls % self.CHECK_EVERY == 0 and not self.healthy():      # periodic host check (synchronises)
-            raise self.L.CnnqError('P2PExchange: a wait timed out (a peer did not post); results since the last check '
-                                   'are invalid')
-        st = ctypes.c_void_p(cur.cuda_stream)
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
-        self.L.check(self.lib.cnnq_p2p_all_gather(p(rec), n, p(self.windows), self.rank, self.world, self.SLOT_FLOATS,
-                                                  self.seq, p(out), p(self.status), st), 'cnnq_p2p_all_gather')
-        return out
+    def fits(self, C):
+        return 0 < C <= self.CMAX
 
     def healthy(self):
-        """Host check (synchronises): no wait has timed out so far."""
+        """Host check (synchronises): no wait for a peer has expired so far.  Call it at synchronisation points and after
+        replays of a graph that holds exchange launches."""
         return int(self.status.item()) == 0
 
     def healthy_so_far(self):
-        """The periodic check of the hot path WITHOUT a synchronisation (round 4): the status word is copied to pinned host
-        memory behind the launches enqueued so far, and what the PREVIOUS copy brought back is looked at once its event
-        has completed - an expired wait is noticed one interval later than with healthy(), the GPU never drains for it."""
+        """The periodic check of the hot path WITHOUT a synchronisation: the status word is copied to pinned host memory
+        behind the launches enqueued so far, and what the PREVIOUS copy brought back is looked at once its event has
+        completed - an expired wait is noticed one interval later than with healthy(), the GPU never drains for it."""
         snap = getattr(self, '_snap', None)
         ok = True
         if snap is not None and snap[1].query():
@@ -206,71 +177,12 @@ class P2PExchange:
         self._snap = snap
         return ok
 
-    def verify(self, rounds=64):
-        """Random records of varying size through both paths; True iff every round matches bit for bit."""
-        g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
-        ok = True
-        for i in range(rounds):
-            c = (1, 7, 64, 256, 2048, 4096)[i % 6]
-            rec = torch.randn((2, c), generator=g, device=self.device)
-            if i % 3 == 2:
-                rec = rec.double()
-            ref = collective_all_gather(rec, self.group)
-            got = self.all_gather(rec)
-            ok = ok and bool(torch.equal(ref, got))
-        return self._all_agree(ok and self.healthy())
-
-    def close(self):
-        """Collective: unmap the peers' windows and free the own one once nobody uses them any more."""
-        torch.cuda.synchronize()
-        dist.barrier(group=self.group)
-        for w in self.mapped:
-            self.lib.cnnq_p2p_close(w)
-        if self.own is not None:
-            self.lib.cnnq_p2p_free(self.own)
-        self.mapped, self.own, self.ok = [], None, False
-        for cache in (_P2P, _XRANK):                     # a closed exchange must not be handed out again
-            for k in [k for k, v in cache.items() if v is self]:
-                del cache[k]
-        from . import ops
-        ops.release_plans()                              # ... nor stay in a cached plan of the hot call
-
-
-class XRankExchange(P2PExchange):
-    """The windows of the IN-LAUNCH cross-rank exchange of config 2 (csrc/cnnq_xrank.hip.h, cnnq_pc_minmax_qdq_xrank): with
-    the batch sharded over the ranks of `group` (one process per GPU, one node), the single-launch kernels push their
-    channels' extrema into every rank's window and wait for the others' inside the launch - x is read once, 8 instead of
-    12 bytes per element.  Opt-in (CNNQ_XRANK=1); `verify()` cross-checks it against the collective path on every rank
-    and must pass before use.  Same rules as P2PExchange - one stream, every rank issues the same calls in the same order -
-    except that its launches CAN be captured into a HIP graph (round 4: the sequence number is a device word)."""
-    CMAX = 4096                                         # channels per (parity, rank) record block: 1 MB at 8 ranks
-    TIMEOUT_TICKS = 200000000                           # 2 s of the 100 MHz clock
-    CHECK_EVERY = 64                                    # launches between two host checks of the status word (about one per
-                                                        # ResNet-50 forward): an expired peer wait poisons that rank's y / qp
-                                                        # with NaN while its peers finish, so the ranks diverge until the check
-
-    def __init__(self, group=None):
-        super().__init__(group)
-        import os
-        ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
-        self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
-        self.seq_dev = None                             # the device-side sequence word (allocated at the first launch)
-        fa = os.environ.get('CNNQ_XRANK_TEST_FAIL_AT')    # tests: rank 0 reports an expired wait at its n-th launch
-        self.fail_at = int(fa) if (fa and self.rank == 0) else 0
-
-    def _alloc_window(self, own, handle):
-        import ctypes
-        self.L.check(self.lib.cnnq_xrank_alloc(self.world, self.CMAX, ctypes.byref(own), handle), 'cnnq_xrank_alloc')
-
-    def fits(self, C):
-        return 0 < C <= self.CMAX
-
     def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st, codes=None, hist_rep=None):
         """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm (the GLOBAL extrema) land at the
         start of the workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes).  codes / hist_rep: this rank's codes and
         code counts (the replica tables of the single-launch kernels).  The launch's sequence number lives in device memory
         (cnnq_pc_minmax_qdq_xrank_dev), so the call may be captured into a HIP graph - every rank then replays its graph
-        the same number of times."""
+        the same number of times, and checks healthy() after its replays."""
         capturing = torch.cuda.is_current_stream_capturing()
         if self.stream is None:
             self.stream = st
@@ -282,6 +194,7 @@ class XRankExchange(P2PExchange):
             self.seq_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq += 1                                   # launches ENQUEUED here (a replayed graph advances the device word, not this)
         self.calls += 1
+        self.captured += 1 if capturing else 0
         if not capturing and self.calls % self.CHECK_EVERY == 0 and not self.healthy_so_far():      # periodic host check (no synchronisation)
             raise self.L.CnnqError('XRankExchange: a wait for a peer expired; results since the last check are invalid')
         if self.fail_at and self.calls == self.fail_at:
@@ -293,9 +206,6 @@ class XRankExchange(P2PExchange):
                                                    hist_rep.data_ptr() if hist_rep is not None else None, st)
         if rc:
             self.L.check(rc, 'cnnq_pc_minmax_qdq_xrank_dev')
-
-    def all_gather(self, rec):
-        raise self.L.CnnqError('XRankExchange carries channel extrema inside the config-2 launch only')
 
     def verify(self, rounds=12):
         """Config 2 of random shards through the in-launch exchange and through the collective path, bit for bit, on
@@ -313,23 +223,54 @@ class XRankExchange(P2PExchange):
             ok = ok and bool(torch.equal(ref, got))
         return self._all_agree(ok and self.healthy())
 
+    def close(self):
+        """Collective: unmap the peers' windows and free the own one once nobody uses them any more.  When launches of this
+        exchange were captured into HIP graphs the windows stay mapped (a few MB, for the life of the process): a replay of
+        such a graph after close() must not fault - it finds no peer, its waits expire and it reports through its status
+        word like any other expired wait."""
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        if not self.captured:
+            for w in self.mapped:
+                self.lib.cnnq_xrank_close(w)
+            if self.own is not None:
+                self.lib.cnnq_xrank_free(self.own)
+        self.mapped, self.own, self.ok = [], None, False
+        for k in [k for k, v in _XRANK.items() if v is self]:    # a closed exchange must not be handed out again
+            del _XRANK[k]
+        from . import ops
+        ops.release_plans()                              # ... nor stay in a cached plan of the hot call
 
-_P2P = {}
+
 _XRANK = {}
+_XRANK_MODE = None
+
+
+def set_xrank_mode(mode):
+    """'0' / '1' / 'auto' for this process (overrides CNNQ_XRANK; None: back to the environment).  A program that sets
+    '1' or 'auto' takes on the recovery: agree over the group when a wait expired, disable_xrank, redo the work."""
+    global _XRANK_MODE
+    if mode not in (None, '0', '1', 'auto'):
+        raise ValueError(mode)
+    _XRANK_MODE = mode
+    from . import ops
+    ops.reload_switches()
 
 
 def xrank_mode():
-    """CNNQ_XRANK: '0' never; '1' whenever a group exchanges (also ranks that share a GPU, also a forced 1-rank exchange);
-    'auto' (default, round 4): when the group has several ranks and one GPU per rank (backend nccl = RCCL) - ranks that
-    share a device cannot count on their launches running together."""
+    """Which exchange a batch-sharded config 2 uses.  '0' (DEFAULT): the collective - statistics launch, RCCL all_gather on
+    the compute stream, Q/DQ launch; host-side skew between the ranks is harmless there.  '1': the in-launch exchange whenever
+    a group exchanges (also ranks that share a GPU, also a forced 1-rank exchange).  'auto': the in-launch exchange when the
+    group has several ranks and one GPU per rank (backend nccl = RCCL) - ranks that share a device cannot count on their
+    launches running together.  From set_xrank_mode, else CNNQ_XRANK."""
     import os
-    m = os.environ.get('CNNQ_XRANK', 'auto')
-    return m if m in ('0', '1') else 'auto'
+    m = _XRANK_MODE if _XRANK_MODE is not None else os.environ.get('CNNQ_XRANK', '0')
+    return m if m in ('1', 'auto') else '0'
 
 
 def xrank_exchange(group=None):
-    """The process-wide XRankExchange of `group` when CNNQ_XRANK allows it (xrank_mode) and it verified against the collective
-    path on every rank; else None (the collective).  World size 1 only with CNNQ_XRANK=1 under CNNQ_FORCE_EXCHANGE=1 (timing
+    """The process-wide XRankExchange of `group` when xrank_mode allows it and it verified against the collective
+    path on every rank; else None (the collective).  World size 1 only with mode '1' under CNNQ_FORCE_EXCHANGE=1 (timing
     the protocol on a 1-GPU box)."""
     import os
     mode = xrank_mode()
@@ -362,27 +303,6 @@ def disable_xrank(group=None):
     _XRANK[key] = None
     from . import ops
     ops.release_plans()                                  # the hot call's cached plans hold the exchange
-
-
-def p2p_exchange(group=None):
-    """The process-wide P2PExchange of `group` when CNNQ_P2P_EXCHANGE=1 and it verified; else None (RCCL)."""
-    import os
-    # CNNQ_XRANK=1 implies it (round 4): a sharded run that exchanges config 2's extrema inside the launch moves the moment
-    # records of the statistics passes (configs 3 / 4 / 5) through the same kind of window - no collective launch anywhere
-    if (os.environ.get('CNNQ_P2P_EXCHANGE', '0') != '1' and os.environ.get('CNNQ_XRANK', 'auto') != '1') or world_size(group) == 1:
-        return None
-    # keyed by the group's membership, not by id(group): a new group object may reuse a collected one's id
-    key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
-    if key not in _P2P:
-        ex = P2PExchange(group)                          # collective; never raises for a local failure
-        good = ex.ok and ex.verify()
-        if not good:
-            if rank(group) == 0:
-                print('cnn_quantization_amd: peer-to-peer exchange unavailable or not verified (%s); using the '
-                      'collective' % (ex.why or 'see other ranks',))
-            ex.close()
-        _P2P[key] = ex if good else None
-    return _P2P[key]
 
 
 def gather_counts(n, device, group=None):

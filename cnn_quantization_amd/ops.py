@@ -4,7 +4,6 @@ current HIP stream go straight to libcnnq_hip.so.  torch supplies memory and str
 No function here synchronises with the host; none has a CPU path - CPU tensors are rejected
 and a missing library raises (cnn_quantization_amd._lib.load)."""
 import ctypes
-import math
 import os
 
 import torch
@@ -44,14 +43,12 @@ def _dev_f32(x, what='tensor'):
 # switches, read ONCE at import (the hot call used to look three of them up per tensor: weak #10 of the round-2
 # review); reload_switches() re-reads them for callers that change the environment afterwards (tests, tools)
 def reload_switches():
-    global _RESIDENT, _SINGLE_CODES, _EXCHANGE_OVERLAP, _P2P_EXCHANGE, _DIRECT_RCCL, _PT_FUSED, _XRANK_ON, _ACIQ_SINGLE
+    global _RESIDENT, _SINGLE_CODES, _DIRECT_RCCL, _PT_FUSED, _XRANK_ON, _ACIQ_SINGLE
     _ACIQ_SINGLE = os.environ.get('CNNQ_ACIQ_SINGLE', '1') != '0'      # 0: the ACIQ path always takes the five-launch chain (A/B)
-    _XRANK_ON = os.environ.get('CNNQ_XRANK', 'auto') != '0'           # sharded config 2 exchanges INSIDE the single launch when D.xrank_exchange says so (auto: one GPU per rank, verified)
+    _XRANK_ON = D.xrank_mode() != '0'                                  # opt-in (CNNQ_XRANK=1 / auto, D.set_xrank_mode): sharded config 2 exchanges INSIDE the single launch
     _PT_FUSED = os.environ.get('CNNQ_PT_FUSED', '0') == '1'           # 1: config 1 in one launch (slower: see ops.minmax_qdq_per_tensor)
     _RESIDENT = os.environ.get('CNNQ_RESIDENT', '1') != '0'            # 0: never take a single-launch kernel
     _SINGLE_CODES = os.environ.get('CNNQ_SINGLE_CODES', '1') != '0'    # 0: codes / entropy requests take the chain
-    _EXCHANGE_OVERLAP = os.environ.get('CNNQ_EXCHANGE_OVERLAP', '0') == '1'
-    _P2P_EXCHANGE = os.environ.get('CNNQ_P2P_EXCHANGE', '0')
     _DIRECT_RCCL = os.environ.get('CNNQ_DIRECT_RCCL', '1')
     _XPLAN.clear()
 
@@ -526,24 +523,46 @@ def minmax_quantize_pack4(x, num_bits=4, positive=False, out=None):
     return packed, qp
 
 
+def _cfg2_workspace_bytes(lib, N, C, HW):
+    wplan = _WS_BYTES.get((N, C, HW))
+    nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
+    if nbytes == 0:
+        L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    return nbytes
+
+
 def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, want_entropy=False, out=None,
                      want_parts=False, group=None, _checked=False, chain=False, _xrank=None):
-    """Config 2 (cnnq_pc_minmax_qdq): exact per-channel min/max partials -> parameter table (one tiny
-    launch) -> fused Q/DQ in descending address order; no host sync.
+    """Config 2 (iq.py:409-451, 557-603): dynamic per-channel min/max -> scale / zero point -> Q/DQ; no host sync.
+    Three routes, one function each:
 
-    World size > 1 (x is this rank's batch shard): the local extrema [2, C] are all-gathered and the
-    parameter kernel reduces the W gathered pairs instead - exact, so the result is bit-identical to
-    a single GPU holding the whole batch.
+    * one GPU (_minmax_qdq_local): a single launch that reads x once where the shape has one, else the three-launch
+      chain (k_minmax -> k_minmax_params -> k_qdq);
+    * the batch sharded over the ranks of `group`, x this rank's shard (world size > 1, or CNNQ_FORCE_EXCHANGE=1 on a
+      1-rank group): the collective route (_minmax_qdq_collective, default: statistics launch -> all_gather of the local
+      extrema [2, C] -> parameters + Q/DQ launch), or - opt-in, D.xrank_mode - the exchange inside the single launch
+      (_minmax_qdq_xrank).  Extrema are exact, so every rank gets the bits of one GPU holding the whole batch.
 
-    chain=True forces the three-launch chain (k_minmax -> k_minmax_params -> k_qdq) where a single-launch kernel
-    would otherwise run: the reference form the single-launch kernels are tested against."""
-    lib = L.load()
+    chain=True forces the three-launch chain where a single-launch kernel would otherwise run: the reference form the
+    single-launch kernels are tested against.  _xrank: an XRankExchange to use (its verify()), False: never."""
     if not _checked:
         x = _dev_f32(x, 'x')
     world = D.world_size(group)
-    exchanging = world > 1 or D.forced_exchange()
+    if not (world > 1 or D.forced_exchange()):
+        return _minmax_qdq_local(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, chain)
     resident = _RESIDENT and not chain
-    if not exchanging and not (want_codes or want_entropy or want_parts):
+    if _xrank is not False and (_xrank is not None or _XRANK_ON) and not ((want_codes or want_entropy) and num_bits > 8):
+        res = _minmax_qdq_xrank(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, group, resident, _xrank)
+        if res is not None:
+            return res
+    return _minmax_qdq_collective(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, group, world, resident)
+
+
+def _minmax_qdq_local(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, chain):
+    """Config 2 on one GPU."""
+    lib = L.load()
+    resident = _RESIDENT and not chain
+    if not (want_codes or want_entropy or want_parts):
         # the hot call: one C entry point, one cached workspace, no torch allocation besides the result
         key = (N, C, HW)
         plan = _WS_BYTES.get(key)
@@ -568,82 +587,112 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         if rc:
             L.check(rc, 'cnnq_pc_minmax_qdq_auto')
         return y
-    if exchanging and _xrank is not False and (_xrank is not None or _XRANK_ON) and not ((want_codes or want_entropy) and num_bits > 8):
-        # CNNQ_XRANK=auto / 1 (D.xrank_mode; verified against the collective at first use): the exchange happens INSIDE the single
-        # launch - x is read once (csrc/cnnq_xrank.hip.h); every rank takes this branch or none does.  Round 4: also with
-        # the codes / the entropy of the codes / the parameters wanted (the ranks' code counts are summed afterwards)
-        st = _raw_stream(x.device.index)
-        if _xrank is None and resident and not (want_codes or want_entropy or want_parts):
-            # the sharded hot call: everything that does not change from call to call is looked up once (the exchange of the
-            # group, the workspaces); D.disable_xrank / release_plans() drop the plans
-            key = ('xr', id(group), x.device.index, st, N, C, HW)
-            plan = _XPLAN.get(key)
-            if plan is None and not torch.cuda.is_current_stream_capturing():    # (a capture-time scratch buffer is never cached)
-                xr = D.xrank_exchange(group)
-                plan = False
-                if xr is not None and xr.fits(C):
-                    wplan = _WS_BYTES.get((N, C, HW))
-                    nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
-                    if nbytes == 0:
-                        L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
-                    plan = (xr, group, _scratch(x, 'cfg2', nbytes, st), _group_workspace(x, st))
-                _XPLAN[key] = plan
-            if plan:
-                y = _out_like(x, out)
-                plan[0].minmax_qdq(x, y, N, C, HW, num_bits, positive, plan[2].data_ptr(), plan[3], GROUP_WS_BYTES, st)
-                return y
-            xr = None if plan is False else D.xrank_exchange(group)
-        else:
-            xr = _xrank if _xrank is not None else D.xrank_exchange(group)
-        hist_rep = _hist_replicas(x, st) if (want_entropy and xr is not None) else None
-        if xr is not None and xr.fits(C) and not (want_entropy and hist_rep is None):
-            wplan = _WS_BYTES.get((N, C, HW))
-            nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
-            if nbytes == 0:
-                L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    if resident and not want_codes and not want_entropy:
+        res = minmax_qdq_resident(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
+        if res is None:
+            res = minmax_qdq_group(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
+        if res is not None:
+            return res
+    if resident and _SINGLE_CODES:
+        # codes / entropy out of the single launch too (round 3): no chain, no memset
+        res = minmax_qdq_single(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out, want_parts=want_parts)
+        if res is not None:
+            return res
+    y = _out_like(x, out)
+    G = max(lib.cnnq_pc_groups(N, C, HW, 1), lib.cnnq_pc_groups(N, C, HW, 0))
+    if G <= 0:
+        L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    pmm = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
+    qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device)
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+    hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
+    L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
+                                   _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
+    res = [y]
+    if want_codes:
+        res.append(codes)
+    if want_entropy:
+        res.append(entropy_from_hist(hist))
+    if want_parts:
+        g_used = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+        stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
+        stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
+        stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]
+        res.append(dict(stats=stats, qp=qp, diag=None))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def _minmax_qdq_xrank(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, group, resident, _xrank):
+    """Config 2 of a batch shard with the cross-rank exchange INSIDE the single launch (csrc/cnnq_xrank.hip.h; opt-in,
+    verified against the collective at first use): x is read once; every rank takes this route or none does.  Also with
+    the codes / the entropy of the codes / the parameters wanted (the ranks' code counts are summed afterwards).  None: this
+    group has no (verified) in-launch exchange - the caller takes the collective."""
+    lib = L.load()
+    st = _raw_stream(x.device.index)
+    if _xrank is None and resident and not (want_codes or want_entropy or want_parts):
+        # the sharded hot call: everything that does not change from call to call is looked up once (the exchange of the
+        # group, the workspaces); D.disable_xrank / release_plans() drop the plans
+        key = ('xr', id(group), x.device.index, st, N, C, HW)
+        plan = _XPLAN.get(key)
+        if plan is None and not torch.cuda.is_current_stream_capturing():    # (a capture-time scratch buffer is never cached)
+            xr = D.xrank_exchange(group)
+            plan = False
+            if xr is not None and xr.fits(C):
+                plan = (xr, group, _scratch(x, 'cfg2', _cfg2_workspace_bytes(lib, N, C, HW), st), _group_workspace(x, st))
+            _XPLAN[key] = plan
+        if plan:
             y = _out_like(x, out)
-            gws = _group_workspace(x, st) if resident else None
-            ws = _scratch(x, 'cfg2', nbytes, st)
-            codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
-            xr.minmax_qdq(x, y, N, C, HW, num_bits, positive, ws.data_ptr(), gws,
-                          GROUP_WS_BYTES if gws is not None else 0, st, codes=codes, hist_rep=hist_rep)
-            if not (want_codes or want_entropy or want_parts):
-                return y
-            res = [y]
-            if want_codes:
-                res.append(codes)
-            if want_entropy:
-                hist = torch.zeros(256, dtype=torch.int64, device=x.device)
-                L.check(lib.cnnq_hist_replicas_fold(_ptr(hist_rep), _ptr(hist), st), 'cnnq_hist_replicas_fold')
-                D.all_reduce_sum_(hist, group)                       # the global batch's code counts
-                res.append(entropy_from_hist(hist))
-            if want_parts:
-                tab = ws[:4 * (L.NQP + 2) * C].view(torch.float32).view(L.NQP + 2, C).clone()    # qp rows, then the global {min, max}
-                stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
-                stats[L.STAT_MIN] = tab[L.NQP]
-                stats[L.STAT_MAX] = tab[L.NQP + 1]
-                res.append(dict(stats=stats, qp=tab[:L.NQP], diag=None))
-            return res[0] if len(res) == 1 else tuple(res)
-    if (exchanging and not (want_codes or want_entropy or want_parts)
-            and not _EXCHANGE_OVERLAP):
-        # the multi-GPU hot call: local extrema (one C call) -> all_gather of [2, C] -> parameters + Q/DQ (one C
-        # call), all in cached workspaces; the collective is the only torch.distributed call
+            plan[0].minmax_qdq(x, y, N, C, HW, num_bits, positive, plan[2].data_ptr(), plan[3], GROUP_WS_BYTES, st)
+            return y
+        xr = None if plan is False else D.xrank_exchange(group)
+    else:
+        xr = _xrank if _xrank is not None else D.xrank_exchange(group)
+    hist_rep = _hist_replicas(x, st) if (want_entropy and xr is not None) else None
+    if xr is None or not xr.fits(C) or (want_entropy and hist_rep is None):
+        return None
+    y = _out_like(x, out)
+    gws = _group_workspace(x, st) if resident else None
+    ws = _scratch(x, 'cfg2', _cfg2_workspace_bytes(lib, N, C, HW), st)
+    codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
+    xr.minmax_qdq(x, y, N, C, HW, num_bits, positive, ws.data_ptr(), gws,
+                  GROUP_WS_BYTES if gws is not None else 0, st, codes=codes, hist_rep=hist_rep)
+    if not (want_codes or want_entropy or want_parts):
+        return y
+    res = [y]
+    if want_codes:
+        res.append(codes)
+    if want_entropy:
+        hist = torch.zeros(256, dtype=torch.int64, device=x.device)
+        L.check(lib.cnnq_hist_replicas_fold(_ptr(hist_rep), _ptr(hist), st), 'cnnq_hist_replicas_fold')
+        D.all_reduce_sum_(hist, group)                       # the global batch's code counts
+        res.append(entropy_from_hist(hist))
+    if want_parts:
+        tab = ws[:4 * (L.NQP + 2) * C].view(torch.float32).view(L.NQP + 2, C).clone()    # qp rows, then the global {min, max}
+        stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
+        stats[L.STAT_MIN] = tab[L.NQP]
+        stats[L.STAT_MAX] = tab[L.NQP + 1]
+        res.append(dict(stats=stats, qp=tab[:L.NQP], diag=None))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def _minmax_qdq_collective(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, group, world, resident):
+    """Config 2 of a batch shard around a collective: local extrema (one launch) -> all_gather of [2, C] (ncclAllGather
+    enqueued directly on the compute stream, rccl.py; torch.distributed on gloo rigs) -> parameters from the W gathered
+    records + Q/DQ (one launch).  x is read twice (12 bytes per element); host-side skew between the ranks is harmless."""
+    lib = L.load()
+    if not (want_codes or want_entropy or want_parts):
+        # the hot call: two C calls and the collective, all in cached workspaces
         st = _raw_stream(x.device.index)
-        p2p, direct = _P2P_EXCHANGE, _DIRECT_RCCL
-        key = (id(group), x.device.index, st, N, C, HW, world, p2p, direct)
+        key = (id(group), x.device.index, st, N, C, HW, world, _DIRECT_RCCL)
         plan = _XPLAN.get(key)
         if plan is None:
             # everything that does not change from call to call: workspace slices, the gathered buffer, the direct
             # RCCL communicator (created collectively at first use).  The plan keeps `group` alive, so its id stays its
             # own, and its scratch buffers too (a later, larger tensor may make _scratch hand out new ones).
-            wplan = _WS_BYTES.get((N, C, HW))
-            nbytes = wplan[0] if wplan is not None else lib.cnnq_pc_minmax_qdq_workspace(N, C, HW)
-            if nbytes == 0:
-                L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
-            ws = _scratch(x, 'cfg2', nbytes, st)
+            ws = _scratch(x, 'cfg2', _cfg2_workspace_bytes(lib, N, C, HW), st)
             gbuf = _scratch(x, 'gath', 8 * C * world, st)
             dc = None
-            if p2p != '1' and x.is_cuda:
+            if x.is_cuda:
                 from . import rccl
                 dc = rccl.direct_comm(group)
             plan = _XPLAN[key] = dict(
@@ -668,17 +717,6 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
         if rc:
             L.check(rc, 'cnnq_pc_gathered_qdq')
         return y
-    if not exchanging and resident and not want_codes and not want_entropy:
-        res = minmax_qdq_resident(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
-        if res is None:
-            res = minmax_qdq_group(x, N, C, HW, num_bits, positive, out=out, want_parts=want_parts)
-        if res is not None:
-            return res
-    if not exchanging and resident and _SINGLE_CODES:
-        # codes / entropy out of the single launch too (round 3): no chain, no memset
-        res = minmax_qdq_single(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out, want_parts=want_parts)
-        if res is not None:
-            return res
     y = _out_like(x, out)
     G = max(lib.cnnq_pc_groups(N, C, HW, 1), lib.cnnq_pc_groups(N, C, HW, 0))
     if G <= 0:
@@ -687,34 +725,26 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
     qp = torch.empty((L.NQP, C), dtype=torch.float32, device=x.device)
     codes = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_codes else None
     hist = torch.zeros(256, dtype=torch.int64, device=x.device) if want_entropy else None
-    if not exchanging:
-        L.check(lib.cnnq_pc_minmax_qdq(_ptr(x), _ptr(y), N, C, HW, int(num_bits), int(bool(positive)), _ptr(pmm),
-                                       _ptr(qp), _ptr(codes), _ptr(hist), _stream(x)), 'cnnq_pc_minmax_qdq')
-    elif (_EXCHANGE_OVERLAP and C >= 8 and not want_codes and not want_entropy
-          and not want_parts):
-        _minmax_qdq_pipelined(x, y, N, C, HW, num_bits, positive, group)
-    else:
-        g_used = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
-        L.check(lib.cnnq_pc_minmax(_ptr(x), N, C, HW, _ptr(pmm), _stream(x)), 'cnnq_pc_minmax')
-        local = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), g_used, C, _ptr(local), _stream(x)), 'cnnq_pc_minmax_reduce')
-        pmm = D.all_gather_records(local, group)                     # [W, 2, C]
-        L.check(lib.cnnq_pc_minmax_params(_ptr(pmm), world, C, int(num_bits), int(bool(positive)), _ptr(qp),
-                                          _stream(x)), 'cnnq_pc_minmax_params')
-        L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), 1, _stream(x)),
-                'cnnq_pc_qdq')
-        if want_entropy:
-            D.all_reduce_sum_(hist, group)
+    g_used = lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
+    L.check(lib.cnnq_pc_minmax(_ptr(x), N, C, HW, _ptr(pmm), _stream(x)), 'cnnq_pc_minmax')
+    local = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), g_used, C, _ptr(local), _stream(x)), 'cnnq_pc_minmax_reduce')
+    pmm = D.all_gather_records(local, group)                     # [W, 2, C]
+    L.check(lib.cnnq_pc_minmax_params(_ptr(pmm), world, C, int(num_bits), int(bool(positive)), _ptr(qp),
+                                      _stream(x)), 'cnnq_pc_minmax_params')
+    L.check(lib.cnnq_pc_qdq(_ptr(x), _ptr(y), N, C, HW, _ptr(qp), _ptr(codes), _ptr(hist), 1, _stream(x)),
+            'cnnq_pc_qdq')
+    if want_entropy:
+        D.all_reduce_sum_(hist, group)
     res = [y]
     if want_codes:
         res.append(codes)
     if want_entropy:
         res.append(entropy_from_hist(hist))
     if want_parts:
-        g_used = world if exchanging else lib.cnnq_pc_groups(N, C, HW, int(x.data_ptr() % 16 == 0))
         stats = torch.zeros((L.NSTAT, C), dtype=torch.float32, device=x.device)
-        stats[L.STAT_MIN] = pmm[:g_used, 0].min(dim=0)[0]
-        stats[L.STAT_MAX] = pmm[:g_used, 1].max(dim=0)[0]
+        stats[L.STAT_MIN] = pmm[:world, 0].min(dim=0)[0]
+        stats[L.STAT_MAX] = pmm[:world, 1].max(dim=0)[0]
         res.append(dict(stats=stats, qp=qp, diag=None))
     return res[0] if len(res) == 1 else tuple(res)
 
@@ -750,42 +780,6 @@ def minmax_qdq_channel_slice(x, c0, c1, num_bits, positive=False, out=None):
     L.check(lib.cnnq_pc_qdq_strided(_slice_ptr(x, c0, HW), _slice_ptr(y, c0, HW), N, Cs, HW, stride, _ptr(qp), None,
                                     None, 1, st), 'cnnq_pc_qdq_strided')
     return y
-
-
-def _minmax_qdq_pipelined(x, y, N, C, HW, num_bits, positive, group):
-    """World size > 1, CNNQ_EXCHANGE_OVERLAP=1: the channels are cut in two halves; while the first half's
-    local extrema travel (RCCL on its own stream) the second half's statistics pass runs, and while the
-    second half's travel the first half is quantized - the exchange latency leaves the critical path.
-    Same arithmetic, hence the same bits as the unsplit path."""
-    lib = L.load()
-    st = _stream(x)
-    world = D.world_size(group)
-    stride = C * HW
-    m = 4 // math.gcd(HW % 4, 4) if HW % 4 else 1       # channels per 16 bytes: keep both halves aligned
-    ca = (C // 2) - (C // 2) % m
-    halves = [(0, ca), (ca, C)]
-    pending = []
-    for c0, c1 in halves:
-        Cs = c1 - c0
-        G = lib.cnnq_pc_groups(N, Cs, HW, _slice_aligned(x, c0, HW, stride))
-        if G <= 0:
-            L.check(G, 'cnnq_pc_groups(%d,%d,%d)' % (N, Cs, HW))
-        pmm = torch.empty((G, 2, Cs), dtype=torch.float32, device=x.device)
-        local = torch.empty((2, Cs), dtype=torch.float32, device=x.device)
-        L.check(lib.cnnq_pc_minmax_strided(_slice_ptr(x, c0, HW), N, Cs, HW, stride, _ptr(pmm), st),
-                'cnnq_pc_minmax_strided')
-        L.check(lib.cnnq_pc_minmax_reduce(_ptr(pmm), G, Cs, _ptr(local), st), 'cnnq_pc_minmax_reduce')
-        pending.append((c0, Cs) + D.all_gather_records_async(local, group))
-    qps = []
-    for c0, Cs, gathered, work in pending:
-        work.wait()
-        qp = torch.empty((L.NQP, Cs), dtype=torch.float32, device=x.device)
-        L.check(lib.cnnq_pc_minmax_params(_ptr(gathered), world, Cs, int(num_bits), int(bool(positive)), _ptr(qp), st),
-                'cnnq_pc_minmax_params')
-        L.check(lib.cnnq_pc_qdq_strided(_slice_ptr(x, c0, HW), _slice_ptr(y, c0, HW), N, Cs, HW, stride, _ptr(qp), None,
-                                        None, 1, st), 'cnnq_pc_qdq_strided')
-        qps.append(qp)
-    return torch.cat(qps, dim=1)
 
 
 def quantize_pack4(x, qp):

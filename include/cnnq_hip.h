@@ -17,8 +17,11 @@
  *     weights [OFM][IFM*K*K] are the same layout with N = 1, C = OFM;
  *     per-sample statistics of any tensor are the same layout with N = 1, C = samples;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
- *     enqueued, never synchronised; nothing is allocated, no global state is kept, every
- *     function is re-entrant;
+ *     enqueued, never synchronised; nothing is allocated, every function is re-entrant; the
+ *     library keeps no state and reads ONE environment variable, once per process:
+ *     CNNQ_NT_BYTES (default 402653184) - tensors above it are streamed with non-temporal loads
+ *     by the read-only passes (a property of the part's Infinity Cache; 0: always).  The kernel
+ *     sweep knobs of the development builds (-DCNNQ_DEV_KNOBS) do not exist in this library;
  *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
  *     CNNQ_E* for rejected arguments (nothing is enqueued then).
  */
@@ -267,7 +270,7 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
 /* Config 2 in ONE launch and ONE read of x for tensors whose channels span several workgroups (csrc/cnnq_group.hip.h):
  * every workgroup keeps its tile of x in registers; the workgroups that hold pieces of the same channels exchange
  * their {min, max} pairs through `ws` (round 4, the slot meeting: a member's pair is stored once into its zero-at-rest slot
- * and IS its arrival, the members poll the group's slots, the last one to leave zeroes them; CNNQ_MEET_SLOTS=0: write-through
+ * and IS its arrival, the members poll the group's slots, the last one to leave zeroes them; flags bit 5: write-through
  * stores and one arrival counter per channel group as in round 2; either way a bounded wait that falls back to recomputing
  * the extrema from x - never a deadlock, never different bits).
  *   x, y must not overlap (both are read / written through __restrict__ pointers, and a workgroup whose bounded wait
@@ -280,10 +283,15 @@ int cnnq_pc_minmax_qdq_resident(const float* x, float* y, int64_t N, int64_t C, 
  *        cnnq_group_ws_status_clear lowers it).
  *   qp   out: qp[CNNQ_NQP][C].   mm: optional out [2][C] = the per-channel min and max.
  *   flags  bit 0: take the recompute path unconditionally (tests).
- *          bit 1: quantize every channel through the hardware divide (tests; CNNQ_IEEE_DIVIDE=1 sets it for every
- *          single-launch kernel of the process).  By default a channel whose extrema are finite, at most 2^70 in
+ *          bit 1: quantize every channel through the hardware divide (tests).  By default a channel whose extrema are finite, at most 2^70 in
  *          magnitude, with a scale of at most 2^30, takes the correctly rounded quotient from the channel's reciprocal
  *          (two fma corrections, csrc/cnnq_qdq.hip.h qdq1_fast): the same bits, half the arithmetic.
+ *          bit 5 (32): the counter meeting of round 2 instead of the slot meeting (tests, A/B).
+ *        A slot of the slot meeting must be ZERO AT REST - a stale non-zero word would be folded into a channel's extrema
+ *        as if a member had stored it: hand the kernel only workspaces from cnnq_group_ws_alloc (zeroed at their full size),
+ *        never one a launch was aborted on (device reset), and never replay a captured graph concurrently with eager
+ *        launches on the same workspace; cnnq_group_ws_at_rest checks it.  The slot region sits between the counter lines
+ *        and the pair blocks (2 MB, since round 4: re-query cnnq_pc_group_workspace, do not hard-code a size).
  * Same shape / alignment conditions and CNNQ_ENOTSUP convention as cnnq_pc_minmax_qdq_resident.
  * cnnq_pc_group_describe: out[8] = {A, K, mode, S, column blocks, workgroups per group, groups, workgroups}. */
 size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW);
@@ -337,12 +345,12 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
 int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
 
 /* Config 2 in ONE launch and ONE read of x when the batch is sharded over `world` GPUs of one node
- * (csrc/cnnq_xrank.hip.h; the Python host uses it by default when every rank has its own GPU and it reproduced the collective
+ * (csrc/cnnq_xrank.hip.h; opt-in in the Python host - CNNQ_XRANK=1 / auto - and only after it reproduced the collective
  * form's bits at first use; the collective form is cnnq_pc_minmax_local_auto -> all_gather -> cnnq_pc_gathered_qdq, which
  * reads x twice).  The reference has no counterpart (its DataParallel replicas use their own sub-batch's range,
  * inference_sim.py:196-200); this reproduces the single-GPU result of int_quantizer.py:409-451,557-603 on the global batch.
  *   windows  device array [world] of pointers: entry r is rank r's window (cnnq_xrank_alloc on rank r, opened here with
- *            cnnq_p2p_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels: one 8-byte
+ *            cnnq_xrank_open from its hipIpc handle; the own window at [rank]); every window holds cmax channels: one 8-byte
  *            slot per (parity, source rank, channel), zero when empty - a rank stores the complement of its {min, max}
  *            pair into every window and polls its own (round 4: the pair is the signal; a small kernel behind the launch
  *            zeroes the launch's parity again).
@@ -355,7 +363,10 @@ int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
  * A rank whose shard has no single-launch kernel (shards may differ by a sample) speaks the same window protocol around
  * two passes over x, so every rank consumes the sequence number whatever its own plan. */
 size_t cnnq_xrank_window_bytes(int world, int cmax);
-int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64]);   /* free / open / close: cnnq_p2p_* */
+int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64]);   /* allocates + zeroes the own window, exports its hipIpc handle; synchronises */
+int cnnq_xrank_open(const unsigned char handle[64], void** window);                   /* maps a peer's window */
+int cnnq_xrank_close(void* window);                                                   /* unmaps it */
+int cnnq_xrank_free(void* window);                                                    /* releases the own window */
 int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
                              float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
                              uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream);
@@ -485,25 +496,6 @@ int cnnq_pt_minmax_qdq_fused(const float* x, float* y, int64_t n, int rows, int 
 #define CNNQ_KLD_NCAND 994
 int cnnq_kld_hist(const float* x, int64_t rows, int64_t len, const float* rowmm, uint32_t* hist, void* stream);
 int cnnq_kld_search(const uint32_t* hist, int64_t rows, const float* rowmm, double* div, double* out, void* stream);
-
-/* Peer-to-peer statistics exchange (opt-in alternative to the RCCL all_gather of SURVEY.md 8e; one process
- * per GPU, all on one node).  Each rank owns a window of fine-grained uncached device memory holding
- * slots[2][W][slot_floats] floats + flags[2][W]; peers map it through hipIpc.
- *   cnnq_p2p_alloc / _open / _close / _free   setup (the only entry points that allocate or synchronise):
- *                     allocate + zero the own window and export its 64-byte IPC handle; map a peer's window;
- *   cnnq_p2p_all_gather  exchange number seq (1, 2, ... consecutive): ONE launch of W workgroups - workgroup b
- *                     writes rec[nfloat] into slot [seq & 1][rank] of rank b's window (`windows`: device array of
- *                     the W mapped window pointers, own one at [rank]), releases the matching flag at system scope,
- *                     then acquire-spins on the own window's flag of rank b and copies that record to
- *                     out[b][nfloat] (out[W][nfloat] is the G axis cnnq_pc_minmax_params / cnnq_pc_combine merge).
- *                     A spin gives up after 2 s and sets bit 0 of *status (device int) - it never hangs. */
-size_t cnnq_p2p_window_bytes(int world, int slot_floats);
-int cnnq_p2p_alloc(int world, int slot_floats, void** window, unsigned char handle[64]);
-int cnnq_p2p_open(const unsigned char handle[64], void** window);
-int cnnq_p2p_close(void* window);
-int cnnq_p2p_free(void* window);
-int cnnq_p2p_all_gather(const float* rec, int nfloat, void* const* windows, int rank, int world, int slot_floats,
-                        uint32_t seq, float* out, int* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,11 +31,14 @@ def test_json_line_contract():
     d = run_bench('--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '8')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'verified', 'group_status',
-              'other_configs', 'ms_per_step_by_rank', 'rccl_ranks', 'box'):
+              'other_configs', 'ms_per_step_by_rank', 'rccl_ranks', 'box', 'sustained'):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
     assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['verified'] is True
     assert d['group_status'] == 0 and d['rccl_ranks'] == 0
+    sus = d['sustained']
+    assert sus['steps'] >= 2 and sus['seconds'] > 0 and abs(sus['ms_per_step'] - sus['seconds'] * 1e3 / sus['steps']) < 1e-9
+    assert abs(sus['value'] * sus['ms_per_step'] * 1e-3 - sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 8) < 1.
     assert d['unit'] == 'elements/s' and d['dtype'] == 'f32' and d['data'] == 'synthetic'
     assert 'workload' in d['config'] and 'model' not in d['config']
     elems = sum(c * hw * hw * n for (c, hw, n) in SHAPES) * 8
@@ -101,3 +104,16 @@ def test_in_launch_exchange_falls_back_to_the_collective():
     assert d['xrank']['probe_ms_collective'] > 0 and d['xrank']['probe_ms_in_launch'] > 0
     assert ('in-launch exchange' in d['config']['exchange']) == d['xrank']['used']
 
+
+
+@pytest.mark.parametrize('xrank', ['0', '1'])
+def test_graph_replay_of_the_sharded_step(xrank):
+    """--graph with the exchange in the captured step: the multi-GPU launch sequence of a 64-sample shard on a
+    1-rank RCCL group, through the collective route (ncclAllGather captured on the compute stream) and through the in-launch
+    exchange (device-side sequence word), replayed from a HIP graph; outputs verified after the replays."""
+    d = run_bench('--batch', '64', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-other-configs', '--force-exchange',
+                  '--graph', '--sustained-secs', '0.2', env={'CNNQ_XRANK': xrank})
+    assert d['verified'] is True and d['group_status'] == 0
+    assert d['config']['launch'] == 'hip graph replay'
+    assert ('in-launch exchange' in d['config']['exchange']) == (xrank == '1')
+    assert d['sustained']['steps'] >= 4

@@ -82,13 +82,14 @@ def _worker(rank, world, port, tmp):
     m = D.merge_row_minmax(st, rows, True, None)
     assert m.shape == (7, 10)
     assert torch.equal(m[0], per_sample_min) and torch.equal(m[1], per_sample_max)
-    # the exchange selection (round 4): auto never starts the in-launch exchange on a backend whose ranks may share a GPU,
-    # '0' never starts it at all; both without touching a device
+    # the exchange selection: the in-launch exchange is opt-in ('0' unless asked for); auto never starts it on a backend
+    # whose ranks may share a GPU; nothing here touches a device
     for mode in ('auto', '0', 'bogus'):
         os.environ['CNNQ_XRANK'] = mode
-        assert D.xrank_mode() == ('0' if mode == '0' else 'auto')
+        assert D.xrank_mode() == ('auto' if mode == 'auto' else '0')
         assert D.xrank_exchange(None) is None
     os.environ.pop('CNNQ_XRANK')
+    assert D.xrank_mode() == '0'
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, 'ok%d' % rank), 'w').write('ok')
@@ -118,9 +119,13 @@ def test_xrank_mode_without_a_process_group(monkeypatch):
     """No process group: every mode answers None (the collective / single-GPU paths), nothing is imported or allocated."""
     sys.path.insert(0, ROOT)
     from cnn_quantization_amd import distributed as D
-    for mode, want in (('auto', 'auto'), ('1', '1'), ('0', '0'), ('', 'auto')):
+    for mode, want in (('auto', 'auto'), ('1', '1'), ('0', '0'), ('', '0')):
         monkeypatch.setenv('CNNQ_XRANK', mode)
         assert D.xrank_mode() == want
         assert D.xrank_exchange(None) is None
     monkeypatch.delenv('CNNQ_XRANK')
-    assert D.xrank_mode() == 'auto'
+    assert D.xrank_mode() == '0'                       # opt-in: the default sharded route is the collective
+    D.set_xrank_mode('auto')                           # a program that implements the recovery opts in for itself
+    assert D.xrank_mode() == 'auto' and D.xrank_exchange(None) is None
+    D.set_xrank_mode(None)
+    assert D.xrank_mode() == '0'

@@ -174,8 +174,8 @@ def test_group_rearms_and_replays_from_a_graph(ops):
 def test_workspace_is_zero_at_rest(slots):
     """Counters and slots are zero whenever no launch is in flight - after launches of every tile shape on ONE workspace,
     normal and with the recompute path forced - so no launch can meet another launch's arrivals: with the slot meeting
-    (round 4) a stale non-zero slot WOULD be taken for a member's pair.  Runs in a process of its own so that the
-    meeting can be chosen (CNNQ_MEET_SLOTS is read once)."""
+    (round 4) a stale non-zero slot WOULD be taken for a member's pair.  Runs in a process of its own (a workspace of its
+    own, nothing else in flight); flags bit 5 selects the counter meeting of round 2."""
     import os
     import subprocess
     import sys
@@ -187,10 +187,11 @@ lib = _lib.load()
 ws = ctypes.c_void_p()
 _lib.check(lib.cnnq_group_ws_alloc(18 << 20, ctypes.byref(ws)), 'alloc')
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+MEET = %d
 shapes = [(40, 6, 56, 56), (300, 3, 56, 56), (66, 3, 112, 112), (260, 2, 112, 112), (70, 40, 7, 7), (64, 256, 14, 14),
           (5, 3, 28, 28), (130, 20, 28, 28), (1, 1100, 2, 2), (600, 2, 8, 8), (64, 512, 7, 7), (512, 16, 56, 56)]
 n = ctypes.c_uint64(0)
-for flags in (0, 1, 0):
+for flags in (0 | MEET, 1 | MEET, 0 | MEET):
     for (N, C, H, W) in shapes:
         x = torch.randn(N, C, H, W, device='cuda') * 3
         y = torch.empty_like(x)
@@ -205,9 +206,8 @@ s = ctypes.c_uint32(0)
 _lib.check(lib.cnnq_group_ws_status(ws, ctypes.byref(s)), 'status')
 assert s.value == 2, s.value          # the test hook reported itself; no wait expired
 print('ok')
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CNNQ_MEET_SLOTS=str(slots))
-    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 0 if slots else 32)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-3000:]
 
 

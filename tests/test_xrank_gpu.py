@@ -64,8 +64,8 @@ def _worker(rank, world, port, tmp):
                 out['o_%d_%d' % (i, half)] = (y.cpu(), codes.cpu(), float(ent), parts['qp'].cpu(), parts['stats'].cpu(), float(ent2),
                                               bool(torch.equal(y, y2)))
         out['launches_out'] = ex.seq - seq0 - out['launches']
-        # CNNQ_XRANK=1 also moves the moment records of the statistics passes through windows (P2PExchange): configs 3 and 5
-        # and the seven statistics, through the windows and - same calls, switch off - through the collective, bit for bit
+        # configs 3 / 5 and the seven statistics of a sharded run move their moment records through the collective whatever
+        # CNNQ_XRANK says (two routes, and the in-launch one is config 2's): same calls, switch on and off, bit for bit
         x = _batch(3, (38, 24, 14, 14))
         n0, n1 = D.shard_batch(38, rank, world)
         xs = x[n0:n1].contiguous().cuda()
@@ -75,13 +75,9 @@ def _worker(rank, world, port, tmp):
                  ops.pc_stats(xs, xs.shape[0], 24, 196, need_b=True, need_kurt=True, need_relu=True)[0]]
             torch.cuda.synchronize()
             return [t.cpu() for t in r]
-        p2p = D.p2p_exchange(None)
-        out['p2p_on'] = p2p is not None
         a = stats_paths()
-        out['p2p_used'] = p2p is not None and p2p.calls > 0 and p2p.healthy()
         os.environ['CNNQ_XRANK'] = '0'
         ops.reload_switches()
-        out['p2p_off'] = D.p2p_exchange(None) is None
         b = stats_paths()
         os.environ['CNNQ_XRANK'] = '1'
         ops.reload_switches()
@@ -123,7 +119,7 @@ def test_two_ranks_on_one_gpu_equal_the_whole_batch(tmp_path):
                 assert torch.equal(o[3][0], rp['scale'].flatten()) and torch.equal(o[3][1], rp['zero_point'].flatten()), (shape, half)
                 assert torch.equal(o[4][1], torch.as_tensor(rp['max']).flatten()) and o[6]
     assert all(p['launches_out'] == 2 * len(SHAPES) * 2 for p in parts)    # they too went through the in-launch exchange
-    assert all(p['p2p_on'] and p['p2p_used'] and p['p2p_off'] and p['stats_same'] for p in parts), [(p['p2p_on'], p['p2p_used'], p['p2p_off'], p['stats_same']) for p in parts]
+    assert all(p['stats_same'] for p in parts)
 
 
 def _single(rank, world, port, tmp):
