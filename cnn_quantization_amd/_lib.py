@@ -98,6 +98,8 @@ SIGNATURES = {
     'cnnq_pc_bcorr_apply': (_I, [_P, _L, _L, _L, _P, _P]),
     'cnnq_pc_midtread_params': (_I, [_P, _L, ctypes.c_double, _I, _I, _P, _I, _P, _P]),
     'cnnq_pc_midtread_qdq': (_I, [_P, _P, _L, _L, _L, _P, _I, _P, _P, _P]),
+    'cnnq_pc_midtread_qdq_single': (_I, [_P, _P, _L, _L, _L, ctypes.c_double, _I, _P, _I, _P, _P, ctypes.c_size_t, _P, _P, _P,
+                                         ctypes.c_uint32, _P]),
     'cnnq_midtread_entropy': (_I, [_P, _P, _L, _L, _P, _P]),
     'cnnq_entropy': (_I, [_P, _I, _P, _P]),
     'cnnq_pt_setup': (_I, [ctypes.POINTER(_F), _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),

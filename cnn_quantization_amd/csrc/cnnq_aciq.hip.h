@@ -15,6 +15,16 @@
 // cannot exist: no parameter of any channel is known before every channel's std is, i.e. before all of x has been read
 // once, and 1.6 GB do not fit the register files.
 //
+// The same structure serves the mid-tread path of config 5 (MODE 1; iq.py:185-225): b is again the only statistic that needs
+// the second pass, the bin allocation (omega, from the std of pass A alone: k_mt_params<GUESS>) plays the part of the bit
+// allocation, and the launch derives delta / c_min / c_max (mt_channel: the function k_mt_params runs), quantizes, clamps,
+// dequantizes and counts the codes into the windowed histogram of cnnq_midtread.hip.h.
+//
+// Channels too populous for the plain register tiles (VGG-16 b512: [512,64,224,224] holds 103 MB per channel, the 768
+// resident K = 32 tiles 98 MB) take eight more rows per tile in LDS (KL = 8: LDS-DMA fills, 160 KB per workgroup, 628 members
+// per channel, one channel resident at a time) - the tile shape k_mmq_flat has as a development knob, planned here whenever
+// nothing smaller fits.
+//
 // Sums, unlike extrema, depend on the order of the additions.  Everything here adds in an order that is a function of
 // the geometry alone: a lane adds its steps in order (fp64 accumulation of fp32 |x - mean|, as k_absdev), lanes fold by
 // a fixed xor tree, waves in index order, and the members' partial sums are added in MEMBER order by every member -
@@ -25,6 +35,7 @@
 #pragma once
 #include "cnnq_common.hip.h"
 #include "cnnq_group.hip.h"
+#include "cnnq_midtread.hip.h"
 #include "cnnq_params.hip.h"
 #include "cnnq_qdq.hip.h"
 
@@ -49,13 +60,19 @@ __device__ __forceinline__ unsigned long long slot_of_sum(double s) {
 }
 __device__ __forceinline__ double sum_of_slot(unsigned long long v) { return __longlong_as_double((long long)~v); }
 
-struct AciqArgs {
+// MODE 0: ACIQ clipping + GEMMLOWP Q/DQ (config 3).  MODE 1: mid-tread quantization with bin allocation (config 5).
+struct FusedArgs {
     float* stats;            // [CNNQ_NSTAT][C]: rows MIN, MAX, MEAN, STD from pass A; row B is written here
+    double count;            // N * H*W: elements per channel
+    // MODE 0
     const float* bits;       // [C] allocated widths (k_bitalloc), or null: cfg.num_bits everywhere
     float* qp;               // [CNNQ_NQP][C] out
     float* diag;             // [CNNQ_NDIAG][C] out, may be null
     cnnq_params_cfg cfg;
-    double count;            // N * H*W: elements per channel
+    // MODE 1
+    float* mt;               // [CNNQ_NMT][C]: rows OMEGA, ALPHA, WSTART from k_mt_params<GUESS>; DELTA, CMIN, CMAX written here
+    MtCfg mcfg;
+    unsigned long long* hist;   // CNNQ_MT_HIST_WORDS(C), zeroed by the caller; may be null (OUT = 0)
 };
 
 // the four |x - mean| of one float4 of ONE channel added to the lane's sum (steps past the tile add nothing)
@@ -78,7 +95,7 @@ __device__ __forceinline__ double wg_sum1(double v, double* l_s) {
     return ((l_s[0] + l_s[1]) + l_s[2]) + l_s[3];
 }
 
-// The slot meeting of k_aciq_flat (slots_meet of cnnq_group.hip.h for sums): wave 0 stores the member's partial sum and
+// The slot meeting of k_fused_flat (slots_meet of cnnq_group.hip.h for sums): wave 0 stores the member's partial sum and
 // polls the group's slots; lane l watches members l, l + 64, ... in windows of 4 and adds a window's values in member
 // order once the whole window has arrived.  Returns 0, or 1 (a wait expired) / 2 (the test hook), meaningful in thread 0;
 // tsum: the lane's share (0 outside wave 0).
@@ -124,33 +141,122 @@ __device__ __forceinline__ int slots_meet_sum(unsigned long long* slots, int mem
     return 0;
 }
 
-// the same fold over member sums that sit in LDS (the cold path): identical order of additions
-__device__ __forceinline__ double fold_member_sums(const double* ms, int Gs) {
+// the same fold over plain member sums (the cold path's table, uncached memory): identical order of additions
+__device__ __forceinline__ double fold_member_sums(const unsigned long long* ms, int Gs) {
     const int tid = threadIdx.x;
     double tsum = 0.;
     if (tid < 64)
         for (int w0 = 0; w0 * 64 < Gs; w0 += 4)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (tid + 64 * (w0 + i) < Gs) tsum += ms[tid + 64 * (w0 + i)];
+                if (tid + 64 * (w0 + i) < Gs)
+                    tsum += __longlong_as_double((long long)__hip_atomic_load(ms + tid + 64 * (w0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return tsum;
 }
 
-// ---- flat tiles (the geometry of k_mmq_flat: a group is ONE channel, a member 256 K consecutive float4 of it) --------
-template <int K, int OUT = 0>
-__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_flat(
-    const float* __restrict__ x, float* __restrict__ y, const FGeo g, const GWs ws, const AciqArgs aa, const unsigned flags,
+// ---- mid-tread arithmetic of the single-launch kernels (MODE 1) ---------------------------------------------------------
+// x / delta without the hardware divide, for a channel inside the domain of qdq1_fast (finite extrema up to 2^70, delta in
+// [1e-8, 2^30]): the correctly rounded quotient from the channel's correctly rounded reciprocal and two fma corrections (the
+// proof in cnnq_qdq.hip.h).  There is no zero point to absorb the sign of a vanishing quotient here, so it is taken from x:
+// the exact quotient of a non-zero x is non-zero with x's sign (delta > 0), and -0 / delta = -0.
+__device__ __forceinline__ float mt_quot_fast(float x, float d, float rd) {
+    float q = x * rd;
+    float r = __builtin_fmaf(-d, q, x);
+    q = __builtin_fmaf(r, rd, q);
+    r = __builtin_fmaf(-d, q, x);
+    q = __builtin_fmaf(r, rd, q);
+    return copysignf(q, x);
+}
+__device__ __forceinline__ bool mt_fast_domain(float vmin, float vmax, float delta) {
+    return fabsf(vmin) <= 0x1p70f && fabsf(vmax) <= 0x1p70f && delta >= 1e-8f && delta <= 0x1p30f;   // false for NaN
+}
+// one element: code (iq.py:202-214) and dequantized value (iq.py:224)
+template <bool FAST>
+__device__ __forceinline__ float mt_qdq1(float x, float d, float rd, float lo, float hi, float& code) {
+    float t = rintf(FAST ? mt_quot_fast(x, d, rd) : x / d);
+    // torch.min(t, hi) = t < hi ? t : hi and torch.max(t, lo) = t > lo ? t : lo, NaN kept (the bound wins ties)
+    t = (t < hi || t != t) ? t : hi;
+    t = (t > lo || t != t) ? t : lo;
+    code = t;
+    return t * d;
+}
+// one code into the histogram: zero and "clamped to a non-integer bound" in registers, an integer code inside the window one
+// LDS atomic, everything else (rare) straight to the global bins (the logic of k_mt_qdq)
+__device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni, bool hi_ni, int wstart, unsigned* sh_hist,
+                                         unsigned* sh_nan, unsigned long long* hist, int C, unsigned& nzero, unsigned& nlo,
+                                         unsigned& nhi) {
+    const bool z = (t == 0.f);
+    const bool at_hi = hi_ni && t == hi;
+    const bool at_lo = lo_ni && t == lo;
+    nzero += z ? 1u : 0u;
+    nhi += at_hi ? 1u : 0u;
+    nlo += at_lo ? 1u : 0u;
+    const int k = (int)t;                       // saturating; NaN -> 0
+    const unsigned kk = (unsigned)(k - wstart);
+    const bool fast = ((float)k == t) && kk < (unsigned)MT_W;
+    if (fast && !z) {
+        atomicAdd(&sh_hist[kk * MT_REP + ((unsigned)threadIdx.x & (MT_REP - 1))], 1u);
+    } else if (!(z || at_hi || at_lo)) {        // rare
+        if (t == rintf(t)) {                    // integer code outside the window (or inf)
+            if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
+            else atomicAdd(&hist[t < 0.f ? MT_NB : MT_NB + 1], 1ull);
+            atomicAdd(&hist[mt_flag_word(C)], 1ull);   // the global bins are in use
+        } else {
+            atomicAdd(sh_nan, 1u);              // NaN: counted with the channel's lower bound, as k_mt_qdq does
+        }
+    }
+}
+// end of the workgroup: the lanes' zero counts and the LDS window into the replica window (blockIdx picks the replica)
+__device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* hist, int C, int wstart, unsigned nzero) {
+    const int tid = threadIdx.x;
+    if (nzero) {
+        const int kk = -wstart;
+        if (kk >= 0 && kk < MT_W) {
+            atomicAdd(&sh_hist[(unsigned)kk * MT_REP + ((unsigned)tid & (MT_REP - 1))], nzero);
+        } else {
+            atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
+            atomicAdd(&hist[mt_flag_word(C)], 1ull);
+        }
+    }
+    __syncthreads();
+    unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C + (size_t)(blockIdx.x & (MT_GR - 1)) * MT_W;
+    for (int i = tid; i < MT_W; i += TPB) {
+        unsigned tot = 0;
+#pragma unroll
+        for (int r = 0; r < MT_REP; ++r) tot += sh_hist[(unsigned)i * MT_REP + ((unsigned)(r + tid) & (MT_REP - 1))];
+        if (tot) {
+            if (wstart + i < MT_NB / 2) {
+                atomicAdd(&rep[i], (unsigned long long)tot);
+            } else {
+                atomicAdd(&hist[MT_NB + 1], (unsigned long long)tot);
+                atomicAdd(&hist[mt_flag_word(C)], 1ull);
+            }
+        }
+    }
+}
+
+// ---- flat tiles (the geometry of k_mmq_flat: a group is ONE channel, a member 256 (K + KL) consecutive float4 of it) -----
+template <int K, int OUT, int KL, int MODE>
+__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_flat(
+    const float* __restrict__ x, float* __restrict__ y, const FGeo g, const GWs ws, const FusedArgs fa, const unsigned flags,
     const XOut xo = XOut{}) {
     static_assert(TPB == 256, "wg_sum1 folds four waves");
     __shared__ double l_s[TPB / 64];
-    __shared__ double sh_ms[GRP_GS_MAX];      // cold path only: every member's partial sum
     __shared__ double sh_tot;
-    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
-    const cnnq_params_cfg& cfg = aa.cfg;
-    const bool ba = cfg.bit_alloc && cfg.num_bits <= 4;
+    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MT_REP) : 1];
+    __shared__ unsigned sh_cnt[4];            // MODE 1 histogram: NaN / clamped-low, clamped-high counts of the channel
+    __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
+    const cnnq_params_cfg& cfg = fa.cfg;
+    const bool ba = MODE == 0 && cfg.bit_alloc && cfg.num_bits <= 4;
     const int nbins = ba ? 256 : 1 << (cfg.num_bits < 8 ? cfg.num_bits : 8);
+    const bool want_hist = OUT == 1 && (MODE == 0 ? xo.hist != nullptr : fa.hist != nullptr);
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_zero(sh_hist, nbins);      // ordered before the first count by the barriers of the exchange
+        // ordered before the first count by the barriers of the exchange
+        if (want_hist) {
+            if constexpr (MODE == 0) xhist_zero(sh_hist, nbins);
+            else for (int i = threadIdx.x; i < MT_W * MT_REP; i += TPB) sh_hist[i] = 0u;
+        }
+        if (threadIdx.x < 4) sh_cnt[threadIdx.x] = 0u;
     }
     __shared__ int sh_timed_out;
     const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -166,11 +272,11 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_fla
         c = c0 + (r - member * cbl);
     }
     // the channel's statistics of pass A (uniform addresses: scalar loads), in flight next to the tile
-    const float vmin = aa.stats[(size_t)CNNQ_STAT_MIN * g.C + c], vmax = aa.stats[(size_t)CNNQ_STAT_MAX * g.C + c];
-    const float vmean = aa.stats[(size_t)CNNQ_STAT_MEAN * g.C + c], vstd = aa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
-    const float bits = ba ? aa.bits[c] : (float)cfg.num_bits;
+    const float vmin = fa.stats[(size_t)CNNQ_STAT_MIN * g.C + c], vmax = fa.stats[(size_t)CNNQ_STAT_MAX * g.C + c];
+    const float vmean = fa.stats[(size_t)CNNQ_STAT_MEAN * g.C + c], vstd = fa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
+    const float bits = ba ? fa.bits[c] : (float)cfg.num_bits;
 
-    const unsigned f0 = (unsigned)member * (256u * K);   // < total
+    const unsigned f0 = (unsigned)member * (256u * (K + KL));   // < total
     const unsigned n_first = f0 / g.cpc;
     const unsigned u = f0 + (unsigned)tid;
     const unsigned n = u / g.cpc;
@@ -182,11 +288,20 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_fla
     const size_t base = ((size_t)n_first * (size_t)g.P + (size_t)c * (size_t)g.HW) * 4;
     const char* xb = reinterpret_cast<const char*>(x) + base;
     char* yb = reinterpret_cast<char*>(y) + base;
-    uint8_t* cbb = (OUT == 1 && xo.codes) ? xo.codes + base / 4 : nullptr;
+    uint8_t* cbb = (MODE == 0 && OUT == 1 && xo.codes) ? xo.codes + base / 4 : nullptr;
 
-    // ---- the tile: K 16-byte loads per lane, back to back (k_mmq_flat's walk)
+    // ---- the tile: the first KL steps straight into LDS (LDS-DMA, issued first), then K 16-byte loads per lane, back to back
     float v[K][4];
     FWalk w = w0;
+    if constexpr (KL > 0) {
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
+                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
+            w.step(g);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
@@ -194,11 +309,23 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_fla
         w.step(g);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // steps of this lane inside the channel: u + 256 j < total
+    // steps of this lane inside the channel: u + 256 s < total.  Two accumulators, the register steps and the LDS steps, each
+    // in step order, added at the end: the order does not depend on what landed first (the cold path does the same)
     const int nvalid = u < g.total ? (int)((g.total - u + 255u) / 256u) : 0;
     double sa = 0.;
 #pragma unroll
-    for (int j = 0; j < K; ++j) absdev_step(v[j], vmean, j < nvalid, sa);
+    for (int j = 0; j < K; ++j) absdev_step(v[j], vmean, KL + j < nvalid, sa);
+    if constexpr (KL > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+        double sl = 0.;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+            const float t[4] = {q.x, q.y, q.z, q.w};
+            absdev_step(t, vmean, l < nvalid, sl);
+        }
+        sa = sl + sa;
+    }
     const double msum = wg_sum1(sa, l_s);
 
     // ---- the meeting: the member's sum is its arrival
@@ -214,25 +341,29 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_fla
     }
     __syncthreads();
     if (sh_timed_out) {
-        // cold path: every member's partial sum from x with that member's own lane mapping, then the same fold
+        // cold path: every member's partial sum from x with that member's own lane mapping, into the group's block of the
+        // pair region (unused by the slot meeting; every workgroup that lands here writes the same values), then the same fold
+        unsigned long long* tab = ws.part + (size_t)c * ws.gstride;
         for (int m = 0; m < g.Gs; ++m) {
-            const unsigned mf0 = (unsigned)m * (256u * K), mu = mf0 + (unsigned)tid;
+            const unsigned mf0 = (unsigned)m * (256u * (K + KL)), mu = mf0 + (unsigned)tid;
             const int mvalid = mu < g.total ? (int)((g.total - mu + 255u) / 256u) : 0;
-            double s2 = 0.;
-            for (int j = 0; j < K; ++j) {
-                const unsigned e = mu + 256u * (unsigned)j;
-                const bool in = j < mvalid;
-                const unsigned ee = in ? e : mf0;
+            double s2 = 0., sl2 = 0.;
+            for (int s = 0; s < K + KL; ++s) {
+                const bool in = s < mvalid;
+                const unsigned ee = in ? mu + 256u * (unsigned)s : mf0;
                 const unsigned nn = ee / g.cpc;
                 float t[4];
                 ldv<4>(x + (size_t)nn * (size_t)g.P + (size_t)c * (size_t)g.HW + (size_t)(ee - nn * g.cpc) * 4, t);
-                absdev_step(t, vmean, in, s2);
+                if (s < KL) absdev_step(t, vmean, in, sl2);
+                else absdev_step(t, vmean, in, s2);
             }
+            if constexpr (KL > 0) s2 = sl2 + s2;
             const double ms = wg_sum1(s2, l_s);
-            if (tid == 0) sh_ms[m] = ms;
+            if (tid == 0) __hip_atomic_store(tab + m, (unsigned long long)__double_as_longlong(ms), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        tsum = fold_member_sums(sh_ms, g.Gs);
+        tsum = fold_member_sums(tab, g.Gs);
     }
     if (tid < 64) {
 #pragma unroll
@@ -241,52 +372,141 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_fla
     }
     __syncthreads();
 
-    // ---- b, clipping range, scale / zero point: every lane derives the same values from the same inputs
-    const float vb = (float)(sh_tot / aa.count);
-    const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, vmean, vstd, vb);
-    const float sc = cp.scale, zp = cp.zp, qm = cp.qmax;
-    const bool fast = qdq_fast_domain(vmin, vmax, sc) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
-    if (member == 0 && tid == 0) {
-        aa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
-        aa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
-        aa.qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
-        aa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
-        if (aa.diag) {
-            if (!ba) aa.diag[(size_t)CNNQ_DIAG_BITS * g.C + c] = bits;      // with bit allocation the row IS aa.bits
-            aa.diag[(size_t)CNNQ_DIAG_ALPHA * g.C + c] = cp.alpha;
-            aa.diag[(size_t)CNNQ_DIAG_DELTA * g.C + c] = cp.delta;
-            aa.diag[(size_t)CNNQ_DIAG_OFFSET * g.C + c] = cp.offset;
-        }
-    }
-
-    // ---- Q/DQ out of the registers (the walk repeated and hidden from the optimiser, as in k_mmq_flat)
+    // ---- b and the channel's parameters: every lane derives the same values from the same inputs
+    const float vb = (float)(sh_tot / fa.count);
     w = w0;
-    asm volatile("" : "+v"(w.ro), "+v"(w.co));
-    const float zpa[1] = {zp};
-    unsigned nzp[1] = {0u};
-    if (__builtin_amdgcn_readfirstlane((int)fast)) {
-        const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp), s_qm = uniform_f(qm);
+    asm volatile("" : "+v"(w.ro), "+v"(w.co));      // the walk repeated and hidden from the optimiser, as in k_mmq_flat
+    if constexpr (MODE == 0) {
+        const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, vmean, vstd, vb);
+        const float sc = cp.scale, zp = cp.zp, qm = cp.qmax;
+        const bool fast = qdq_fast_domain(vmin, vmax, sc) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
+        if (member == 0 && tid == 0) {
+            fa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
+            fa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
+            fa.qp[(size_t)CNNQ_QP_QMAX * g.C + c] = qm;
+            fa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
+            if (fa.diag) {
+                if (!ba) fa.diag[(size_t)CNNQ_DIAG_BITS * g.C + c] = bits;      // with bit allocation the row IS fa.bits
+                fa.diag[(size_t)CNNQ_DIAG_ALPHA * g.C + c] = cp.alpha;
+                fa.diag[(size_t)CNNQ_DIAG_DELTA * g.C + c] = cp.delta;
+                fa.diag[(size_t)CNNQ_DIAG_OFFSET * g.C + c] = cp.offset;
+            }
+        }
+        // ---- Q/DQ out of LDS and registers
+        const float zpa[1] = {zp};
+        unsigned nzp[1] = {0u};
+        if (__builtin_amdgcn_readfirstlane((int)fast)) {
+            const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp), s_qm = uniform_f(qm);
+            if constexpr (KL > 0) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            float o[4], cd[4];
-            qdq4_fast(v[j], s_sc, s_rs, s_zp, s_qm, o, cd);
-            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-            w.step(g);
+                for (int l = 0; l < KL; ++l) {
+                    const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w};
+                    float o[4], cd[4];
+                    qdq4_fast(t, s_sc, s_rs, s_zp, s_qm, o, cd);
+                    if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                    w.step(g);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                float o[4], cd[4];
+                qdq4_fast(v[j], s_sc, s_rs, s_zp, s_qm, o, cd);
+                if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                w.step(g);
+            }
+        } else {
+            if constexpr (KL > 0) {
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w};
+                    float o[4], cd[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = qdq1(t[e], sc, zp, qm, cd[e]);
+                    if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                    w.step(g);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                float o[4], cd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
+                if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                w.step(g);
+            }
+        }
+        if constexpr (OUT == 1) {
+            if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, nbins, zpa, nzp);
         }
     } else {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
+        const float omega = fa.mt[(size_t)CNNQ_MT_OMEGA * g.C + c], am = fa.mt[(size_t)CNNQ_MT_ALPHA * g.C + c];
+        const MtChan mc = mt_channel(fa.mcfg, omega, am, vmin, vmax, vmean, vb);
+        const float d = mc.delta, lo = mc.cmin, hi = mc.cmax;
+        const bool fast = mt_fast_domain(vmin, vmax, d) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
+        if (member == 0 && tid == 0) {
+            fa.mt[(size_t)CNNQ_MT_DELTA * g.C + c] = d;
+            fa.mt[(size_t)CNNQ_MT_CMIN * g.C + c] = lo;
+            fa.mt[(size_t)CNNQ_MT_CMAX * g.C + c] = hi;
+            fa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
+        }
+        const int wstart = want_hist ? (int)fa.mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
+        const bool hi_ni = hi != rintf(hi), lo_ni = lo != rintf(lo);     // a non-integer bound is a value of its own
+        unsigned nzero = 0u, nlo = 0u, nhi = 0u;
+        auto emit = [&](const float (&t)[4], bool isfast, float rd) {
             float o[4], cd[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
-            if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            for (int e = 0; e < 4; ++e) o[e] = isfast ? mt_qdq1<true>(t[e], d, rd, lo, hi, cd[e]) : mt_qdq1<false>(t[e], d, rd, lo, hi, cd[e]);
+            if (w.ro < lim) {
+                stv_nt<4>(reinterpret_cast<float*>(yb + (w.ro + w.co)), o);
+                if constexpr (OUT == 1) {
+                    if (want_hist) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_cnt[0], fa.hist, g.C, nzero, nlo, nhi);
+                    }
+                }
+            }
             w.step(g);
+        };
+        if (__builtin_amdgcn_readfirstlane((int)fast)) {
+            const float rd = uniform_f(1.0f / d);
+            if constexpr (KL > 0) {
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w};
+                    emit(t, true, rd);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) emit(v[j], true, rd);
+        } else {
+            if constexpr (KL > 0) {
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w};
+                    emit(t, false, 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) emit(v[j], false, 0.f);
+        }
+        if constexpr (OUT == 1) {
+            if (want_hist) {
+                if (nlo) atomicAdd(&sh_cnt[0], nlo);
+                if (nhi) atomicAdd(&sh_cnt[1], nhi);
+                mt_flush(sh_hist, fa.hist, g.C, wstart, nzero);      // (its barrier orders the counters too)
+                if (tid == 0) {
+                    if (sh_cnt[0]) atomicAdd(&fa.hist[MT_NB + 2 + c], (unsigned long long)sh_cnt[0]);
+                    if (sh_cnt[1]) atomicAdd(&fa.hist[MT_NB + 2 + g.C + c], (unsigned long long)sh_cnt[1]);
+                }
+            }
         }
     }
-    if constexpr (OUT == 1) {
-        if (xo.hist) xhist_flush<1>(sh_hist, xo.hist, nbins, zpa, nzp);
-    }
     // ---- leave the group; the last member out re-arms the group's slots
+    __syncthreads();
     if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
     __syncthreads();
     if (sh_timed_out)
@@ -427,18 +647,28 @@ __device__ __forceinline__ void group_fold_sums(const unsigned long long* src, i
     }
 }
 
-template <int A, int K, int OUT = 0>
-__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_group(
-    const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const GWs ws, const AciqArgs aa,
+// MODE 1 (mid-tread): sh_sc = delta, sh_zp = c_min, sh_qm = c_max, sh_rs = 1 / delta; A == 1 only (no VGG layer straddles)
+template <int A, int K, int OUT, int MODE>
+__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_group(
+    const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const GWs ws, const FusedArgs aa,
     const unsigned flags, const XOut xo = XOut{}) {
+    static_assert(MODE == 0 || A == 1, "the mid-tread form has no straddling instance");
     __shared__ double l_a[TPB * A];
     __shared__ double sh_sum[MAXCH];
-    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MT_REP) : 1];
+    __shared__ unsigned sh_clo[(MODE == 1 && OUT == 1) ? MAXCH : 1], sh_chi[(MODE == 1 && OUT == 1) ? MAXCH : 1];
     const cnnq_params_cfg& cfg = aa.cfg;
-    const bool ba = cfg.bit_alloc && cfg.num_bits <= 4;
+    const bool ba = MODE == 0 && cfg.bit_alloc && cfg.num_bits <= 4;
     const int nbins = ba ? 256 : 1 << (cfg.num_bits < 8 ? cfg.num_bits : 8);
+    const bool want_hist = OUT == 1 && (MODE == 0 ? xo.hist != nullptr : aa.hist != nullptr);
     if constexpr (OUT == 1) {
-        if (xo.hist) xhist_zero(sh_hist, nbins);
+        if (want_hist) {
+            if constexpr (MODE == 0) xhist_zero(sh_hist, nbins);
+            else {
+                for (int i = threadIdx.x; i < MT_W * MT_REP; i += TPB) sh_hist[i] = 0u;
+                for (int i = threadIdx.x; i < MAXCH; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
+            }
+        }
     }
     __shared__ float sh_mean[MAXCH], sh_sc[MAXCH], sh_zp[MAXCH], sh_rs[MAXCH], sh_qm[MAXCH];
     __shared__ int sh_timed_out, sh_slow;
@@ -553,29 +783,45 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_gro
         wg_channel_sums<1>(g, b, true, one, l_a, sh_sum);
     }
 
-    // ---- b, clipping range, scale / zero point of the owned channels: identical in every member
+    // ---- b and the parameters of the owned channels: identical in every member
     for (int ch = tid; ch < nch; ch += TPB) {
         const int c = b.c0 + ch;
         const float vmin = aa.stats[(size_t)CNNQ_STAT_MIN * g.C + c], vmax = aa.stats[(size_t)CNNQ_STAT_MAX * g.C + c];
-        const float vstd = aa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
-        const float bits = ba ? aa.bits[c] : (float)cfg.num_bits;
         const float vb = (float)(sh_sum[ch] / aa.count);
-        const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, sh_mean[ch], vstd, vb);
-        sh_sc[ch] = cp.scale;
-        sh_zp[ch] = cp.zp;
-        sh_qm[ch] = cp.qmax;
-        sh_rs[ch] = 1.0f / cp.scale;
-        if (!qdq_fast_domain(vmin, vmax, cp.scale) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
-        if (rb.member == 0) {
-            aa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = cp.scale;
-            aa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = cp.zp;
-            aa.qp[(size_t)CNNQ_QP_QMAX * g.C + c] = cp.qmax;
-            aa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
-            if (aa.diag) {
-                if (!ba) aa.diag[(size_t)CNNQ_DIAG_BITS * g.C + c] = bits;      // with bit allocation the row IS aa.bits
-                aa.diag[(size_t)CNNQ_DIAG_ALPHA * g.C + c] = cp.alpha;
-                aa.diag[(size_t)CNNQ_DIAG_DELTA * g.C + c] = cp.delta;
-                aa.diag[(size_t)CNNQ_DIAG_OFFSET * g.C + c] = cp.offset;
+        if constexpr (MODE == 0) {
+            const float vstd = aa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
+            const float bits = ba ? aa.bits[c] : (float)cfg.num_bits;
+            const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, sh_mean[ch], vstd, vb);
+            sh_sc[ch] = cp.scale;
+            sh_zp[ch] = cp.zp;
+            sh_qm[ch] = cp.qmax;
+            sh_rs[ch] = 1.0f / cp.scale;
+            if (!qdq_fast_domain(vmin, vmax, cp.scale) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
+            if (rb.member == 0) {
+                aa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = cp.scale;
+                aa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = cp.zp;
+                aa.qp[(size_t)CNNQ_QP_QMAX * g.C + c] = cp.qmax;
+                aa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
+                if (aa.diag) {
+                    if (!ba) aa.diag[(size_t)CNNQ_DIAG_BITS * g.C + c] = bits;      // with bit allocation the row IS aa.bits
+                    aa.diag[(size_t)CNNQ_DIAG_ALPHA * g.C + c] = cp.alpha;
+                    aa.diag[(size_t)CNNQ_DIAG_DELTA * g.C + c] = cp.delta;
+                    aa.diag[(size_t)CNNQ_DIAG_OFFSET * g.C + c] = cp.offset;
+                }
+            }
+        } else {
+            const float omega = aa.mt[(size_t)CNNQ_MT_OMEGA * g.C + c], am = aa.mt[(size_t)CNNQ_MT_ALPHA * g.C + c];
+            const MtChan mc = mt_channel(aa.mcfg, omega, am, vmin, vmax, sh_mean[ch], vb);
+            sh_sc[ch] = mc.delta;
+            sh_zp[ch] = mc.cmin;
+            sh_qm[ch] = mc.cmax;
+            sh_rs[ch] = 1.0f / mc.delta;
+            if (!mt_fast_domain(vmin, vmax, mc.delta) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;
+            if (rb.member == 0) {
+                aa.mt[(size_t)CNNQ_MT_DELTA * g.C + c] = mc.delta;
+                aa.mt[(size_t)CNNQ_MT_CMIN * g.C + c] = mc.cmin;
+                aa.mt[(size_t)CNNQ_MT_CMAX * g.C + c] = mc.cmax;
+                aa.stats[(size_t)CNNQ_STAT_B * g.C + c] = vb;
             }
         }
     }
@@ -597,43 +843,87 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_aciq_gro
         zp[a] = sh_zp[chl[a]];
         qm[a] = sh_qm[chl[a]];
     }
+    const bool fastq = !__builtin_amdgcn_readfirstlane(sh_slow);
 
-    // ---- Q/DQ out of the registers
-    unsigned nzp[A];
+    if constexpr (MODE == 0) {
+        // ---- Q/DQ out of the registers
+        unsigned nzp[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) nzp[a] = 0u;
-    if (!__builtin_amdgcn_readfirstlane(sh_slow)) {
-        float rs[A];
+        for (int a = 0; a < A; ++a) nzp[a] = 0u;
+        if (fastq) {
+            float rs[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a) rs[a] = sh_rs[chl[a]];
+            for (int a = 0; a < A; ++a) rs[a] = sh_rs[chl[a]];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (j < nrows) {
-                float o[4], cd[4];
+            for (int j = 0; j < K; ++j) {
+                if (j < nrows) {
+                    float o[4], cd[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = qdq1_fast(v[j][e], sc[A == 1 ? 0 : e], rs[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
-                if (okq)
-                    xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, nullptr, (baseq + (size_t)j * (size_t)g.P) * 4, o, cd, sh_hist,
-                                   zp, nzp);
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = qdq1_fast(v[j][e], sc[A == 1 ? 0 : e], rs[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
+                    if (okq)
+                        xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, nullptr, (baseq + (size_t)j * (size_t)g.P) * 4, o, cd, sh_hist,
+                                       zp, nzp);
+                }
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (j < nrows) {
+                    float o[4], cd[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
+                    if (okq)
+                        xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, nullptr, (baseq + (size_t)j * (size_t)g.P) * 4, o, cd, sh_hist,
+                                       zp, nzp);
+                }
+            }
+        }
+        if constexpr (OUT == 1) {
+            if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, nbins, zp, nzp);
         }
     } else {
+        // ---- mid-tread: quantize, clamp, dequantize out of the registers; count the codes
+        const float d = sc[0], lo = zp[0], hi = qm[0];
+        const float rd = fastq ? sh_rs[chl[0]] : 0.f;
+        const int wstart = want_hist ? (int)aa.mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
+        const bool hi_ni = hi != rintf(hi), lo_ni = lo != rintf(lo);
+        unsigned nzero = 0u, nlo = 0u, nhi = 0u;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (j < nrows) {
                 float o[4], cd[4];
+                if (fastq) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
-                if (okq)
-                    xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, nullptr, (baseq + (size_t)j * (size_t)g.P) * 4, o, cd, sh_hist,
-                                   zp, nzp);
+                    for (int e = 0; e < 4; ++e) o[e] = mt_qdq1<true>(v[j][e], d, rd, lo, hi, cd[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = mt_qdq1<false>(v[j][e], d, rd, lo, hi, cd[e]);
+                }
+                if (okq) {
+                    stv_nt<4>(y + baseq + (size_t)j * (size_t)g.P, o);
+                    if constexpr (OUT == 1) {
+                        if (want_hist) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_clo[chl[0]], aa.hist, g.C, nzero, nlo, nhi);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (OUT == 1) {
+            if (want_hist) {
+                if (nlo) atomicAdd(&sh_clo[chl[0]], nlo);
+                if (nhi) atomicAdd(&sh_chi[chl[0]], nhi);
+                mt_flush(sh_hist, aa.hist, g.C, wstart, nzero);      // (its barrier orders the clamp counters too)
+                for (int i = tid; i < nch; i += TPB) {
+                    if (sh_clo[i]) atomicAdd(&aa.hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]);
+                    if (sh_chi[i]) atomicAdd(&aa.hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]);
+                }
             }
         }
     }
-    if constexpr (OUT == 1) {
-        if (xo.hist) xhist_flush<A>(sh_hist, xo.hist, nbins, zp, nzp);
-    }
+    __syncthreads();
     // ---- leave the group; the last member out re-arms the group's slots
     if (tid == 0) sh_timed_out = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
     __syncthreads();

@@ -52,6 +52,7 @@ constexpr int GRP_CNT_STRIDE = 64;                 // words between two groups' 
                                                    // 16 counters per line every arrival, departure and poll of 16
                                                    // groups serialised on one line (~130 ns per workgroup, measured)
 constexpr int GRP_GS_MAX = 512;                    // members of a group (all co-resident: capacity >= 512 workgroups)
+constexpr int GRP_GS_BIG = 704;                    // ... of a big-channel group (K = 32 + 8 LDS rows: the channel alone on the chip's 768 slots)
 #ifndef GRP_ACQUIRE
 #define GRP_ACQUIRE 0     // 1: agent-scope acquire (buffer_inv sc1) between the wait and the reads of the group's pairs.
                           // Not needed by construction - the pairs live in fine-grained (uncached) memory, a block is
@@ -331,11 +332,11 @@ __device__ __forceinline__ unsigned long long slot_of(float mn, float mx) {
 }
 
 // Wave 0 of the member does the meeting (no barrier inside the wait: the other waves sit at the caller's barrier): lane l
-// watches members l, l + 64, ... (GRP_GS_MAX / 64 = 8 at most).  Returns 0, or 1 (a wait expired) / 2 (the test hook),
+// watches members l, l + 64, ... (12 at most, in windows of 4).  Returns 0, or 1 (a wait expired) / 2 (the test hook),
 // meaningful in thread 0; tn / tx: this lane's share of the fold (identities outside wave 0).
 __device__ __forceinline__ int slots_meet(unsigned long long* slots, int member, int Gs, float cmn, float cmx, unsigned flags,
                                           long long timeout_ticks, float& tn, float& tx) {
-    static_assert(GRP_GS_MAX <= 8 * 64, "a lane of wave 0 watches at most 8 members");
+    static_assert(GRP_GS_BIG <= 12 * 64, "a lane of wave 0 watches at most 12 members (three windows of 4)");
     const int tid = threadIdx.x;
     tn = INFINITY;
     tx = -INFINITY;

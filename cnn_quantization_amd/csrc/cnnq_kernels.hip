@@ -495,7 +495,7 @@ size_t cnnq_pc_group_workspace(int64_t N, int64_t C, int64_t HW) {
     // the larger of the two tilings a caller may end up with (flat tiles for the single launch, row pieces for
     // k_minmax_group's half of the multi-GPU path)
     GPlan p, q;
-    const size_t a = plan_group(N, C, HW, true, &p) ? 0 : p.ws_bytes;
+    const size_t a = plan_group(N, C, HW, true, &p, true, 1) ? 0 : p.ws_bytes;
     const size_t b = plan_group(N, C, HW, true, &q, /*allow_flat=*/false) ? 0 : q.ws_bytes;
     return a > b ? a : b;
 }
@@ -550,7 +550,7 @@ int cnnq_debug_group_trace(void* buf) {
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]) {
     if (!out) return CNNQ_EINVAL;
     GPlan p;
-    const int rc = plan_group(N, C, HW, true, &p);
+    const int rc = plan_group(N, C, HW, true, &p, true, 1);
     if (rc) return rc;
     const int32_t vals[8] = {p.v.A, p.K + p.KL, p.g.mode, p.g.S, p.g.ncb, p.Gs, p.ngroups, p.g.S * p.g.ncb};
     for (int i = 0; i < 8; ++i) out[i] = vals[i];
@@ -837,7 +837,7 @@ int cnnq_pc_aciq_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW,
 }
 
 // Config 3 with pass B, the parameters and the Q/DQ in ONE launch (cnnq_aciq.hip.h): pass A -> merge -> (bit allocation)
-// -> k_aciq_flat / k_aciq_group: 12 instead of 16 bytes per element, four launches.  Laplace clipping on the per-channel
+// -> k_fused_flat / k_fused_group<MODE 0>: 12 instead of 16 bytes per element, four launches.  Laplace clipping on the per-channel
 // route (clip == 1, no direct_range), bit allocation on the 'gaus' prior only (the 'laplace' prior IS b, which only exists
 // inside the last launch).  CNNQ_ENOTSUP - nothing enqueued - for every other configuration, for shapes without a
 // single-launch plan and for a `gws` too small: the caller takes cnnq_pc_aciq_qdq.  ws: part[G][CNNQ_NMOM][C] doubles
@@ -853,7 +853,7 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
     if (use_ba && !diag) return CNNQ_EINVAL;                     // the bit table lives in diag
     if (cfg->clip != 1 || cfg->direct_range || (use_ba && cfg->prior_is_b) || !gws) return CNNQ_ENOTSUP;
     GPlan gp;
-    if (plan_group(N, C, HW, al16(x) && al16(y), &gp) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    if (plan_group(N, C, HW, al16(x) && al16(y), &gp, true, 1) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
     if ((size_t)gp.ngroups * gp.gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
@@ -871,7 +871,7 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
         rc = launch_status();
     }
     if (rc) return rc;
-    AciqArgs aa;
+    FusedArgs aa = {};
     aa.stats = stats;
     aa.bits = bits;
     aa.qp = qp;
@@ -882,7 +882,7 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
     xo.codes = codes;
     xo.hist = reinterpret_cast<unsigned long long*>(hist_rep);
     xo.packed = nullptr;
-    return launch_aciq(x, y, gp, aa, gws, flags & 3u, st, (codes || hist_rep) ? 1 : 0, xo);
+    return launch_fused(0, x, y, gp, aa, gws, flags & 3u, st, (codes || hist_rep) ? 1 : 0, xo);
 }
 
 // ... behind ONE call with the chain as the fallback: ws as cnnq_pc_aciq_qdq (cnnq_pc_aciq_workspace bytes); the
@@ -990,7 +990,7 @@ int cnnq_pc_midtread_params(const float* stats, int64_t C, double target, int cl
                             int ntab, float* mt, void* stream) {
     if (!stats || !mt || !tables || ntab < 2 || C <= 0 || C >= ((int64_t)1 << 31)) return CNNQ_EINVAL;
     const MtCfg cfg{target, clip ? 1 : 0, sym ? 1 : 0};
-    hipLaunchKernelGGL(k_mt_params, dim3(1), dim3(PTPB), 0, (hipStream_t)stream, stats, (int)C, cfg, tables, ntab, mt);
+    hipLaunchKernelGGL(k_mt_params<false>, dim3(1), dim3(PTPB), 0, (hipStream_t)stream, stats, (int)C, cfg, tables, ntab, mt);
     return launch_status();
 }
 
@@ -1024,6 +1024,42 @@ int cnnq_pc_midtread_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t
 #undef LAUNCH_MT
 #undef LAUNCH_MT3
     return launch_status();
+}
+
+// Config 5 with pass B, the step sizes / clamp bounds and the quantization in ONE launch (cnnq_aciq.hip.h, MODE 1): pass A ->
+// merge -> k_mt_params<GUESS> (omega and the clipping multiplier need nothing but the std) -> k_fused_flat / k_fused_group:
+// 12 instead of 16 bytes per element.  clip = 1 only (without clipping nothing needs pass B).  hist (optional,
+// CNNQ_MT_HIST_WORDS(C) words) is zeroed here.  CNNQ_ENOTSUP - nothing enqueued - for shapes without a single-launch plan or a
+// gws that is NULL / too small: the caller takes pc_stats -> cnnq_pc_midtread_params -> cnnq_pc_midtread_qdq.
+int cnnq_pc_midtread_qdq_single(const float* x, float* y, int64_t N, int64_t C, int64_t HW, double target, int sym,
+                                const double* tables, int ntab, void* ws, void* gws, size_t gws_bytes, float* stats, float* mt,
+                                uint64_t* hist, unsigned flags, void* stream) {
+    if (!x || !y || !tables || ntab < 2 || !ws || !stats || !mt || ((uintptr_t)ws & 7) || ((uintptr_t)hist & 7)) return CNNQ_EINVAL;
+    if (gws && ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
+    if (!gws) return CNNQ_ENOTSUP;
+    GPlan gp;
+    if (plan_group(N, C, HW, al16(x) && al16(y), &gp, true, 1) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    if ((size_t)gp.ngroups * gp.gstride * 8 > GRP_WS_SLOT_BYTES || (!gp.flat && gp.v.A != 1)) return CNNQ_ENOTSUP;
+    const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
+    if (G <= 0) return G ? G : CNNQ_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    hipStream_t st = (hipStream_t)stream;
+    if (hist && hipMemsetAsync(hist, 0, (size_t)CNNQ_MT_HIST_WORDS(C) * sizeof(uint64_t), st) != hipSuccess) return launch_status();
+    int rc = cnnq_pc_moments(x, N, C, HW, 0, part, stream);
+    if (rc) return rc;
+    rc = cnnq_pc_combine(part, G, C, 0, nullptr, stats, stream);
+    if (rc) return rc;
+    const MtCfg mcfg{target, 1, sym ? 1 : 0};
+    hipLaunchKernelGGL(k_mt_params<true>, dim3(1), dim3(PTPB), 0, st, stats, (int)C, mcfg, tables, ntab, mt);
+    rc = launch_status();
+    if (rc) return rc;
+    FusedArgs fa = {};
+    fa.stats = stats;
+    fa.count = (double)N * (double)HW;
+    fa.mt = mt;
+    fa.mcfg = mcfg;
+    fa.hist = reinterpret_cast<unsigned long long*>(hist);
+    return launch_fused(1, x, y, gp, fa, gws, flags & 3u, st, hist ? 1 : 0, XOut{});
 }
 
 int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int64_t total, float* out, void* stream) {

@@ -22,6 +22,54 @@ constexpr int MT_REP = 8;                 // LDS copies of a window bin (by lane
 // last word of the histogram: non-zero when any count went to the global bins [0, MT_NB + 2) (a code outside the window)
 __host__ __device__ constexpr size_t mt_flag_word(int C) { return (size_t)MT_NB + 2 + 2 * (size_t)C + (size_t)MT_GR * MT_W; }
 
+// eq. 10 (iq.py:128-135) for one channel: omega = round(C * 2^target * sigma^(2/3) / sum sigma^(2/3)), and the clipping
+// multiplier of that many bins by linear interpolation in the (omega, alpha) table, fp64 like numpy (iq.py:137-145)
+__device__ __forceinline__ void mt_omega_alpha(const MtCfg& cfg, float B, float psum, float vstd, const double* __restrict__ otab,
+                                               const double* __restrict__ atab, int ntab, float& omega, float& am) {
+    const float p = powf(vstd, (float)(2. / 3));
+    omega = rintf((B * p) / psum);
+    am = 0.f;
+    if (cfg.clip) {
+        const double om = (double)(cfg.sym ? omega : omega * 2.f);
+        int lo = 0, hi = ntab;  // searchsorted, side='left'
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (otab[mid] < om) lo = mid + 1; else hi = mid;
+        }
+        const int i = lo < ntab ? lo : ntab - 1;     // (the reference raises beyond the table)
+        const int im = i == 0 ? ntab - 1 : i - 1;    // numpy's index -1 wraps
+        const double inc = (atab[i] - atab[im]) / (otab[i] - otab[im]);
+        am = (float)(atab[i] - inc * (otab[i] - om));
+    }
+}
+
+// step size and clamp bounds of one channel (iq.py:193-214) - the single definition of this arithmetic: k_mt_params runs it
+// per table row, the single-launch kernels (cnnq_aciq.hip.h) in every workgroup that holds a piece of the channel
+struct MtChan {
+    float delta, cmin, cmax;
+};
+__device__ __forceinline__ MtChan mt_channel(const MtCfg& cfg, float omega, float am, float vmin, float vmax, float mu, float vb) {
+    MtChan r;
+    const float mu0 = fmaxf(mu, 0.f);
+    float rng;
+    if (cfg.clip) rng = cfg.sym ? (2.f * am) * vb : mu0 + am * vb;
+    else rng = cfg.sym ? vmax - vmin : vmax;
+    r.delta = (omega > 0.f) ? rng / omega : 3.402823466e+38f;
+    r.cmin = -INFINITY;
+    r.cmax = INFINITY;
+    if (cfg.clip) {
+        const float muq = (cfg.sym ? mu : mu0) / r.delta;
+        r.cmax = muq + (cfg.sym ? omega / 2.f : omega);
+        r.cmin = cfg.sym ? muq - omega / 2.f : 0.f;
+    }
+    return r;
+}
+
+// GUESS: before pass B nothing but the std is known, so the single-launch form cannot compute the smallest clamp bound the
+// histogram window starts at - it takes the bound a Laplace channel (b = std / sqrt 2) would have.  Exact (0) for the
+// non-negative range; for the symmetric range only the speed of the histogram depends on it (codes outside the window are
+// counted in the global bins, and the flag word tells k_mt_entropy to read them).
+template <bool GUESS>
 __global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ stats, int C, const MtCfg cfg,
                                                     const double* __restrict__ tabs, int ntab,
                                                     float* __restrict__ mt) {
@@ -34,47 +82,23 @@ __global__ void __launch_bounds__(PTPB) k_mt_params(const float* __restrict__ st
     const float* vb = stats + (size_t)CNNQ_STAT_B * C;
     const double* otab = tabs;
     const double* atab = tabs + ntab;
-    // eq. 10 (iq.py:128-135): omega = round(C * 2^target * sigma^(2/3) / sum sigma^(2/3))
     double psum_d = 0.;
     for (int c = tid; c < C; c += PTPB) psum_d += (double)powf(vstd[c], (float)(2. / 3));
     const float psum = (float)block_sum(psum_d, sh);
     const float B = (float)((double)C * pow(2., cfg.target));
     float wmin = 1e9f;
     for (int c = tid; c < C; c += PTPB) {
-        const float p = powf(vstd[c], (float)(2. / 3));
-        const float omega = rintf((B * p) / psum);
-        float rng, am = 0.f;
-        const float mu = vmean[c];
-        const float mu0 = fmaxf(mu, 0.f);
-        if (cfg.clip) {
-            // linear interpolation in the (omega, alpha) table, fp64 like numpy (iq.py:137-145)
-            const double om = (double)(cfg.sym ? omega : omega * 2.f);
-            int lo = 0, hi = ntab;  // searchsorted, side='left'
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (otab[mid] < om) lo = mid + 1; else hi = mid;
-            }
-            const int i = lo < ntab ? lo : ntab - 1;     // (the reference raises beyond the table)
-            const int im = i == 0 ? ntab - 1 : i - 1;    // numpy's index -1 wraps
-            const double inc = (atab[i] - atab[im]) / (otab[i] - otab[im]);
-            am = (float)(atab[i] - inc * (otab[i] - om));
-            rng = cfg.sym ? (2.f * am) * vb[c] : mu0 + am * vb[c];
-        } else {
-            rng = cfg.sym ? vmax[c] - vmin[c] : vmax[c];
+        float omega, am;
+        mt_omega_alpha(cfg, B, psum, vstd[c], otab, atab, ntab, omega, am);
+        const MtChan r = mt_channel(cfg, omega, am, vmin[c], vmax[c], vmean[c], GUESS ? vstd[c] * 0.70710678f : vb[c]);
+        if constexpr (!GUESS) {
+            mt[(size_t)CNNQ_MT_DELTA * C + c] = r.delta;
+            mt[(size_t)CNNQ_MT_CMIN * C + c] = r.cmin;
+            mt[(size_t)CNNQ_MT_CMAX * C + c] = r.cmax;
         }
-        const float delta = (omega > 0.f) ? rng / omega : 3.402823466e+38f;
-        float cmin = -INFINITY, cmax = INFINITY;
-        if (cfg.clip) {
-            const float muq = (cfg.sym ? mu : mu0) / delta;
-            cmax = muq + (cfg.sym ? omega / 2.f : omega);
-            cmin = cfg.sym ? muq - omega / 2.f : 0.f;
-        }
-        mt[(size_t)CNNQ_MT_DELTA * C + c] = delta;
-        mt[(size_t)CNNQ_MT_CMIN * C + c] = cmin;
-        mt[(size_t)CNNQ_MT_CMAX * C + c] = cmax;
         mt[(size_t)CNNQ_MT_OMEGA * C + c] = omega;
         mt[(size_t)CNNQ_MT_ALPHA * C + c] = am;
-        if (cfg.clip) wmin = fminf(wmin, floorf(fminf(fmaxf(cmin, -1e9f), 1e9f)));
+        if (cfg.clip) wmin = fminf(wmin, floorf(fminf(fmaxf(r.cmin, -1e9f), 1e9f)));
     }
     // first code of the histogram window: the smallest clamp bound of the tensor (codes are >= c_min); without
     // clipping the window is centred on zero

@@ -270,7 +270,11 @@ constexpr size_t GRP_WS_SLOT_BYTES = (size_t)16 * GRP_MAX_LINES * 8;   // 2 MB: 
 constexpr size_t GRP_WS_PAIRS = GRP_WS_SLOTS + GRP_WS_SLOT_BYTES;      // pair blocks / records: written before read, may hold anything
 
 // flat tiles (k_mmq_flat) when a channel row is long enough that the row-piece tiling of k_mmq_group would idle lanes
-int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
+// lds_rows: 0 - never; 1 - eight more tile rows in LDS (KL = 8) only for channels too populous for GRP_GS_MAX plain K = 32
+// tiles (VGG-16 b512 [512,64,224,224]: 103 MB per channel -> 628 members of 160 KB, one channel on the chip at a time);
+// 2 - for every K = 32 plan (development knob CNNQ_FLAT_KL=8).  allow_full: also rows that are whole multiples of the
+// workgroup (the row pieces of k_mmq_group fill every lane there and are tried first).
+int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, int lds_rows, bool allow_full) {
     static const int allow = env_int("CNNQ_GRP_FLAT", 1);       // development knob
     static const int forceK = env_int("CNNQ_GRP_K", 0);
     static const int target = env_int("CNNQ_GRP_WGS", 1024);
@@ -278,7 +282,7 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     const int64_t cpc = HW / 4;
     static const int mincpc = env_int("CNNQ_FLAT_MINCPC", 128);   // development knob
     if (cpc < mincpc || C * HW >= (int64_t)1 << 31 || N * cpc >= (int64_t)1 << 31) return CNNQ_ENOTSUP;
-    if (cpc % TPB == 0) return CNNQ_ENOTSUP;     // the row pieces already fill every lane
+    if (cpc % TPB == 0 && !allow_full) return CNNQ_ENOTSUP;     // the row pieces already fill every lane
     const int64_t total = N * cpc;
     int K = 8;
     if (forceK == 8 || forceK == 16 || forceK == 32) {
@@ -290,9 +294,15 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
     // round 4: eight more steps per tile in LDS (160 KB per workgroup; flat_lds_rows() below: a development knob).  Measured +1.5 %
     // on the packed single launch with the counter meeting, nothing with the slot meeting, -1 % on the b512 step
-    const int KL = (K == 32 && lds_rows) ? 8 : 0;
-    const int64_t Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
-    if (Gs > GRP_GS_MAX || Gs < 2) return CNNQ_ENOTSUP;
+    int KL = (K == 32 && lds_rows == 2) ? 8 : 0;
+    int64_t Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
+    int64_t gs_max = GRP_GS_MAX;
+    if (Gs > GRP_GS_MAX && K == 32 && lds_rows >= 1) {          // a big channel: 160 KB tiles, the channel alone on the chip
+        KL = 8;
+        Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
+        gs_max = GRP_GS_BIG;
+    }
+    if (Gs > gs_max || Gs < 2) return CNNQ_ENOTSUP;
     const int64_t rows = (TPB * (K + KL)) / cpc + 3;             // samples a tile can touch, with slack
     if (rows * C * HW * 4 >= (int64_t)1 << 32) return CNNQ_ENOTSUP;
     const int64_t nsub = (Gs + GRP_SUB - 1) / GRP_SUB;
@@ -322,23 +332,24 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, bool lds_rows) {
     return 0;
 }
 
-int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, bool lds_rows);
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, int lds_rows);
 
-// CNNQ_FLAT_KL=8 (development knob): the flat tiles of the plain and the packed output take eight more steps in LDS
-// (k_mmq_flat<32, 0 / 2, false, 8>; the codes output and the cross-rank stage have no such instance)
-inline bool flat_lds_rows(int out, bool xrank) {
+// the lds_rows argument of the config-2 kernels' plans: k_mmq_flat has KL = 8 instances for the plain and the packed output
+// (<32, 0 / 2, false, 8>), none for the codes output and the cross-rank stage; CNNQ_FLAT_KL=8 (development knob): every
+// K = 32 plan takes them
+inline int flat_lds_rows(int out, bool xrank) {
     static const int kl_knob = env_int("CNNQ_FLAT_KL", 0);
-    return kl_knob == 8 && out != 1 && !xrank;
+    return (out == 1 || xrank) ? 0 : (kl_knob == 8 ? 2 : 1);
 }
 
 // plans are pure functions of their arguments (the development knobs are read once): the hot call asks for the same
 // handful of geometries over and over, so each host thread remembers the last 64
-int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true, bool lds_rows = false) {
+int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true, int lds_rows = 0) {
     struct Entry { int64_t N, C, HW; int key, rc; GPlan plan; };
     constexpr int SLOTS = 64;
     thread_local Entry cache[SLOTS];
     thread_local int used = 0, next = 0;
-    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0) | (lds_rows ? 4 : 0);
+    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0) | (lds_rows << 2);
     for (int i = 0; i < used; ++i)
         if (cache[i].N == N && cache[i].C == C && cache[i].HW == HW && cache[i].key == key) {
             *p = cache[i].plan;
@@ -352,12 +363,25 @@ int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool 
     return rc;
 }
 
-int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, bool lds_rows) {
+int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p);
+
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, int lds_rows) {
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (!aligned16) return CNNQ_ENOTSUP;
     p->flat = 0;
     p->KL = 0;
-    if (allow_flat && plan_flat(N, C, HW, p, lds_rows) == 0) return 0;
+    if (allow_flat && plan_flat(N, C, HW, p, lds_rows, false) == 0) return 0;
+    const int rc = plan_rows(N, C, HW, p);
+    if (rc != CNNQ_ENOTSUP || !allow_flat || lds_rows == 0) return rc;
+    // neither fits: a channel too populous for 512 plain tiles - flat tiles with eight more rows in LDS, if that is enough
+    GPlan q;
+    if (plan_flat(N, C, HW, &q, lds_rows, true) != 0 || q.KL != 8) return rc;
+    *p = q;
+    return 0;
+}
+
+// the row-piece tiling of k_mmq_group
+int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p) {
     p->flat = 0;
     p->KL = 0;
     if (HW % 4 == 0) {
@@ -461,10 +485,14 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     return launch_status();
 }
 
-// the single-launch ACIQ kernels (cnnq_aciq.hip.h) on the plan and the workspace of launch_group; slot meeting only
-int launch_aciq(const float* x, float* y, const GPlan& p, const AciqArgs& aa, void* ws, unsigned flags, hipStream_t st, int out,
-                const XOut& xo) {
-    if ((size_t)p.ngroups * p.gstride * 8 > GRP_WS_SLOT_BYTES || p.KL) return CNNQ_ENOTSUP;
+// the single-launch ACIQ / mid-tread kernels (cnnq_aciq.hip.h; mode 0 / 1) on the plan and the workspace of launch_group;
+// slot meeting only.  out: mode 0 - 1 with codes / histogram (xo); mode 1 - 1 with the code histogram (fa.hist)
+int launch_fused(int mode, const float* x, float* y, const GPlan& p, const FusedArgs& fa, void* ws, unsigned flags, hipStream_t st,
+                 int out, const XOut& xo) {
+    if ((size_t)p.ngroups * p.gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
+    if (p.KL && !(p.flat && p.K == 32 && p.KL == 8)) return CNNQ_ENOTSUP;
+    if (mode == 1 && !p.flat && p.v.A != 1) return CNNQ_ENOTSUP;      // no straddling mid-tread instance
+    if (p.KL && mode == 0 && out == 1) return CNNQ_ENOTSUP;          // 32 KB of LDS rows + the 32 KB code table: two workgroups per CU, a big channel needs three
     flags |= mmq_env_flags();
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
@@ -475,27 +503,34 @@ int launch_aciq(const float* x, float* y, const GPlan& p, const AciqArgs& aa, vo
     const dim3 block(TPB);
     if (p.flat) {
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
-#define LAUNCH_AF(K)                                                                                            \
-    do {                                                                                                        \
-        if (out == 1) hipLaunchKernelGGL((k_aciq_flat<K, 1>), fgrid, block, 0, st, x, y, p.fg, w, aa, flags, xo);  \
-        else hipLaunchKernelGGL((k_aciq_flat<K, 0>), fgrid, block, 0, st, x, y, p.fg, w, aa, flags, xo);           \
+#define LAUNCH_FF(K, KL)                                                                                                   \
+    do {                                                                                                                   \
+        if (mode == 0 && out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, 0, 0>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);   \
+        else if (mode == 0) hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 0>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);         \
+        else if (out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, KL, 1>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);          \
+        else hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 1>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);                        \
     } while (0)
-        if (p.K == 32) LAUNCH_AF(32); else if (p.K == 16) LAUNCH_AF(16); else LAUNCH_AF(8);
-#undef LAUNCH_AF
+        if (p.K == 32 && p.KL == 8) LAUNCH_FF(32, 8);
+        else if (p.K == 32) LAUNCH_FF(32, 0);
+        else if (p.K == 16) LAUNCH_FF(16, 0);
+        else LAUNCH_FF(8, 0);
+#undef LAUNCH_FF
         return launch_status();
     }
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb));
-#define LAUNCH_AG(A, K)                                                                                                 \
-    do {                                                                                                                \
-        if (out == 1) hipLaunchKernelGGL((k_aciq_group<A, K, 1>), grid, block, 0, st, x, y, p.g, p.Gs, w, aa, flags, xo);  \
-        else hipLaunchKernelGGL((k_aciq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, w, aa, flags, xo);           \
+#define LAUNCH_FG(A, K, MODE)                                                                                                   \
+    do {                                                                                                                        \
+        if (out == 1) hipLaunchKernelGGL((k_fused_group<A, K, 1, MODE>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo);   \
+        else hipLaunchKernelGGL((k_fused_group<A, K, 0, MODE>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo);            \
     } while (0)
-    if (p.v.A == 4) {
-        if (p.K == 32) LAUNCH_AG(4, 32); else if (p.K == 16) LAUNCH_AG(4, 16); else if (p.K == 8) LAUNCH_AG(4, 8); else LAUNCH_AG(4, 4);
+    if (mode == 1) {
+        if (p.K == 32) LAUNCH_FG(1, 32, 1); else if (p.K == 16) LAUNCH_FG(1, 16, 1); else if (p.K == 8) LAUNCH_FG(1, 8, 1); else LAUNCH_FG(1, 4, 1);
+    } else if (p.v.A == 4) {
+        if (p.K == 32) LAUNCH_FG(4, 32, 0); else if (p.K == 16) LAUNCH_FG(4, 16, 0); else if (p.K == 8) LAUNCH_FG(4, 8, 0); else LAUNCH_FG(4, 4, 0);
     } else {
-        if (p.K == 32) LAUNCH_AG(1, 32); else if (p.K == 16) LAUNCH_AG(1, 16); else if (p.K == 8) LAUNCH_AG(1, 8); else LAUNCH_AG(1, 4);
+        if (p.K == 32) LAUNCH_FG(1, 32, 0); else if (p.K == 16) LAUNCH_FG(1, 16, 0); else if (p.K == 8) LAUNCH_FG(1, 8, 0); else LAUNCH_FG(1, 4, 0);
     }
-#undef LAUNCH_AG
+#undef LAUNCH_FG
     return launch_status();
 }
 

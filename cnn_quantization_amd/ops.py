@@ -1085,8 +1085,15 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
     N, C, HW = (1, 1, x.numel()) if whole_tensor else geometry(x, per_channel_dim)
     local = group is False
     grp = None if local else group
-    stats, _ = pc_stats(x, N, C, HW, need_b=bool(clip), group=grp, local_only=local)
     tabs = _midtread_tables(x.device)
+    if (_ACIQ_SINGLE and _RESIDENT and clip and not whole_tensor and per_channel_dim == 1 and not want_codes
+            and (local or D.world_size(grp) == 1)):
+        # pass B, the step sizes / clamp bounds and the quantization in ONE launch that reads x once
+        # (cnnq_pc_midtread_qdq_single: 12 instead of 16 bytes per element) when the shape has a single-launch plan
+        res = mid_tread_qdq_single(x, N, C, HW, target, sym, tabs, want_entropy, want_parts)
+        if res is not None:
+            return res
+    stats, _ = pc_stats(x, N, C, HW, need_b=bool(clip), group=grp, local_only=local)
     mt = torch.empty((L.NMT, C), dtype=torch.float32, device=x.device)
     L.check(lib.cnnq_pc_midtread_params(_ptr(stats), C, float(target), int(bool(clip)), int(bool(sym)), _ptr(tabs),
                                         tabs.shape[1], _ptr(mt), _stream(x)), 'cnnq_pc_midtread_params')
@@ -1107,6 +1114,40 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
     res = [y, entropy]
     if want_codes:
         res.append(codes)
+    if want_parts:
+        res.append(dict(stats=stats, mt=mt, hist=hist))
+    return tuple(res)
+
+
+def mid_tread_qdq_single(x, N, C, HW, target, sym, tabs, want_entropy=False, want_parts=False, flags=0):
+    """Config 5 with clipping in four launches (cnnq_pc_midtread_qdq_single) + the entropy kernel.  Returns what mid_tread_qdq
+    returns, or None when the shape has no single-launch plan."""
+    lib = L.load()
+    st = _raw_stream(x.device.index)
+    gws = _group_workspace(x, st)
+    if gws is None:
+        return None
+    al = int(x.data_ptr() % 16 == 0)
+    key = ('aciq', N, C, HW, al)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WS_BYTES[key] = (lib.cnnq_pc_aciq_workspace(N, C, HW, al) + 15) // 16 * 16
+    ws = _scratch(x, 'aciq', nbytes + (L.NQP + L.NDIAG) * C * 4, st)
+    y = torch.empty_like(x)
+    tabs_out = torch.empty((L.NSTAT + L.NMT, C), dtype=torch.float32, device=x.device)
+    stats, mt = tabs_out[:L.NSTAT], tabs_out[L.NSTAT:]
+    hist = torch.empty(L.mt_hist_words(C), dtype=torch.int64, device=x.device) if want_entropy else None     # zeroed by the call
+    rc = lib.cnnq_pc_midtread_qdq_single(_ptr(x), _ptr(y), N, C, HW, float(target), int(bool(sym)), _ptr(tabs), tabs.shape[1],
+                                         ws.data_ptr(), gws, GROUP_WS_BYTES, _ptr(stats), _ptr(mt), _ptr(hist), int(flags), st)
+    if rc == L.ENOTSUP:
+        return None
+    L.check(rc, 'cnnq_pc_midtread_qdq_single')
+    entropy = None
+    if want_entropy:
+        ent = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_midtread_entropy(_ptr(hist), _ptr(mt), C, x.numel(), _ptr(ent), st), 'cnnq_midtread_entropy')
+        entropy = ent[0]
+    res = [y, entropy]
     if want_parts:
         res.append(dict(stats=stats, mt=mt, hist=hist))
     return tuple(res)

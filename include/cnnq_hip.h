@@ -450,6 +450,17 @@ int cnnq_pc_midtread_params(const float* stats, int64_t C, double target, int cl
                             int ntab, float* mt, void* stream);
 int cnnq_pc_midtread_qdq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const float* mt, int clip,
                          float* codes, uint64_t* hist, void* stream);
+/* Config 5 (clip = 1) with pass B, the parameter derivation and the quantization in ONE launch that reads x once (round 5;
+ * csrc/cnnq_aciq.hip.h MODE 1): pass A, merge, omega / clipping multiplier from the std alone, the single launch - 12 instead of
+ * 16 bytes per element.  Channels too populous for the plain register tiles ([512,64,224,224]: 103 MB per channel) take eight
+ * more tile rows in LDS and have the chip to themselves, one channel at a time.  mt: out, every row; row WSTART is the exact
+ * first code of the histogram window for the non-negative range and an estimate (b = std / sqrt 2) for the symmetric one - the
+ * histogram is correct either way (codes outside the window are counted in the global bins and the flag word says so).
+ * stats [CNNQ_NSTAT][C] out; ws >= cnnq_pc_aciq_workspace bytes; gws / flags as cnnq_pc_aciq_qdq_single; hist: optional,
+ * CNNQ_MT_HIST_WORDS(C) words, zeroed HERE (cnnq_midtread_entropy consumes it).  CNNQ_ENOTSUP: no single-launch plan. */
+int cnnq_pc_midtread_qdq_single(const float* x, float* y, int64_t N, int64_t C, int64_t HW, double target, int sym,
+                                const double* tables, int ntab, void* ws, void* gws, size_t gws_bytes, float* stats, float* mt,
+                                uint64_t* hist, unsigned flags, void* stream);
 int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int64_t total, float* out, void* stream);
 
 /* Shannon entropy in bits, -sum p*log2(p) over the non-empty bins -> out[0] (utils/entropy.py:12-15). */

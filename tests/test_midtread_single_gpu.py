@@ -1,0 +1,224 @@
+"""Config 5 (mid-tread quantization with bin allocation, clipping around the mean, entropy of the codes; iq.py:185-225)
+with pass B, the step sizes / clamp bounds and the quantization in ONE launch (cnnq_pc_midtread_qdq_single,
+csrc/cnnq_aciq.hip.h MODE 1), and the big-channel tiles (eight more rows in LDS) that the planner falls back to when a
+channel's batch population exceeds 512 plain register tiles.  What must hold:
+
+* given the device's own statistics table, the single launch equals the two kernels that are pinned bit for bit to the
+  reference (tests/test_hip_parity.py::test_midtread_bit_exact_given_oracle_stats): cnnq_pc_midtread_params +
+  cnnq_pc_midtread_qdq on that table - every parameter row and every output float, and the entropy of the codes;
+* the reference-generated golden vectors within the statistics tier, through ops.mid_tread_qdq (which now routes here);
+* the sum exchange is deterministic: meeting == forced recompute == IEEE divide == a second run, workspace zero at rest;
+* big channels (> 512 tiles of 128 KB per channel): config 2, config 3 and config 5 through the 160 KB tiles equal their
+  chains.
+Needs an MI355X: `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from cnn_quantization_amd import ops as _ops
+    return _ops
+
+
+def acts(shape, seed, relu, device='cpu'):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    C = shape[1]
+    x = torch.empty(shape, device=device).exponential_(1.0, generator=gen)
+    x = x * (torch.rand(shape, generator=gen, device=device) < 0.5).float().mul_(2).sub_(1)
+    x = x * (torch.rand(1, C, 1, 1, generator=gen, device=device) * 3 + 0.05) + torch.randn(1, C, 1, 1, generator=gen, device=device) * 0.3
+    if relu:
+        x = x.clamp_(min=0)
+    if C > 2:
+        x[:, C // 2] = 0. if relu else 0.25            # a constant channel: std == 0 -> omega == 0, delta = FLT_MAX
+    return x.contiguous()
+
+
+def chain_on_table(ops, xd, stats, target, sym, want_hist):
+    """The two reference-pinned kernels on a given statistics table: (y, mt, entropy)."""
+    from cnn_quantization_amd import _lib as L
+    lib = L.load()
+    N, C = xd.shape[:2]
+    HW = xd[0, 0].numel()
+    tabs = ops._midtread_tables(xd.device)
+    mt = torch.empty((L.NMT, C), dtype=torch.float32, device=xd.device)
+    L.check(lib.cnnq_pc_midtread_params(ops._ptr(stats.contiguous()), C, float(target), 1, int(sym), ops._ptr(tabs), tabs.shape[1],
+                                        ops._ptr(mt), ops._stream(xd)), 'params')
+    y = torch.empty_like(xd)
+    hist = torch.zeros(L.mt_hist_words(C), dtype=torch.int64, device=xd.device) if want_hist else None
+    L.check(lib.cnnq_pc_midtread_qdq(ops._ptr(xd), ops._ptr(y), N, C, HW, ops._ptr(mt), 1, None, ops._ptr(hist), ops._stream(xd)), 'qdq')
+    ent = None
+    if want_hist:
+        e = torch.empty(1, dtype=torch.float32, device=xd.device)
+        L.check(lib.cnnq_midtread_entropy(ops._ptr(hist), ops._ptr(mt), C, xd.numel(), ops._ptr(e), ops._stream(xd)), 'entropy')
+        ent = float(e)
+    return y, mt, ent, hist
+
+
+def hist_counts(hist, mt, C):
+    """The histogram as {code value: count}, whatever mix of window replicas and global bins holds it."""
+    from cnn_quantization_amd import _lib as L
+    h = hist.cpu().numpy()
+    nb, w, gr = L.MT_HIST_BINS, L.MT_HIST_WINDOW, L.MT_HIST_REPLICAS
+    wstart = int(mt[L.MT_WSTART][0])
+    out = {}
+    for i in np.nonzero(h[:nb])[0]:
+        out[float(i - nb // 2)] = out.get(float(i - nb // 2), 0) + int(h[i])
+    rep = h[nb + 2 + 2 * C: nb + 2 + 2 * C + gr * w].reshape(gr, w).sum(0)
+    for i in np.nonzero(rep)[0]:
+        out[float(wstart + i)] = out.get(float(wstart + i), 0) + int(rep[i])
+    out['below'], out['above'] = int(h[nb]), int(h[nb + 1])
+    lo, hi = mt[L.MT_CMIN].cpu().numpy(), mt[L.MT_CMAX].cpu().numpy()
+    for c in range(C):
+        if h[nb + 2 + c]:
+            out[('lo', float(lo[c]))] = out.get(('lo', float(lo[c])), 0) + int(h[nb + 2 + c])
+        if h[nb + 2 + C + c]:
+            out[('hi', float(hi[c]))] = out.get(('hi', float(hi[c])), 0) + int(h[nb + 2 + C + c])
+    return out
+
+
+SHAPES = [(40, 6, 56, 56), (33, 5, 28, 28), (24, 3, 32, 32), (70, 12, 14, 14), (8, 4, 112, 112), (64, 37, 14, 14), (6, 3, 64, 64)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('sym', [False, True])
+def test_single_launch_equals_the_pinned_kernels_on_its_own_statistics(ops, shape, sym):
+    from cnn_quantization_amd import _lib as L
+    N, C = shape[:2]
+    HW = shape[2] * shape[3]
+    x = acts(shape, 11 + C + HW, relu=not sym)
+    xd = x.cuda()
+    ops.group_status(xd, clear=True)
+    tabs = ops._midtread_tables(xd.device)
+    res = ops.mid_tread_qdq_single(xd, N, C, HW, 4, sym, tabs, want_entropy=True, want_parts=True)
+    assert res is not None
+    y, ent, parts = res
+    st, mt = parts['stats'], parts['mt']
+    t64 = x.double().transpose(0, 1).reshape(C, -1)
+    assert torch.equal(st[L.STAT_MAX].cpu(), x.amax(dim=(0, 2, 3))) and torch.equal(st[L.STAT_MIN].cpu(), x.amin(dim=(0, 2, 3)))
+    b64 = (t64 - st[L.STAT_MEAN].cpu().double()[:, None]).abs().mean(1)
+    np.testing.assert_allclose(st[L.STAT_B].cpu().double(), b64, rtol=2e-6, atol=1e-9)
+    y0, mt0, ent0, hist0 = chain_on_table(ops, xd, st, 4, sym, True)
+    for r in (L.MT_DELTA, L.MT_CMIN, L.MT_CMAX, L.MT_OMEGA, L.MT_ALPHA):
+        assert bits_equal(mt[r].cpu(), mt0[r].cpu()), r
+    if not sym:
+        assert bits_equal(mt[L.MT_WSTART].cpu(), mt0[L.MT_WSTART].cpu())      # exact for the non-negative range
+    assert bits_equal(y.cpu(), y0.cpu())
+    assert hist_counts(parts['hist'], mt, C) == hist_counts(hist0, mt0, C)
+    assert abs(float(ent) - ent0) <= 1e-5 * max(1., ent0)
+    assert ops.group_status(xd) == 0
+
+
+@pytest.mark.parametrize('shape', SHAPES[:5])
+def test_recompute_path_and_reruns_give_the_same_bits(ops, shape):
+    N, C = shape[:2]
+    HW = shape[2] * shape[3]
+    xd = acts(shape, 5 + C, relu=True).cuda()
+    tabs = ops._midtread_tables(xd.device)
+    ops.group_status(xd, clear=True)
+    y0, e0, p0 = ops.mid_tread_qdq_single(xd, N, C, HW, 4, False, tabs, want_entropy=True, want_parts=True)
+    t0 = torch.cat([p0['stats'], p0['mt']]).clone()
+    y0, e0 = y0.clone(), float(e0)
+    for flags in (0, 1, 2, 3):
+        y1, e1, p1 = ops.mid_tread_qdq_single(xd, N, C, HW, 4, False, tabs, want_entropy=True, want_parts=True, flags=flags)
+        assert bits_equal(torch.cat([p1['stats'], p1['mt']]).cpu(), t0.cpu()), flags
+        assert bits_equal(y1.cpu(), y0.cpu()), flags
+        assert abs(float(e1) - e0) <= 1e-6, flags
+    assert ops.group_status(xd, clear=True) == ops.GROUP_TEST_HOOK
+    from cnn_quantization_amd import _lib
+    nz = ctypes.c_uint64()
+    ws = ops._GROUP_WS[(xd.device.index, ops._raw_stream(xd.device.index))]
+    assert _lib.load().cnnq_group_ws_at_rest(ws, ctypes.byref(nz)) == 0 and nz.value == 0
+
+
+def test_golden_through_the_pipeline(ops, golden):
+    """The reference-generated mid-tread vectors through ops.mid_tread_qdq without the codes output (the route that takes the
+    single launch): omega exact, alpha to 1e-6, y within a step on at most 5e-4 of the elements, entropy to 2e-3."""
+    from cnn_quantization_amd import _lib as L
+    g = golden('midtread')
+    n_single = 0
+    for key in g.np('names'):
+        key = str(key)
+        name, si = key.rsplit('_s', 1)
+        x = g.t('x' + si).cuda()
+        target, half = float(g.np(key + '_target')), bool(g.np(key + '_half'))
+        N, C = x.shape[:2]
+        single = ops.mid_tread_qdq_single(x, N, C, x[0, 0].numel(), target, not half, ops._midtread_tables(x.device)) is not None
+        n_single += int(single)
+        y, ent, parts = ops.mid_tread_qdq(x, target, clip=True, sym=not half, want_entropy=True, want_parts=True)
+        mt = parts['mt'].cpu()
+        assert np.array_equal(mt[L.MT_OMEGA].numpy(), g.np(key + '_omega')), key
+        np.testing.assert_allclose(mt[L.MT_ALPHA].numpy(), g.np(key + '_alpha_mult').astype(np.float32), rtol=1e-6, err_msg=key)
+        ref = g.np(key + '_y')
+        step = float(mt[L.MT_DELTA][mt[L.MT_OMEGA] > 0].max())
+        d = np.abs(y.cpu().numpy() - ref)
+        assert float(d.max()) <= step * 1.001 + 1e-6, key
+        assert float((d > 1e-5 * np.abs(ref) + 1e-7).mean()) <= 2e-3, key
+        assert abs(float(ent) - float(g.np(key + '_entropy'))) < 2e-3, key
+    assert n_single >= 4, n_single
+
+
+BIG = [(17, 2, 1024, 1024), (20, 2, 900, 1000)]      # > 512 tiles of 128 KB per channel: the 160 KB tiles (K = 32 + 8 LDS rows)
+
+
+@pytest.mark.parametrize('shape', BIG)
+def test_big_channels_take_the_lds_rows(ops, shape):
+    from cnn_quantization_amd import _lib as L
+    lib = L.load()
+    N, C = shape[:2]
+    HW = shape[2] * shape[3]
+    d = (ctypes.c_int32 * 8)()
+    assert lib.cnnq_pc_group_describe(N, C, HW, d) == 0 and d[1] == 40 and d[2] == 3 and 512 < d[5] * 40 // 32, list(d)
+    xd = acts(shape, 3, relu=False, device='cuda')
+    ops.group_status(xd, clear=True)
+    # config 2: the single launch against the three-launch chain
+    y = ops.minmax_qdq_group(xd, N, C, HW, 4, False)
+    assert y is not None
+    yc = ops.minmax_qdq_fused(xd, N, C, HW, 4, False, chain=True)
+    assert torch.equal(y, yc)
+    del y, yc
+    # config 3
+    y1, p1 = ops.aciq_qdq_single(xd, N, C, HW, 4, False, True, None, True, want_parts=True)
+    ops._ACIQ_SINGLE = False
+    try:
+        y0, p0 = ops.act_qdq_per_channel(xd, 4, clip='laplace', bit_alloc=True, want_parts=True)
+    finally:
+        ops.reload_switches()
+    np.testing.assert_allclose(p1['stats'][L.STAT_B].cpu(), p0['stats'][L.STAT_B].cpu(), rtol=2e-7, atol=0)
+    same = (p1['qp'] == p0['qp']).all(0)
+    assert int(same.sum()) >= C - 1 and torch.equal(y1[:, same], y0[:, same])
+    del y0, y1
+    # config 5, both ranges, with the entropy
+    tabs = ops._midtread_tables(xd.device)
+    for sym in (False, True):
+        y, ent, parts = ops.mid_tread_qdq_single(xd, N, C, HW, 4, sym, tabs, want_entropy=True, want_parts=True)
+        y0, mt0, ent0, _ = chain_on_table(ops, xd, parts['stats'], 4, sym, True)
+        assert bits_equal(parts['mt'][L.MT_DELTA].cpu(), mt0[L.MT_DELTA].cpu())
+        assert torch.equal(y, y0) and abs(float(ent) - ent0) <= 1e-5 * max(1., ent0)
+        del y, y0
+    assert ops.group_status(xd) == 0
+
+
+def test_vgg_first_layer_full_size(ops):
+    """[512,64,224,224] (6.6 GB, 103 MB per channel: 628 members, one channel on the chip at a time): config 5 with the entropy
+    through the single launch == the pinned kernels on its statistics."""
+    from cnn_quantization_amd import _lib as L
+    import bench
+    shape = (512, 64, 224, 224)
+    xd = bench.laplace_activation(shape, 77, torch.device('cuda')).clamp_(min=0)
+    ops.group_status(xd, clear=True)
+    y, ent, parts = ops.mid_tread_qdq(xd, 4, clip=True, sym=False, want_entropy=True, want_parts=True)
+    assert bits_equal(parts['stats'][L.STAT_MAX].cpu(), xd.amax(dim=(0, 2, 3)).cpu())
+    y0, mt0, ent0, _ = chain_on_table(ops, xd, parts['stats'], 4, False, True)
+    for r in (L.MT_DELTA, L.MT_CMIN, L.MT_CMAX, L.MT_OMEGA, L.MT_WSTART):
+        assert bits_equal(parts['mt'][r].cpu(), mt0[r].cpu()), r
+    assert torch.equal(y, y0)
+    assert abs(float(ent) - ent0) <= 1e-5 * max(1., ent0)
+    assert ops.group_status(xd) == 0
