@@ -15,11 +15,18 @@ def other_configs(ops, device, batch):
     largest tensor of the set."""
     from cnn_quantization_amd import _lib as Lb
 
-    def obj(elems, t, bpe, what, verified=None):
+    def obj(elems, t, bpe, what, verified=None, moved=None):
+        """bpe: SURVEY 8(d3)'s algorithmic bytes per element (what `frac` is priced on, comparable across rounds); moved: what
+        the launches of this round actually read + write per element where that is less (the single-launch forms keep their
+        tile in registers between the statistics and the quantization: one read of x fewer)."""
         gbs = elems * bpe / t / 1e9
-        return {'workload': what, 'ms': t * 1e3, 'value': elems / t, 'unit': 'elements/s', 'verified': verified,
-                'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                             'algorithmic_bytes_per_element': bpe, 'traffic': None}}
+        r = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+             'algorithmic_bytes_per_element': bpe, 'traffic': None}
+        if moved is not None:
+            r['bytes_moved_per_element'] = moved
+            r['achieved_moved'] = elems * moved / t / 1e9
+            r['frac_moved'] = elems * moved / t / 1e9 / HBM_PEAK_GBS
+        return {'workload': what, 'ms': t * 1e3, 'value': elems / t, 'unit': 'elements/s', 'verified': verified, 'roofline': r}
 
     def codes_consistent(y, codes, qp, C):
         sc, zp, qm = (qp[r].view(1, C, 1, 1) for r in (Lb.QP_SCALE, Lb.QP_ZP, Lb.QP_QMAX))
@@ -85,7 +92,8 @@ def other_configs(ops, device, batch):
     ok3 = (bool(torch.equal(y3, ys[big])) and codes_consistent(y3, c3, p3['qp'], Cb) and float(bits3.min()) >= 0
            and float(bits3.max()) <= 8 and abs(float(bits3.mean()) - 4.) <= 0.011 + 1. / Cb)      # iq.py:403, in steps of 1/C
     out['config3'] = obj(elems, t, 16, 'ResNet-50 b%d, per-channel int4 + ACIQ laplace + bit allocation, dynamic statistics '
-                         '(-c laplace -baa)' % batch, bool(ok3))
+                         '(-c laplace -baa): pass A, merge, bit allocation, then ONE launch for pass B + parameters + Q/DQ '
+                         '(cnnq_pc_aciq_qdq_single)' % batch, bool(ok3), moved=12)
     del ys, c3
     # the same configuration with the bit-allocated integer codes as the STORED result
     # (sum(bits)/8 bytes per position instead of 4 B/elem of dequantized floats); the packing pass alone is timed: its
@@ -145,8 +153,16 @@ def other_configs(ops, device, batch):
     d5, lo5, hi5 = (p5['mt'][r].view(1, Cv, 1, 1) for r in (Lb.MT_DELTA, Lb.MT_CMIN, Lb.MT_CMAX))
     ok5 = (bool(torch.equal(c5 * d5, y5)) and bool((c5 >= lo5).all()) and bool((c5 <= hi5).all())
            and int(p5['hist'][:-1].sum()) == xv.numel() and math.isfinite(float(e5)))
-    out['config5'] = obj(elems, t, 16, 'VGG-16 b%d, mid-tread per-channel W4A4 + ACIQ + bin allocation + entropy (-mtq -me)' % batch,
-                         bool(ok5))
+    # the timed route (no codes output) is the single launch; it is checked against the chain's outputs on the same tensor
+    y5s, e5s, p5s = ops.mid_tread_qdq(xv, 4, clip=True, sym=False, want_entropy=True, want_parts=True)
+    same5 = (p5s['mt'][Lb.MT_DELTA] == p5['mt'][Lb.MT_DELTA])
+    ok5 = (ok5 and int(same5.sum()) >= Cv - 1 and bool(torch.equal(y5s[:, same5], y5[:, same5]))
+           and abs(float(e5s) - float(e5)) <= 1e-3)
+    del y5s
+    out['config5'] = obj(elems, t, 16, 'VGG-16 b%d, mid-tread per-channel W4A4 + ACIQ + bin allocation + entropy (-mtq -me): pass A, '
+                         'merge, bin allocation, then ONE launch for pass B + step sizes + quantization + code histogram '
+                         '(cnnq_pc_midtread_qdq_single; the two 224x224 layers on 160 KB tiles, one channel on the chip at a time)'
+                         % batch, bool(ok5), moved=12)
     del vl, y5, c5
     torch.cuda.empty_cache()
     return out

@@ -180,6 +180,10 @@ __device__ __forceinline__ float mt_qdq1(float x, float d, float rd, float lo, f
     code = t;
     return t * d;
 }
+// LDS copies of a window bin in the single-launch kernels: one per lane of a 32-lane LDS service group (bank = lane % 32
+// whatever the code: conflict-free by construction, as the code table of config 2) - 16 KB per workgroup, affordable because
+// these workgroups are long-lived (k_mt_qdq's short tiles keep MT_REP = 8: 4 KB to zero and flush per 56 KB of x)
+constexpr int MTF_REP = 32;
 // one code into the histogram: zero and "clamped to a non-integer bound" in registers, an integer code inside the window one
 // LDS atomic, everything else (rare) straight to the global bins (the logic of k_mt_qdq)
 __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni, bool hi_ni, int wstart, unsigned* sh_hist,
@@ -195,7 +199,7 @@ __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni
     const unsigned kk = (unsigned)(k - wstart);
     const bool fast = ((float)k == t) && kk < (unsigned)MT_W;
     if (fast && !z) {
-        atomicAdd(&sh_hist[kk * MT_REP + ((unsigned)threadIdx.x & (MT_REP - 1))], 1u);
+        atomicAdd(&sh_hist[kk * MTF_REP + ((unsigned)threadIdx.x & (MTF_REP - 1))], 1u);
     } else if (!(z || at_hi || at_lo)) {        // rare
         if (t == rintf(t)) {                    // integer code outside the window (or inf)
             if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
@@ -212,7 +216,7 @@ __device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* 
     if (nzero) {
         const int kk = -wstart;
         if (kk >= 0 && kk < MT_W) {
-            atomicAdd(&sh_hist[(unsigned)kk * MT_REP + ((unsigned)tid & (MT_REP - 1))], nzero);
+            atomicAdd(&sh_hist[(unsigned)kk * MTF_REP + ((unsigned)tid & (MTF_REP - 1))], nzero);
         } else {
             atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
             atomicAdd(&hist[mt_flag_word(C)], 1ull);
@@ -222,8 +226,8 @@ __device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* 
     unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C + (size_t)(blockIdx.x & (MT_GR - 1)) * MT_W;
     for (int i = tid; i < MT_W; i += TPB) {
         unsigned tot = 0;
-#pragma unroll
-        for (int r = 0; r < MT_REP; ++r) tot += sh_hist[(unsigned)i * MT_REP + ((unsigned)(r + tid) & (MT_REP - 1))];
+#pragma unroll 8
+        for (int r = 0; r < MTF_REP; ++r) tot += sh_hist[(unsigned)i * MTF_REP + ((unsigned)(r + tid) & (MTF_REP - 1))];
         if (tot) {
             if (wstart + i < MT_NB / 2) {
                 atomicAdd(&rep[i], (unsigned long long)tot);
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
     static_assert(TPB == 256, "wg_sum1 folds four waves");
     __shared__ double l_s[TPB / 64];
     __shared__ double sh_tot;
-    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MT_REP) : 1];
+    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MTF_REP) : 1];
     __shared__ unsigned sh_cnt[4];            // MODE 1 histogram: NaN / clamped-low, clamped-high counts of the channel
     __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
     const cnnq_params_cfg& cfg = fa.cfg;
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         // ordered before the first count by the barriers of the exchange
         if (want_hist) {
             if constexpr (MODE == 0) xhist_zero(sh_hist, nbins);
-            else for (int i = threadIdx.x; i < MT_W * MT_REP; i += TPB) sh_hist[i] = 0u;
+            else for (int i = threadIdx.x; i < MT_W * MTF_REP; i += TPB) sh_hist[i] = 0u;
         }
         if (threadIdx.x < 4) sh_cnt[threadIdx.x] = 0u;
     }
@@ -655,7 +659,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
     static_assert(MODE == 0 || A == 1, "the mid-tread form has no straddling instance");
     __shared__ double l_a[TPB * A];
     __shared__ double sh_sum[MAXCH];
-    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MT_REP) : 1];
+    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MTF_REP) : 1];
     __shared__ unsigned sh_clo[(MODE == 1 && OUT == 1) ? MAXCH : 1], sh_chi[(MODE == 1 && OUT == 1) ? MAXCH : 1];
     const cnnq_params_cfg& cfg = aa.cfg;
     const bool ba = MODE == 0 && cfg.bit_alloc && cfg.num_bits <= 4;
@@ -665,7 +669,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
         if (want_hist) {
             if constexpr (MODE == 0) xhist_zero(sh_hist, nbins);
             else {
-                for (int i = threadIdx.x; i < MT_W * MT_REP; i += TPB) sh_hist[i] = 0u;
+                for (int i = threadIdx.x; i < MT_W * MTF_REP; i += TPB) sh_hist[i] = 0u;
                 for (int i = threadIdx.x; i < MAXCH; i += TPB) { sh_clo[i] = 0u; sh_chi[i] = 0u; }
             }
         }
