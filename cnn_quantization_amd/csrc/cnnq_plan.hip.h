@@ -178,13 +178,18 @@ int plan_whole(int64_t N, int64_t C, int64_t HW, bool aligned16, WPlan* p) {
     if (u > 1024) return CNNQ_ENOTSUP;
     static const int forceT = env_int("CNNQ_RES_T", 0);
     static const int Ts[3] = {256, 512, 1024};
+    // at least ~512 contiguous bytes per sample and workgroup when the layer has the channels for it - and ~1 KB when that
+    // still leaves two workgroups per CU (round 5, the 64-sample shard: [64,1024,14,14] 25.6 -> 22.0 us with two channels per
+    // workgroup, 512 workgroups; layers that would drop to 256 or fewer workgroups lose with it)
+    static const int min_knob = env_int("CNNQ_RES_UNITS", 0);   // development knob: float4 per sample and workgroup
+    for (int pass = 0; pass < 2; ++pass)
     for (int ti = 0; ti < 3; ++ti) {
+        const int min_f4 = min_knob ? min_knob : (pass == 0 ? 64 : 32);
+        if (min_knob && pass == 1) break;
         const int T = Ts[ti];
         if (forceT && T != forceT) continue;
         if (p->A == 4 && T == 512) continue;   // not instantiated
         if (u > T) continue;
-        // at least ~512 contiguous bytes per sample and workgroup when the layer has the channels for it
-        static const int min_f4 = env_int("CNNQ_RES_UNITS", 32);   // development knob: float4 per sample and workgroup
         int64_t units = (min_f4 + u - 1) / u;
         if (units > T / u) units = T / u;
         if (units * m > C) units = (C + m - 1) / m;
@@ -196,6 +201,7 @@ int plan_whole(int64_t N, int64_t C, int64_t HW, bool aligned16, WPlan* p) {
         const int64_t need = (N + RL - 1) / RL;
         const int K = need <= 8 ? 8 : need <= 16 ? 16 : 32;
         if (need > 32 || (T == 1024 && K > 16) || (T == 512 && K < 16)) continue;
+        if (!min_knob && pass == 0 && (C + units * m - 1) / (units * m) < 512) continue;   // the wider block only with >= 512 workgroups
         p->T = T;
         p->K = K;
         p->g.N = (int)N; p->g.C = (int)C; p->g.HW = (int)HW; p->g.P = (int)(C * HW);
@@ -292,6 +298,10 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, int lds_rows, bool all
             if (C * ((total + TPB * K - 1) / (TPB * K)) >= target) break;
     }
     while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
+    // a channel in more than ~8 members pays for the meeting more than for the fewer workgroups of a higher tile (round 5, the
+    // 64-sample shard: [64,64,56,56] K = 8 / 16 / 32 -> 25 / 13 / 7 members: 23.9 / 21.7 / 19.4 us)
+    if (!forceK)
+        while (K < 32 && (total + TPB * K - 1) / (TPB * K) > 8) K <<= 1;
     // round 4: eight more steps per tile in LDS (160 KB per workgroup; flat_lds_rows() below: a development knob).  Measured +1.5 %
     // on the packed single launch with the counter meeting, nothing with the slot meeting, -1 % on the b512 step
     int KL = (K == 32 && lds_rows == 2) ? 8 : 0;
