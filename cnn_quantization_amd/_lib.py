@@ -44,6 +44,8 @@ SIGNATURES = {
     'cnnq_pc_combine_dev': (_I, [_P, _I, _L, _P, _I, _P, _P, _P]),
     'cnnq_pc_stats_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_stats': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
+    'cnnq_pc_stats_single': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, ctypes.c_size_t, _P, _P, ctypes.c_uint32, _P]),
+    'cnnq_pc_stats_auto': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, ctypes.c_size_t, _P, _P, _P]),
     'cnnq_pc_params': (_I, [_P, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P]),
     'cnnq_pc_qdq': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _P]),
     'cnnq_pc_quantize_pack4': (_I, [_P, _P, _L, _L, _L, _P, _P]),

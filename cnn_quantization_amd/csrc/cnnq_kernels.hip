@@ -170,6 +170,37 @@ int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, 
     return launch_status();
 }
 
+// The same table from ONE launch that reads x once (cnnq_stats1.hip.h: the tile stays in registers across pass A and pass B,
+// the partial sums meet through the slot region of the group workspace): 4 instead of 8 bytes per element, one launch instead
+// of three.  Flat-tile plans only; CNNQ_ENOTSUP - nothing enqueued - otherwise (and for a gws that is NULL or too small): the
+// caller takes cnnq_pc_stats.  flags: 0 (tests: 1 = skip the waits and recompute).
+int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,
+                         size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream) {
+    if (!x || !stats || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
+    if (!gws) return CNNQ_ENOTSUP;
+    GPlan gp;
+    if (plan_group(N, C, HW, al16(x), &gp, true, 0) != 0 || !gp.flat || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    // two meetings with nothing to write behind them: beyond ~128 members per channel they cost more than the second read
+    // ([512,64,112,112], 196 members: 529 us against the chain's 495; tests force it with flag 8)
+    if (gp.Gs > 128 && !(flags & 8u)) return CNNQ_ENOTSUP;
+    St1Args sa;
+    sa.stats = stats;
+    sa.mom = mom;
+    sa.count = (double)N * (double)HW;
+    sa.need_relu = need_relu ? 1 : 0;
+    sa.need_dev = (need_b || need_kurt) ? 1 : 0;
+    sa.need_kurt = need_kurt ? 1 : 0;
+    return launch_stats_flat(x, gp, sa, gws, flags & 1u, N * C * HW * 4 > NT_BYTES, (hipStream_t)stream);
+}
+
+// cnnq_pc_stats_single when it applies, else cnnq_pc_stats: one call, the same ws
+int cnnq_pc_stats_auto(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
+                       size_t gws_bytes, double* mom, float* stats, void* stream) {
+    const int rc = cnnq_pc_stats_single(x, N, C, HW, need_b, need_kurt, need_relu, gws, gws_bytes, mom, stats, 0u, stream);
+    if (rc != CNNQ_ENOTSUP) return rc;
+    return cnnq_pc_stats(x, N, C, HW, need_b, need_kurt, need_relu, ws, mom, stats, stream);
+}
+
 int cnnq_pc_combine_dev(const double* part2, int G, int64_t C, const double* mom, int want_kurt, double* dev_out,
                         float* stats, void* stream) {
     if (!part2 || G <= 0 || C <= 0 || C >= ((int64_t)1 << 31) || (!dev_out && !stats) || (stats && !mom))

@@ -6,6 +6,7 @@
 #include "cnnq_resident.hip.h"
 #include "cnnq_group.hip.h"
 #include "cnnq_aciq.hip.h"
+#include "cnnq_stats1.hip.h"
 
 namespace {
 
@@ -541,6 +542,31 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
         if (p.K == 32) LAUNCH_FG(1, 32, 0); else if (p.K == 16) LAUNCH_FG(1, 16, 0); else if (p.K == 8) LAUNCH_FG(1, 8, 0); else LAUNCH_FG(1, 4, 0);
     }
 #undef LAUNCH_FG
+    return launch_status();
+}
+
+// the single-read statistics kernel (cnnq_stats1.hip.h) on a flat plan and the workspace of launch_group
+int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* ws, unsigned flags, bool ntl, hipStream_t st) {
+    if (!p.flat || p.KL) return CNNQ_ENOTSUP;
+    if ((size_t)p.ngroups * p.gstride * ST_LINE * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
+    GWs w;
+    w.status = reinterpret_cast<unsigned*>(ws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
+    w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_SLOTS);
+    w.gstride = p.gstride;
+    const dim3 grid((unsigned)((int64_t)p.fg.C * p.fg.Gs)), block(TPB);
+    FGeo fg = p.fg;
+    fg.cb = 1;          // member fastest: with nothing to write the launch is bound by how long a group's members wait for each other
+#define LAUNCH_SF(KR, KL)                                                                                              \
+    do {                                                                                                               \
+        if (sa.need_relu && ntl) hipLaunchKernelGGL((k_stats_flat<KR, KL, true, true>), grid, block, 0, st, x, fg, w, sa, flags);   \
+        else if (sa.need_relu) hipLaunchKernelGGL((k_stats_flat<KR, KL, true, false>), grid, block, 0, st, x, fg, w, sa, flags);    \
+        else if (ntl) hipLaunchKernelGGL((k_stats_flat<KR, KL, false, true>), grid, block, 0, st, x, fg, w, sa, flags);             \
+        else hipLaunchKernelGGL((k_stats_flat<KR, KL, false, false>), grid, block, 0, st, x, fg, w, sa, flags);                     \
+    } while (0)
+    if (p.K == 32) LAUNCH_SF(24, 8); else if (p.K == 16) LAUNCH_SF(16, 0); else LAUNCH_SF(8, 0);
+#undef LAUNCH_SF
     return launch_status();
 }
 

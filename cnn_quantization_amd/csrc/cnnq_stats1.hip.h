@@ -1,0 +1,425 @@
+// cnnq_stats1.hip.h - the seven per-channel statistics of `-sm collect` (config 4; statistic_manager_perchannel.py:45-79) in
+// ONE launch and ONE read of x: 4 instead of 8 bytes per element, one launch instead of three (k_moments -> k_absdev<RAW> ->
+// k_combine_all).  Part of the single translation unit cnnq_kernels.hip.
+//
+// Round 2 built this once on the counter meeting (four dependent round trips per exchange, two exchanges per launch) and it
+// lost to the two streaming passes on every layer.  With the slot meeting an exchange is one store and one polling round
+// trip, and the partial sums travel the way cnnq_aciq.hip.h moves them: complemented 8-byte words that ARE the arrival,
+// added in member order.  The workgroup keeps its tile of x in registers across both phases:
+//
+//   phase 1   per lane min / max / sum / sum of squares (and the sums of relu(x)) -> the member's five words into its line of
+//             the slot region -> every member polls the group's lines and folds them in member order -> mean, std, std_pos;
+//   phase 2   sum |x - mean| and sum ((x - mean) / std)^4 out of the same registers -> two more words per member -> the same
+//             meeting -> b, kurtosis; member 0 writes the channel's row of the table (and the merged moment record).
+//
+// Flat tiles (the geometry of k_mmq_flat: a group is one channel) only - the layers that hold the bytes (ResNet-50 b512: 25 of
+// 53 tensors, 90 % of the elements); shapes without a flat plan keep the three-launch chain.  The arithmetic per element and
+// the final formulas are the chain's (Mom::add4, k_absdev's fp32 (x - mean) * (1 / std), mean_of / std_of, k_combine_all);
+// only the order of the fp64 additions differs, as it does between any two tilings: results agree with the chain to fp64
+// rounding, and are bit-identical run after run and between the meeting and the recompute path (the cold path recomputes
+// EVERY member's words with that member's own lane mapping and folds them in the same order).
+#pragma once
+#include "cnnq_aciq.hip.h"
+#include "cnnq_common.hip.h"
+#include "cnnq_group.hip.h"
+#include "cnnq_stats.hip.h"
+
+namespace {
+
+constexpr int ST_W1 = 5;     // phase-1 words of a member: {min, max} pair, sum, sum of squares, relu sum, relu sum of squares
+constexpr int ST_W2 = 2;     // phase-2 words: sum |x - mean|, sum z^4
+constexpr int ST_LINE = 8;   // words per member line (64 bytes: one store instruction of lanes 0..4 covers a phase's words)
+
+struct St1Args {
+    float* stats;            // [CNNQ_NSTAT][C] out: every row
+    double* mom;             // [CNNQ_NMOM][C] out, may be null
+    double count;            // N * H*W
+    int need_relu, need_dev, need_kurt;      // relu sums; phase 2 at all; the fourth moment
+};
+
+// the member's words of one phase (every thread holds them): lane i stores word i (predicated stores of a compile-time
+// indexed array: a select chain over the array made the compiler index it in scratch)
+__device__ __forceinline__ void st_publish(unsigned long long* line, const unsigned long long (&w)[ST_W1], int first, int nw) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ST_W1; ++i)
+        if (tid == i && i < nw) __hip_atomic_store(line + first + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Fold of the words of every member's line.  Lane (w, j) = (tid / 32, tid % 32), w < nw, takes word w of members j, j + 32,
+// ... in member order (st_fold_poll: windows of four slots polled with a bounded wait; the cold path: st_fold_add member by
+// member - the same per-lane sequence of additions); st_fold_finish folds the 32 lanes of a word by a fixed xor tree.  Word 0
+// of phase 1 is the {min, max} pair.  Results in sh_out[w] (the pair as its two floats in sh_mm).
+struct StFold {
+    double acc;
+    float amn, amx;
+    __device__ __forceinline__ void init() { acc = 0.; amn = INFINITY; amx = -INFINITY; }
+    __device__ __forceinline__ void add(unsigned long long v, bool is_pair) {
+        if (is_pair) {
+            float a, b;
+            unpack_pair(v, a, b);
+            amn = pmin(amn, a);
+            amx = pmax(amx, b);
+        } else {
+            acc += __longlong_as_double((long long)v);
+        }
+    }
+};
+// the cold path: member m's words (every thread holds them) into the fold of the lanes that own member m
+__device__ __forceinline__ void st_fold_add(StFold& f, int m, const unsigned long long (&words)[ST_W1], int nw, bool pair0) {
+    const int tid = threadIdx.x;
+    const int w = tid >> 5, j = tid & 31;
+    if ((m & 31) == j) {
+#pragma unroll
+        for (int i = 0; i < ST_W1; ++i)
+            if (w == i && i < nw) f.add(words[i], pair0 && i == 0);
+    }
+}
+__device__ __forceinline__ void st_fold_finish(StFold& f, int nw, bool pair0, double* sh_out, float* sh_mm) {
+    const int tid = threadIdx.x;
+    const int w = tid >> 5, j = tid & 31;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        f.acc += shfl_xor_d(f.acc, m);
+        f.amn = pmin(f.amn, shfl_xor_f(f.amn, m));
+        f.amx = pmax(f.amx, shfl_xor_f(f.amx, m));
+    }
+    if (w < nw && j == 0) {
+        sh_out[w] = f.acc;
+        if (pair0 && w == 0) { sh_mm[0] = f.amn; sh_mm[1] = f.amx; }
+    }
+}
+// the meeting: returns false (wave-uniformly) when a wait expired, after OR-ing 1 into *sh_code
+__device__ __forceinline__ bool st_fold_poll(StFold& f, const unsigned long long* lines, int Gs, int first, int nw, bool pair0,
+                                             long long tmo, int* sh_code) {
+    const int tid = threadIdx.x;
+    const int w = tid >> 5, j = tid & 31;
+    const bool active = w < nw;
+    long long t0 = 0;
+    int spins = 0;
+    for (int m0 = 0; m0 < Gs; m0 += 128) {        // windows of 4 members per lane
+        unsigned pend = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pend |= (active && m0 + j + 32 * i < Gs) ? (1u << i) : 0u;
+        const unsigned mine = pend;
+        unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+        const unsigned long long* p = lines + (size_t)(m0 + j) * ST_LINE + first + w;
+        for (;; ++spins) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((pend >> i) & 1u) {
+                    v[i] = __hip_atomic_load(p + (size_t)32 * i * ST_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v[i]) pend &= ~(1u << i);
+                }
+            if (__ballot(pend != 0u) == 0ull) break;
+            int expired = 0;
+            if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                expired = (now - t0 > tmo || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(expired)) {
+                if ((tid & 63) == 0) atomicOr(sh_code, 1);
+                return false;
+            }
+            if (spins < 2) __builtin_amdgcn_s_sleep(8);
+            else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((mine >> i) & 1u) f.add(~v[i], pair0 && w == 0);      // member order, whatever the arrival order was
+    }
+    return true;
+}
+
+// a member's words: the pair (NaNs canonical) as it is, the sums as plain doubles (st_publish complements them on the way out)
+struct StWords {
+    unsigned long long w[ST_W1];
+};
+
+// KR steps of the tile in registers, the first KL in LDS (LDS-DMA: no staging registers) - the 128 KB tile is 24 + 8: with
+// all 32 steps in registers next to the accumulators of two phases the allocator spilled six of them
+template <int KR, int KL, bool RELU, bool NTL>
+__global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_stats_flat(const float* __restrict__ x, const FGeo g, const GWs ws,
+                                                                                       const St1Args sa, const unsigned flags) {
+    static_assert(TPB == 256, "four waves");
+    constexpr int K = KR + KL;
+    __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
+    __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
+    __shared__ double l_d[4][TPB / 64];
+    __shared__ double sh_out[8], sh_out2[2];      // the folded words of phase 1 (kept for the final row) and of phase 2
+    __shared__ float sh_mm[2];
+    __shared__ int sh_code;
+    const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    int c, member;
+    if (g.cb <= 1) {
+        c = (int)blockIdx.x / g.Gs;
+        member = (int)blockIdx.x - c * g.Gs;
+    } else {
+        const int per = g.cb * g.Gs, blk = (int)blockIdx.x / per, r = (int)blockIdx.x - blk * per;
+        const int c0 = blk * g.cb, cbl = min(g.cb, g.C - c0);
+        member = r / cbl;
+        c = c0 + (r - member * cbl);
+    }
+    if (tid == 0) sh_code = ((flags & MMQ_FLAG_TEST_HOOK) ? 2 : 0) | ((st0 & 1u) ? 4 : 0);
+
+    // ---- the tile: K 16-byte loads per lane, back to back (k_mmq_flat's walk)
+    const unsigned f0 = (unsigned)member * (256u * K);
+    const unsigned n_first = f0 / g.cpc;
+    const unsigned u = f0 + (unsigned)tid;
+    const unsigned n = u / g.cpc;
+    FWalk w;
+    w.ro = (n - n_first) * g.rs;
+    w.co = (u - n * g.cpc) * 16u;
+    const unsigned long long lim64 = (unsigned long long)((unsigned)g.N - n_first) * g.rs;
+    const unsigned lim = lim64 > 0xffffffffull ? 0xffffffffu : (unsigned)lim64;
+    const char* xb = reinterpret_cast<const char*>(x) + ((size_t)n_first * (size_t)g.P + (size_t)c * (size_t)g.HW) * 4;
+    float v[KR][4];
+    if constexpr (KL > 0) {
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
+                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
+            w.step(g);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+        const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+        ldv_sel<4, NTL>(reinterpret_cast<const float*>(xb + off), v[j]);
+        w.step(g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nvalid = u < g.total ? (int)((g.total - u + 255u) / 256u) : 0;
+
+    // one member's phase-1 words from its lanes' accumulators: xor trees per wave, the four waves in index order (thread 0)
+    auto reduce1 = [&](Mom& a, StWords& out) {
+        if (a.ss != a.ss) { a.mn = NAN; a.mx = NAN; }          // a NaN element (k_moments: the sum of squares tells)
+        a.template wave_reduce<RELU>();
+        __syncthreads();
+        if (lane == 0) {
+            l_mn[wv] = a.mn; l_mx[wv] = a.mx; l_d[0][wv] = a.s; l_d[1][wv] = a.ss;
+            if constexpr (RELU) { l_d[2][wv] = a.rs; l_d[3][wv] = a.rss; }
+        }
+        __syncthreads();
+        Mom r;
+        r.init();
+        for (int i = 0; i < TPB / 64; ++i) {
+            Mom o;
+            o.mn = l_mn[i]; o.mx = l_mx[i]; o.s = l_d[0][i]; o.ss = l_d[1][i];
+            o.rs = RELU ? l_d[2][i] : 0.; o.rss = RELU ? l_d[3][i] : 0.;
+            r.template merge<true>(o);
+        }
+        const bool nn = (r.mn != r.mn) || (r.mx != r.mx);
+        out.w[0] = pack_pair(nn ? NAN : r.mn, nn ? NAN : r.mx);
+        out.w[1] = (unsigned long long)__double_as_longlong(r.s);
+        out.w[2] = (unsigned long long)__double_as_longlong(r.ss);
+        out.w[3] = (unsigned long long)__double_as_longlong(r.rs);
+        out.w[4] = (unsigned long long)__double_as_longlong(r.rss);
+    };
+    auto reduce2 = [&](double a, double k4, StWords& out) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a += shfl_xor_d(a, m); k4 += shfl_xor_d(k4, m); }
+        __syncthreads();
+        if (lane == 0) { l_d[0][wv] = a; l_d[1][wv] = k4; }
+        __syncthreads();
+        out.w[0] = (unsigned long long)__double_as_longlong(((l_d[0][0] + l_d[0][1]) + l_d[0][2]) + l_d[0][3]);
+        out.w[1] = (unsigned long long)__double_as_longlong(((l_d[1][0] + l_d[1][1]) + l_d[1][2]) + l_d[1][3]);
+        out.w[2] = out.w[3] = out.w[4] = 0ull;
+    };
+    // slot encoding of a member's words: the complement; a sum's NaN made canonical first (the pair's NaNs already are)
+    auto encode = [&](StWords& sw, int nw, bool pair0) {
+#pragma unroll
+        for (int i = 0; i < ST_W1; ++i)
+            if (i < nw) sw.w[i] = (pair0 && i == 0) ? ~sw.w[i] : slot_of_sum(__longlong_as_double((long long)sw.w[i]));
+    };
+    // a member's tile from x again, for the cold path: step s of member m for this lane
+    auto cold_load = [&](int m, int s, float (&t)[4], bool& in) {
+        const unsigned mf0 = (unsigned)m * (256u * K), mu = mf0 + (unsigned)tid;
+        const int mvalid = mu < g.total ? (int)((g.total - mu + 255u) / 256u) : 0;
+        in = s < mvalid;
+        const unsigned ee = in ? mu + 256u * (unsigned)s : mf0;
+        const unsigned nn = ee / g.cpc;
+        ldv<4>(x + (size_t)nn * (size_t)g.P + (size_t)c * (size_t)g.HW + (size_t)(ee - nn * g.cpc) * 4, t);
+    };
+
+    // ---- phase 1: the register steps and the LDS steps in accumulators of their own, each in step order, merged at the end
+    //      (the order of the additions does not depend on what landed first; the cold path does the same)
+    Mom acc;
+    acc.init();
+#pragma unroll
+    for (int j = 0; j < KR; ++j)
+        if (KL + j < nvalid) acc.template add4<RELU>(v[j]);
+    if constexpr (KL > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+        Mom al;
+        al.init();
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+            const float t[4] = {q.x, q.y, q.z, q.w};
+            if (l < nvalid) al.template add4<RELU>(t);
+        }
+        al.template merge<true>(acc);
+        acc = al;
+    }
+    StWords sw;
+    reduce1(acc, sw);
+    constexpr int NW1 = RELU ? ST_W1 : 3;
+    unsigned long long* lines = ws.slots + (size_t)c * ws.gstride * ST_LINE;      // zero at rest
+    encode(sw, NW1, true);
+    st_publish(lines + (size_t)member * ST_LINE, sw.w, 0, NW1);
+    __syncthreads();                                   // sh_code is set; l_* are free again
+    const long long tmo = (sh_code & 4) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS;
+    StFold fold;
+    fold.init();
+    if (!(sh_code & 2) && st_fold_poll(fold, lines, g.Gs, 0, NW1, true, tmo, &sh_code)) st_fold_finish(fold, NW1, true, sh_out, sh_mm);
+    __syncthreads();
+    bool cold = (sh_code & 3) != 0;
+    if (cold) {
+        // every member's words from x with that member's own lane mapping, folded in the same order
+        if (tid == 0) atomicOr(ws.status, (unsigned)(sh_code & 3));
+        fold.init();
+        for (int m = 0; m < g.Gs; ++m) {
+            Mom a2, al2;
+            a2.init();
+            al2.init();
+            for (int s = 0; s < K; ++s) {
+                float t[4];
+                bool in;
+                cold_load(m, s, t, in);
+                if (in) {
+                    if (s < KL) al2.template add4<RELU>(t);
+                    else a2.template add4<RELU>(t);
+                }
+            }
+            if constexpr (KL > 0) {
+                al2.template merge<true>(a2);
+                a2 = al2;
+            }
+            StWords s2;
+            reduce1(a2, s2);
+            st_fold_add(fold, m, s2.w, NW1, true);
+        }
+        st_fold_finish(fold, NW1, true, sh_out, sh_mm);
+        __syncthreads();
+    }
+    // mean / std / std_pos: every lane derives the same values (the formulas of k_combine); the folded words stay in LDS for
+    // the final row - seven doubles held across phase 2 next to the tile were spilled
+    float mean, sd, std_pos = 0.f;
+    {
+        const MomSum r{(double)sh_mm[0], (double)sh_mm[1], sh_out[1], sh_out[2], sa.count, RELU ? sh_out[3] : 0., RELU ? sh_out[4] : 0.};
+        mean = mean_of(r);
+        sd = std_of(r);
+        if constexpr (RELU) {
+            double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
+            if (rv < 0.) rv = 0.;
+            std_pos = (float)sqrt(rv);
+        }
+    }
+    float vb = 0.f, kurt = 0.f;
+    if (sa.need_dev) {
+        // ---- phase 2 (k_absdev's arithmetic: fp32 difference, reciprocal of the std, fp64 sums)
+        const float isd = sa.need_kurt ? 1.f / sd : 0.f;
+        auto dev4 = [&](const float (&t)[4], double& a, double& k4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = t[e] - mean;
+                a += (double)fabsf(d);
+                const float z = d * isd;
+                const float z2 = z * z;
+                k4 += (double)(z2 * z2);
+            }
+        };
+        bool published = false;
+        if (!cold) {
+            // out of the registers.  (On the cold path the tile is NOT used again - this member's words come out of the loop
+            // below like everybody's - so its registers are free there: the recompute code next to a live tile spilled it.)
+            double da = 0., dk = 0.;
+#pragma unroll
+            for (int j = 0; j < KR; ++j)
+                if (KL + j < nvalid) dev4(v[j], da, dk);
+            if constexpr (KL > 0) {
+                double la = 0., lk = 0.;
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w};
+                    if (l < nvalid) dev4(t, la, lk);
+                }
+                da = la + da;
+                dk = lk + dk;
+            }
+            reduce2(da, dk, sw);
+            encode(sw, ST_W2, false);
+            st_publish(lines + (size_t)member * ST_LINE, sw.w, ST_W1, ST_W2);
+            published = true;
+            fold.init();
+            if (st_fold_poll(fold, lines, g.Gs, ST_W1, ST_W2, false, tmo, &sh_code)) st_fold_finish(fold, ST_W2, false, sh_out2, sh_mm);
+            __syncthreads();
+            cold = (sh_code & 3) != 0;
+            if (cold && tid == 0) atomicOr(ws.status, (unsigned)(sh_code & 3));
+        }
+        if (cold) {
+            fold.init();
+            for (int m = 0; m < g.Gs; ++m) {
+                double a2 = 0., k2 = 0., la2 = 0., lk2 = 0.;
+                for (int s = 0; s < K; ++s) {
+                    float t[4];
+                    bool in;
+                    cold_load(m, s, t, in);
+                    if (in) {
+                        if (s < KL) dev4(t, la2, lk2);
+                        else dev4(t, a2, k2);
+                    }
+                }
+                if constexpr (KL > 0) {
+                    a2 = la2 + a2;
+                    k2 = lk2 + k2;
+                }
+                StWords s2;
+                reduce2(a2, k2, s2);
+                st_fold_add(fold, m, s2.w, ST_W2, false);
+                if (m == member && !published) {       // the others wait for this member's words whatever happened to it
+                    encode(s2, ST_W2, false);
+                    st_publish(lines + (size_t)member * ST_LINE, s2.w, ST_W1, ST_W2);
+                }
+            }
+            __syncthreads();                           // a hot attempt's partial sh_out2 writes are behind us
+            st_fold_finish(fold, ST_W2, false, sh_out2, sh_mm);
+            __syncthreads();
+        }
+        vb = (float)(sh_out2[0] / sa.count);
+        kurt = sa.need_kurt ? (float)(sh_out2[1] / sa.count - 3.) : 0.f;
+    }
+    if (member == 0 && tid == 0) {
+        const size_t C = (size_t)g.C;
+        sa.stats[(size_t)CNNQ_STAT_MIN * C + c] = sh_mm[0];
+        sa.stats[(size_t)CNNQ_STAT_MAX * C + c] = sh_mm[1];
+        sa.stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean;
+        sa.stats[(size_t)CNNQ_STAT_STD * C + c] = sd;
+        sa.stats[(size_t)CNNQ_STAT_STD_POS * C + c] = std_pos;
+        sa.stats[(size_t)CNNQ_STAT_B * C + c] = vb;
+        sa.stats[(size_t)CNNQ_STAT_KURT * C + c] = kurt;
+        if (sa.mom) {
+            sa.mom[(size_t)CNNQ_MOM_MIN * C + c] = (double)sh_mm[0];
+            sa.mom[(size_t)CNNQ_MOM_MAX * C + c] = (double)sh_mm[1];
+            sa.mom[(size_t)CNNQ_MOM_SUM * C + c] = sh_out[1];
+            sa.mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = sh_out[2];
+            sa.mom[(size_t)CNNQ_MOM_COUNT * C + c] = sa.count;
+            sa.mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = RELU ? sh_out[3] : 0.;
+            sa.mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = RELU ? sh_out[4] : 0.;
+        }
+    }
+    // ---- leave the group; the last member out re-arms the group's lines
+    __syncthreads();
+    if (tid == 0) sh_code = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
+    __syncthreads();
+    if (sh_code)
+        for (int m = tid; m < g.Gs * ST_LINE; m += TPB) __hip_atomic_store(lines + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace

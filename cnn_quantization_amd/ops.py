@@ -174,15 +174,19 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
     x = _dev_f32(x, 'x')
     world = 1 if local_only else D.world_size(group)
     if world == 1:
-        # one C call, one cached workspace, three launches (cnnq_pc_stats)
+        # one C call, one cached workspace (cnnq_pc_stats_auto)
         lib = L.load()
         nbytes = lib.cnnq_pc_stats_workspace(N, C, HW, int(x.data_ptr() % 16 == 0))
         if nbytes == 0:
             L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
         stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
         mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
-        L.check(lib.cnnq_pc_stats(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)),
-                                  _ptr(_scratch(x, 'stats', nbytes)), _ptr(mom), _ptr(stats), _stream(x)), 'cnnq_pc_stats')
+        st = _raw_stream(x.device.index)
+        gws = _group_workspace(x, st) if (_ACIQ_SINGLE and _RESIDENT) else None
+        # one launch that reads x once where the shape has a flat plan (cnnq_pc_stats_single), else the three-launch chain
+        L.check(lib.cnnq_pc_stats_auto(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)),
+                                       _ptr(_scratch(x, 'stats', nbytes, st)), gws, GROUP_WS_BYTES if gws is not None else 0,
+                                       _ptr(mom), _ptr(stats), st), 'cnnq_pc_stats')
         return stats, mom
     part = pc_moments(x, N, C, HW, need_relu)
     if world > 1:
@@ -195,6 +199,26 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
             dev_local = pc_combine_dev(part2, mom, None, need_kurt, want_sums=True)
             part2 = D.all_gather_records(dev_local, group)
         pc_combine_dev(part2, mom, stats, need_kurt)
+    return stats, mom
+
+
+def pc_stats_single(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, flags=8):
+    """The statistics table and the merged moment record from ONE launch that reads x once (cnnq_pc_stats_single), or None
+    when the shape has no flat-tile plan.  flags: bit 3 (default here) also takes channels of more than 128 tiles, which
+    ops.pc_stats leaves to the chain; bit 0 forces the recompute path (tests)."""
+    lib = L.load()
+    x = _dev_f32(x, 'x')
+    st = _raw_stream(x.device.index)
+    gws = _group_workspace(x, st)
+    if gws is None:
+        return None
+    stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
+    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
+    rc = lib.cnnq_pc_stats_single(_ptr(x), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)), gws,
+                                  GROUP_WS_BYTES, _ptr(mom), _ptr(stats), int(flags), st)
+    if rc == L.ENOTSUP:
+        return None
+    L.check(rc, 'cnnq_pc_stats_single')
     return stats, mom
 
 

@@ -128,6 +128,19 @@ int cnnq_pc_combine(const double* part, int G, int64_t C, int has_relu, double* 
 int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float* stats, int want_kurt,
                    double* part2, void* stream);
 
+/* All statistics of cnnq_pc_stats from ONE launch that reads x once (round 5; csrc/cnnq_stats1.hip.h): a workgroup keeps its
+ * tile of x in registers (and LDS) across pass A and pass B, and the workgroups of a channel exchange their partial sums twice
+ * through the slot region of the exchange workspace (cnnq_group_ws_alloc) - 4 instead of 8 bytes per element, one launch
+ * instead of three; the same per-element arithmetic and final formulas as the chain, a different (fixed) order of the fp64
+ * additions.  Flat-tile geometries (H*W % 4 == 0, H*W / 4 >= 128 and not a multiple of 256, 2 .. 512 tiles per channel);
+ * CNNQ_ENOTSUP otherwise, and for more than 128 tiles per channel (the chain is faster there; flags bit 3 lifts that, tests).
+ * flags: 0 (tests: 1 = skip the waits and recompute).  cnnq_pc_stats_auto: this when it applies,
+ * else cnnq_pc_stats (ws as there). */
+int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,
+                         size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream);
+int cnnq_pc_stats_auto(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
+                       size_t gws_bytes, double* mom, float* stats, void* stream);
+
 /* Merge pass-B records; divides by the COUNT row of `mom` and writes stats rows B (and KURT).
  * `dev_out` (merged [CNNQ_NDEV][C] sums, for the cross-rank exchange) may be NULL, and
  * `stats` may be NULL when only the merged sums are wanted. */
