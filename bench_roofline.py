@@ -122,7 +122,9 @@ def roofline_objects(layers, batch, world, single_launch=True):
     # HBM bytes from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command and
     # committed under profiles/ (never measured inside a timed run); attached only to the configuration they
     # were measured on
-    pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+    pmc = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
     if not os.path.exists(pmc):
         pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
     if os.path.exists(pmc):
@@ -139,7 +141,9 @@ def roofline_objects(layers, batch, world, single_launch=True):
             pass
     # the same kernel's average duration under `rocprofv3 --kernel-trace --stats` of this command, committed with the box
     # it was measured on (profiles/r04_rocprof_headline.json): next to the live figure so the two can be paired
-    rp = os.path.join(ROOT, 'profiles', 'r04_rocprof_headline.json')
+    rp = os.path.join(ROOT, 'profiles', 'r05_rocprof_headline.json')
+    if not os.path.exists(rp):
+        rp = os.path.join(ROOT, 'profiles', 'r04_rocprof_headline.json')
     if os.path.exists(rp) and world == 1:
         try:
             with open(rp) as f:
