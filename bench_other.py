@@ -136,7 +136,14 @@ def other_configs(ops, device, batch):
     ok4 = (bool(torch.equal(st4[Lb.STAT_MAX], xb.amax(dim=(0, 2, 3)))) and bool(torch.equal(st4[Lb.STAT_MIN], xb.amin(dim=(0, 2, 3))))
            and float(((st4[Lb.STAT_MEAN][:8].double() - m8).abs() / m8.abs().clamp(min=1e-3)).max()) < 1e-5
            and float(((st4[Lb.STAT_STD][:8].double() - s8).abs() / s8).max()) < 1e-5)
-    out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics' % batch, bool(ok4))
+    # layers with a flat-tile plan of at most 128 tiles per channel take ONE launch that reads x once (cnnq_pc_stats_single)
+    import ctypes
+    lib, d8 = Lb.load(), (ctypes.c_int32 * 8)()
+    one_read = sum(x.numel() for x, _ in layers
+                   if lib.cnnq_pc_group_describe(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], d8) == 0 and d8[2] == 3 and d8[5] <= 128)
+    out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics; %.0f %% of the elements in one '
+                         'launch and one read of x (cnnq_pc_stats_single), the rest in the three-launch chain' % (batch, 100. * one_read / elems),
+                         bool(ok4), moved=8 - 4. * one_read / elems)
     del layers, xb, sub
     torch.cuda.empty_cache()
     # ---- config 5
