@@ -155,6 +155,13 @@ __device__ __forceinline__ double fold_member_sums(const unsigned long long* ms,
 }
 
 // ---- mid-tread arithmetic of the single-launch kernels (MODE 1) ---------------------------------------------------------
+// qdq_fast_domain for parameters that come out of the clipping / bit-allocation arithmetic: finite extrema do not make zp and
+// qmax numbers there (an Inf or NaN activation in ANOTHER channel turns the allocation's sum, and with it every channel's
+// bit width, into NaN), and qdq1_fast's single-instruction clamp is the general path's compare + select only without NaN.
+__device__ __forceinline__ bool aciq_fast_domain(float vmin, float vmax, const ChanParams& cp) {
+    return qdq_fast_domain(vmin, vmax, cp.scale) && cp.zp == cp.zp && cp.qmax == cp.qmax;
+}
+
 // x / delta without the hardware divide, for a channel inside the domain of qdq1_fast (finite extrema up to 2^70, delta in
 // [1e-8, 2^30]): the correctly rounded quotient from the channel's correctly rounded reciprocal and two fma corrections (the
 // proof in cnnq_qdq.hip.h).  There is no zero point to absorb the sign of a vanishing quotient here, so it is taken from x:
@@ -184,23 +191,24 @@ __device__ __forceinline__ float mt_qdq1(float x, float d, float rd, float lo, f
 // whatever the code: conflict-free by construction, as the code table of config 2) - 16 KB per workgroup, affordable because
 // these workgroups are long-lived (k_mt_qdq's short tiles keep MT_REP = 8: 4 KB to zero and flush per 56 KB of x)
 constexpr int MTF_REP = 32;
-// one code into the histogram: zero and "clamped to a non-integer bound" in registers, an integer code inside the window one
-// LDS atomic, everything else (rare) straight to the global bins (the logic of k_mt_qdq)
+// one code into the histogram.  Common case, branch-free: an integer code inside the window is one LDS atomic (zero included:
+// with a replica per lane of the LDS service group the mode of the distribution no longer serialises on one address, so the
+// register count k_mt_qdq keeps for it - and its compares - are not needed here); a code clamped to a NON-integer bound is
+// counted in a register (it equals the bound only by clamping).  Everything else - an integer outside the window, inf, NaN -
+// takes a branch that is rarely entered and counts into the global bins.  10 vector operations per element instead of ~25:
+// the histogram cost the long-lived workgroups 9-16 % of the launch before.
 __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni, bool hi_ni, int wstart, unsigned* sh_hist,
-                                         unsigned* sh_nan, unsigned long long* hist, int C, unsigned& nzero, unsigned& nlo,
-                                         unsigned& nhi) {
-    const bool z = (t == 0.f);
-    const bool at_hi = hi_ni && t == hi;
-    const bool at_lo = lo_ni && t == lo;
-    nzero += z ? 1u : 0u;
-    nhi += at_hi ? 1u : 0u;
-    nlo += at_lo ? 1u : 0u;
+                                         unsigned* sh_nan, unsigned long long* hist, int C, unsigned& nlo, unsigned& nhi) {
     const int k = (int)t;                       // saturating; NaN -> 0
     const unsigned kk = (unsigned)(k - wstart);
-    const bool fast = ((float)k == t) && kk < (unsigned)MT_W;
-    if (fast && !z) {
+    const bool inwin = ((float)k == t) && kk < (unsigned)MT_W;
+    const bool at_hi = hi_ni && t == hi;
+    const bool at_lo = lo_ni && t == lo;
+    nhi += at_hi ? 1u : 0u;
+    nlo += at_lo ? 1u : 0u;
+    if (inwin) {
         atomicAdd(&sh_hist[kk * MTF_REP + ((unsigned)threadIdx.x & (MTF_REP - 1))], 1u);
-    } else if (!(z || at_hi || at_lo)) {        // rare
+    } else if (!(at_hi || at_lo)) {             // rare
         if (t == rintf(t)) {                    // integer code outside the window (or inf)
             if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
             else atomicAdd(&hist[t < 0.f ? MT_NB : MT_NB + 1], 1ull);
@@ -210,18 +218,9 @@ __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni
         }
     }
 }
-// end of the workgroup: the lanes' zero counts and the LDS window into the replica window (blockIdx picks the replica)
-__device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* hist, int C, int wstart, unsigned nzero) {
+// end of the workgroup: the LDS window into the replica window (blockIdx picks the replica)
+__device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* hist, int C, int wstart) {
     const int tid = threadIdx.x;
-    if (nzero) {
-        const int kk = -wstart;
-        if (kk >= 0 && kk < MT_W) {
-            atomicAdd(&sh_hist[(unsigned)kk * MTF_REP + ((unsigned)tid & (MTF_REP - 1))], nzero);
-        } else {
-            atomicAdd(&hist[MT_NB / 2], (unsigned long long)nzero);
-            atomicAdd(&hist[mt_flag_word(C)], 1ull);
-        }
-    }
     __syncthreads();
     unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C + (size_t)(blockIdx.x & (MT_GR - 1)) * MT_W;
     for (int i = tid; i < MT_W; i += TPB) {
@@ -383,7 +382,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
     if constexpr (MODE == 0) {
         const ChanParams cp = channel_params(cfg, ba, bits, vmin, vmax, vmean, vstd, vb);
         const float sc = cp.scale, zp = cp.zp, qm = cp.qmax;
-        const bool fast = qdq_fast_domain(vmin, vmax, sc) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
+        const bool fast = aciq_fast_domain(vmin, vmax, cp) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
         if (member == 0 && tid == 0) {
             fa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = sc;
             fa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = zp;
@@ -457,7 +456,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         }
         const int wstart = want_hist ? (int)fa.mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
         const bool hi_ni = hi != rintf(hi), lo_ni = lo != rintf(lo);     // a non-integer bound is a value of its own
-        unsigned nzero = 0u, nlo = 0u, nhi = 0u;
+        unsigned nlo = 0u, nhi = 0u;
         auto emit = [&](const float (&t)[4], bool isfast, float rd) {
             float o[4], cd[4];
 #pragma unroll
@@ -467,7 +466,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                 if constexpr (OUT == 1) {
                     if (want_hist) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_cnt[0], fa.hist, g.C, nzero, nlo, nhi);
+                        for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_cnt[0], fa.hist, g.C, nlo, nhi);
                     }
                 }
             }
@@ -501,7 +500,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
             if (want_hist) {
                 if (nlo) atomicAdd(&sh_cnt[0], nlo);
                 if (nhi) atomicAdd(&sh_cnt[1], nhi);
-                mt_flush(sh_hist, fa.hist, g.C, wstart, nzero);      // (its barrier orders the counters too)
+                mt_flush(sh_hist, fa.hist, g.C, wstart);      // (its barrier orders the counters too)
                 if (tid == 0) {
                     if (sh_cnt[0]) atomicAdd(&fa.hist[MT_NB + 2 + c], (unsigned long long)sh_cnt[0]);
                     if (sh_cnt[1]) atomicAdd(&fa.hist[MT_NB + 2 + g.C + c], (unsigned long long)sh_cnt[1]);
@@ -800,7 +799,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
             sh_zp[ch] = cp.zp;
             sh_qm[ch] = cp.qmax;
             sh_rs[ch] = 1.0f / cp.scale;
-            if (!qdq_fast_domain(vmin, vmax, cp.scale) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
+            if (!aciq_fast_domain(vmin, vmax, cp) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;   // any writer, same value
             if (rb.member == 0) {
                 aa.qp[(size_t)CNNQ_QP_SCALE * g.C + c] = cp.scale;
                 aa.qp[(size_t)CNNQ_QP_ZP * g.C + c] = cp.zp;
@@ -892,7 +891,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
         const float rd = fastq ? sh_rs[chl[0]] : 0.f;
         const int wstart = want_hist ? (int)aa.mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
         const bool hi_ni = hi != rintf(hi), lo_ni = lo != rintf(lo);
-        unsigned nzero = 0u, nlo = 0u, nhi = 0u;
+        unsigned nlo = 0u, nhi = 0u;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (j < nrows) {
@@ -909,7 +908,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
                     if constexpr (OUT == 1) {
                         if (want_hist) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_clo[chl[0]], aa.hist, g.C, nzero, nlo, nhi);
+                            for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_clo[chl[0]], aa.hist, g.C, nlo, nhi);
                         }
                     }
                 }
@@ -919,7 +918,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
             if (want_hist) {
                 if (nlo) atomicAdd(&sh_clo[chl[0]], nlo);
                 if (nhi) atomicAdd(&sh_chi[chl[0]], nhi);
-                mt_flush(sh_hist, aa.hist, g.C, wstart, nzero);      // (its barrier orders the clamp counters too)
+                mt_flush(sh_hist, aa.hist, g.C, wstart);      // (its barrier orders the clamp counters too)
                 for (int i = tid; i < nch; i += TPB) {
                     if (sh_clo[i]) atomicAdd(&aa.hist[MT_NB + 2 + b.c0 + i], (unsigned long long)sh_clo[i]);
                     if (sh_chi[i]) atomicAdd(&aa.hist[MT_NB + 2 + g.C + b.c0 + i], (unsigned long long)sh_chi[i]);

@@ -564,8 +564,11 @@ int cnnq_group_ws_at_rest(const void* ws, uint64_t* nonzero_words_host) {
     std::vector<uint32_t> h(GRP_WS_PAIRS / 4);
     const hipError_t e = hipMemcpy(h.data(), ws, GRP_WS_PAIRS, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return (int)e;
+    // the fused per-tensor kernel's corner of the header works by epoch (k_pt_fused: the epoch word and the row records
+    // are written before they are read in every launch, nothing there needs to be zero): not part of the invariant
+    constexpr size_t ptf0 = PTF_OFF / 4, ptf1 = (PTF_OFF + 256 + (size_t)PTF_MAX_ROWS * 16) / 4;
     uint64_t n = 0;
-    for (size_t i = 1; i < h.size(); ++i) n += h[i] != 0u;
+    for (size_t i = 1; i < h.size(); ++i) n += (i < ptf0 || i >= ptf1) && h[i] != 0u;
     *nonzero_words_host = n;
     return 0;
 }
@@ -1120,7 +1123,8 @@ int cnnq_pt_setup(const float* range_offset_host, const float* stats, int64_t st
 
 // config 1 behind one call AND one launch (k_pt_fused): x viewed as [rows][n / rows]; rows_mode 0: batch mean of the
 // per-row extrema (conv activations, iq.py:515-526), 1: the tensor's extrema.  gws: the exchange workspace of
-// cnnq_group_ws_alloc (its header region; zero between launches).  ptp_out (may be NULL): the eight parameters
+// cnnq_group_ws_alloc (its header region: an epoch word and row records that every launch writes
+// before it reads - nothing there has to be zero - and the counter lines, zero between launches).  ptp_out (may be NULL): the eight parameters
 // cnnq_pt_setup would have written.  CNNQ_ENOTSUP: shapes the kernel does not take (rows not whole float4s, more than
 // 1024 rows, unaligned pointers, more 16 KB tiles than the workspace has records for) - use cnnq_pc_minmax + cnnq_pc_minmax_reduce + cnnq_pt_setup + cnnq_pt_qdq.
 int cnnq_pt_minmax_qdq_fused(const float* x, float* y, int64_t n, int rows, int rows_mode, int zero_min, int num_bits,

@@ -313,7 +313,8 @@ int cnnq_group_ws_free(void* ws);
 int cnnq_group_ws_status(const void* ws, uint32_t* status_host);
 int cnnq_group_ws_status_clear(void* ws);
 /* tests: counts the 32-bit words that are not zero in the regions every launch leaves zero (everything below the pair
- * blocks but the status word: counter lines, the slot meeting's slots); synchronises. */
+ * blocks but the status word and the epoch-versioned corner of the header that cnnq_pt_minmax_qdq_fused writes before it
+ * reads: counter lines, the slot meeting's slots); synchronises. */
 int cnnq_group_ws_at_rest(const void* ws, uint64_t* nonzero_words_host);
 int cnnq_pc_group_describe(int64_t N, int64_t C, int64_t HW, int32_t out[8]);
 int cnnq_pc_minmax_qdq_group(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,

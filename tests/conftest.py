@@ -60,3 +60,24 @@ def bits_equal(a, b):
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
     b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
     return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture(autouse=True)
+def _group_workspace_zero_at_rest(request):
+    """After every -m gpu test: every group workspace this process has handed to a kernel is zero at rest (header word 0, the
+    sticky status, aside) - the invariant the slot meeting and the sum exchange rest on, checked where it could first break."""
+    yield
+    if request.node.get_closest_marker('gpu') is None:
+        return
+    import sys
+    ops = sys.modules.get('cnn_quantization_amd.ops')
+    if ops is None or not getattr(ops, '_GROUP_WS', None):
+        return
+    import ctypes
+    import torch
+    from cnn_quantization_amd import _lib
+    torch.cuda.synchronize()
+    for key, ws in list(ops._GROUP_WS.items()):
+        nz = ctypes.c_uint64()
+        rc = _lib.load().cnnq_group_ws_at_rest(ws, ctypes.byref(nz))
+        assert rc == 0 and nz.value == 0, 'group workspace %r: %d non-zero words at rest after %s' % (key, nz.value, request.node.nodeid)

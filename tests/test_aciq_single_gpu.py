@@ -226,3 +226,30 @@ def test_unsupported_configurations_fall_back(ops):
     ya = ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True, prior_is_b=True)       # chain: the prior is b itself
     refa = O.act_clipping_qdq(x.cpu(), 4, 'laplace', bit_alloc_act=True, bit_alloc_prior='laplace')
     assert float(((ya.cpu() - refa).abs() > 1e-5).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize('half', [False, True])
+def test_nan_and_inf_channels_behave_like_the_chain(ops, half):
+    """A NaN activation poisons exactly its channel (statistics, parameters, every output of the channel), +-inf saturate a
+    channel's range - in the single launch as in the five-launch chain (whose semantics are pinned to the reference by
+    tests/golden/nan.npz): same NaN pattern, same bits elsewhere."""
+    shape = (40, 6, 56, 56)
+    N, C, HW = 40, 6, 56 * 56
+    x = acts(shape, 17, relu=half)
+    x[3, 1, 5, 7] = float('nan')
+    x[7, 4, 0, 0] = float('inf')
+    if not half:
+        x[9, 5, 2, 2] = float('-inf')
+    xd = x.cuda()
+    y1, p1 = ops.aciq_qdq_single(xd, N, C, HW, 4, half, True, None, True, want_parts=True)
+    ops._ACIQ_SINGLE = False
+    try:
+        y0, p0 = ops.act_qdq_per_channel(xd, 4, positive=half, clip='laplace', bit_alloc=True, want_parts=True)
+    finally:
+        ops.reload_switches()
+    assert torch.equal(torch.isnan(y1), torch.isnan(y0))
+    assert not bool(torch.isnan(y1[:, 0]).any())
+    assert torch.equal(torch.isnan(p1['qp']), torch.isnan(p0['qp'])) and torch.equal(torch.isnan(p1['stats']), torch.isnan(p0['stats']))
+    same = ((p1['qp'] == p0['qp']) | (torch.isnan(p1['qp']) & torch.isnan(p0['qp']))).all(0)
+    assert int(same.sum()) >= C - 1
+    assert torch.equal(torch.nan_to_num(y1[:, same], nan=7.), torch.nan_to_num(y0[:, same], nan=7.))

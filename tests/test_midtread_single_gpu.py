@@ -222,3 +222,22 @@ def test_vgg_first_layer_full_size(ops):
     assert torch.equal(y, y0)
     assert abs(float(ent) - ent0) <= 1e-5 * max(1., ent0)
     assert ops.group_status(xd) == 0
+
+
+def test_nan_and_inf_channels_behave_like_the_pinned_kernels(ops):
+    """NaN / inf inputs: the single launch equals the pinned kernels on its own statistics table (NaN patterns identical,
+    all other bits equal), and the histogram totals still account for every element."""
+    from cnn_quantization_amd import _lib as L
+    shape = (40, 6, 56, 56)
+    N, C, HW = 40, 6, 56 * 56
+    x = acts(shape, 19, relu=True)
+    x[3, 1, 5, 7] = float('nan')
+    x[7, 4, 0, 0] = float('inf')
+    xd = x.cuda()
+    tabs = ops._midtread_tables(xd.device)
+    y, ent, parts = ops.mid_tread_qdq_single(xd, N, C, HW, 4, False, tabs, want_entropy=True, want_parts=True)
+    y0, mt0, ent0, hist0 = chain_on_table(ops, xd, parts['stats'], 4, False, True)
+    assert torch.equal(torch.isnan(y), torch.isnan(y0))
+    assert torch.equal(torch.nan_to_num(y, nan=7., posinf=8., neginf=9.), torch.nan_to_num(y0, nan=7., posinf=8., neginf=9.))
+    h = parts['hist'].cpu()
+    assert int(h[:-1].sum()) == x.numel()
