@@ -179,7 +179,7 @@ int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int n
     if (!x || !stats || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
     if (!gws) return CNNQ_ENOTSUP;
     GPlan gp;
-    if (plan_group(N, C, HW, al16(x), &gp, true, 0) != 0 || !gp.flat || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    if (plan_group(N, C, HW, al16(x), &gp, true, 0) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
     // two meetings with nothing to write behind them: beyond ~128 members per channel they cost more than the second read
     // ([512,64,112,112], 196 members: 529 us against the chain's 495; tests force it with flag 8)
     if (gp.Gs > 128 && !(flags & 8u)) return CNNQ_ENOTSUP;
@@ -190,6 +190,14 @@ int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int n
     sa.need_relu = need_relu ? 1 : 0;
     sa.need_dev = (need_b || need_kurt) ? 1 : 0;
     sa.need_kurt = need_kurt ? 1 : 0;
+    if (!gp.flat) {
+        // short rows: row-piece tiles (k_stats_group).  A single-round grid of register tiles loads, reduces and meets in lockstep:
+        // the memory system idles through two meetings, and the two streaming passes of the chain win wherever a workgroup owns
+        // many channels (measured b512: [512,1024,14,14] 134 us against the chain's 155, [512,512,14,14] 76 / 77,
+        // [512,2048,7,7] 114 / 88, [512,512,7,7] 91 / 46) - by default only the large layers of one channel per lane
+        if (!(flags & 8u) && (gp.v.A != 1 || N * C * HW * 4 < ((int64_t)256 << 20))) return CNNQ_ENOTSUP;
+        return launch_stats_group(x, gp, sa, gws, gws_bytes, flags & 1u, (hipStream_t)stream);
+    }
     return launch_stats_flat(x, gp, sa, gws, flags & 1u, N * C * HW * 4 > NT_BYTES, (hipStream_t)stream);
 }
 

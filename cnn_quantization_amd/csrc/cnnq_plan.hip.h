@@ -570,6 +570,35 @@ int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* w
     return launch_status();
 }
 
+// the single-read statistics kernel on a row-piece plan (k_stats_group): SG_NP words per member and owned channel
+int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* ws, size_t ws_bytes, unsigned flags, hipStream_t st) {
+    if (p.flat) return CNNQ_ENOTSUP;
+    const int kk = (p.g.mode == 1) ? 1 : p.g.k;
+    const int64_t words = (((int64_t)p.Gs * SG_NP * kk + 15) / 16) * 16;
+    if (kk > MAXCH || words >= (int64_t)1 << 30) return CNNQ_ENOTSUP;
+    const size_t bytes = (size_t)p.ngroups * (size_t)words * 8;
+    if (bytes > GRP_WS_SLOT_BYTES || GRP_WS_PAIRS + bytes > ws_bytes) return CNNQ_ENOTSUP;
+    GWs w;
+    w.status = reinterpret_cast<unsigned*>(ws);
+    w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
+    w.part = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_PAIRS);
+    w.slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + GRP_WS_SLOTS);
+    w.gstride = (int)words;
+    const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
+#define LAUNCH_SG(A, KR, KL)                                                                                             \
+    do {                                                                                                                 \
+        if (sa.need_relu) hipLaunchKernelGGL((k_stats_group<A, KR, KL, true>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags);  \
+        else hipLaunchKernelGGL((k_stats_group<A, KR, KL, false>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags);              \
+    } while (0)
+    if (p.v.A == 4) {
+        if (p.K == 32) LAUNCH_SG(4, 24, 8); else if (p.K == 16) LAUNCH_SG(4, 16, 0); else if (p.K == 8) LAUNCH_SG(4, 8, 0); else LAUNCH_SG(4, 4, 0);
+    } else {
+        if (p.K == 32) LAUNCH_SG(1, 24, 8); else if (p.K == 16) LAUNCH_SG(1, 16, 0); else if (p.K == 8) LAUNCH_SG(1, 8, 0); else LAUNCH_SG(1, 4, 0);
+    }
+#undef LAUNCH_SG
+    return launch_status();
+}
+
 // rank-local extrema in one launch (k_minmax_group): the plan and workspace of launch_group
 int launch_minmax_group(const float* x, const GPlan& p, void* ws, float* out, hipStream_t st) {
     GWs w;

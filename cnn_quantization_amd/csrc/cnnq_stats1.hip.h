@@ -12,8 +12,9 @@
 //   phase 2   sum |x - mean| and sum ((x - mean) / std)^4 out of the same registers -> two more words per member -> the same
 //             meeting -> b, kurtosis; member 0 writes the channel's row of the table (and the merged moment record).
 //
-// Flat tiles (the geometry of k_mmq_flat: a group is one channel) only - the layers that hold the bytes (ResNet-50 b512: 25 of
-// 53 tensors, 90 % of the elements); shapes without a flat plan keep the three-launch chain.  The arithmetic per element and
+// Flat tiles (k_stats_flat; the geometry of k_mmq_flat: a group is one channel) for the layers that hold the bytes (ResNet-50
+// b512: 25 of 53 tensors, 90 % of the elements) and row-piece tiles (k_stats_group, below) for short channel rows, which pay
+// only on the largest of them (cnnq_pc_stats_single has the rule and the measurements); the rest keep the three-launch chain.  The arithmetic per element and
 // the final formulas are the chain's (Mom::add4, k_absdev's fp32 (x - mean) * (1 / std), mean_of / std_of, k_combine_all);
 // only the order of the fp64 additions differs, as it does between any two tilings: results agree with the chain to fp64
 // rounding, and are bit-identical run after run and between the meeting and the recompute path (the cold path recomputes
@@ -420,6 +421,415 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
     __syncthreads();
     if (sh_code)
         for (int m = tid; m < g.Gs * ST_LINE; m += TPB) __hip_atomic_store(lines + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+// ---- row-piece tiles (the geometry of k_mmq_group / k_fused_group: a member is <= 256 float4 columns x <= K samples) -------
+// The layers the flat tiles do not take: short channel rows (ResNet-50's 14x14 and 7x7 layers - a workgroup owns k whole
+// channels, its lanes one channel each or, where H*W is not a multiple of 4, one channel per ELEMENT), and rows that are
+// whole multiples of the workgroup.  A member publishes SG_NP words per owned channel: plane 0 the {min, max} pair, planes
+// 1-4 the sums of phase 1, planes 5-6 the sums of phase 2; [member][plane][k] 8-byte words in the group's block of the slot
+// region, every one of them the complement of its value (never zero: zero is "not arrived").  One poll per phase takes all
+// planes at once: lane (plane, channel, j) folds the words of members j, j + L, ... in member order.
+constexpr int SG_NP = 7;
+
+template <int A, bool RELU>
+struct SgAcc {
+    float mn[A], mx[A];
+    double s[A], ss[A], rs[RELU ? A : 1], rss[RELU ? A : 1];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            mn[a] = INFINITY; mx[a] = -INFINITY; s[a] = 0.; ss[a] = 0.;
+            if constexpr (RELU) { rs[a] = 0.; rss[a] = 0.; }
+        }
+    }
+    // one float4 of the lane's column: A == 1 - four values of one channel (Mom::add4: the 4-sums in fp32); A == 4 - one
+    // value for each of four accumulator sets (Mom::add)
+    __device__ __forceinline__ void add(const float (&v)[4]) {
+        if constexpr (A == 1) {
+            mn[0] = fminf(fminf(mn[0], fminf(v[0], v[1])), fminf(v[2], v[3]));
+            mx[0] = fmaxf(fmaxf(mx[0], fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            s[0] += (double)((v[0] + v[1]) + (v[2] + v[3]));
+            ss[0] += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            if constexpr (RELU) {
+                const float r0 = fmaxf(v[0], 0.f), r1 = fmaxf(v[1], 0.f), r2 = fmaxf(v[2], 0.f), r3 = fmaxf(v[3], 0.f);
+                rs[0] += (double)((r0 + r1) + (r2 + r3));
+                rss[0] += (double)((r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mn[e] = pmin(mn[e], v[e]);
+                mx[e] = pmax(mx[e], v[e]);
+                const double d = (double)v[e];
+                s[e] += d;
+                ss[e] = fma(d, d, ss[e]);
+                if constexpr (RELU) {
+                    const double r = (double)fmaxf(v[e], 0.f);
+                    rs[e] += r;
+                    rss[e] = fma(r, r, rss[e]);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void poison() {          // A == 1: v_min / v_max dropped a NaN; the sum of squares tells
+        if constexpr (A == 1)
+            if (ss[0] != ss[0]) { mn[0] = NAN; mx[0] = NAN; }
+    }
+};
+
+// lane accumulators -> the tile's per-channel values: sh_mn / sh_mx [nch] and sh_q[plane][nch] (sum, sum of squares, relu sums)
+template <int A, bool RELU>
+__device__ __forceinline__ void sg_reduce1(const Geo& g, const Blk& b, bool ok, SgAcc<A, RELU>& ac, double* l_a, float* sh_mn,
+                                           float* sh_mx, double* sh_q) {
+    ac.poison();
+    float* l_mn = reinterpret_cast<float*>(l_a);
+    float* l_mx = l_mn + TPB * A;
+    __syncthreads();                     // l_a and the tables may still be read from a previous call
+    wg_channel_minmax<A>(g, b, ok, ac.mn, ac.mx, l_mn, l_mx, sh_mn, sh_mx);
+    wg_channel_sums<A>(g, b, ok, ac.s, l_a, sh_q);
+    wg_channel_sums<A>(g, b, ok, ac.ss, l_a, sh_q + MAXCH);
+    if constexpr (RELU) {
+        wg_channel_sums<A>(g, b, ok, ac.rs, l_a, sh_q + 2 * MAXCH);
+        wg_channel_sums<A>(g, b, ok, ac.rss, l_a, sh_q + 3 * MAXCH);
+    }
+}
+
+// The fold of np planes starting at plane p0 of every member's block ([member][SG_NP * kk] words at src, complemented).
+// POLL: the words are slots (zero = not arrived; bounded wait, on expiry 1 is OR-ed into *sh_code and the function returns);
+// otherwise the cold path's table.  Plane 0 is the pair plane.  Results: sh_mn / sh_mx [ch] and out[(plane - first sum
+// plane) * MAXCH + ch].
+template <int W, bool POLL>
+__device__ __forceinline__ void sg_fold(const unsigned long long* src, int Gs, int kk, int nch, int p0, int np, long long tmo,
+                                        double* out, float* sh_mn, float* sh_mx, int* sh_code) {
+    const int tid = threadIdx.x;
+    const int nvc = np * kk;
+    int L = 1;
+    {
+        const int nv = nvc < TPB ? nvc : TPB;
+        while (L < 64 && 2 * L * nv <= TPB) L <<= 1;
+    }
+    const int per = TPB / L, mstride = SG_NP * kk;
+    const int sub = tid / L, j = tid - sub * L;
+    long long t0 = 0;
+    int spins = 0;
+    for (int v0 = 0; v0 < nvc; v0 += per) {
+        const int vc = v0 + sub;
+        const int pl = vc / kk, ch = vc - pl * kk;      // plane (relative to p0), channel
+        const bool active = vc < nvc && ch < nch;
+        const bool is_pair = (p0 + pl) == 0;
+        double acc = 0.;
+        float amn = INFINITY, amx = -INFINITY;
+        for (int w0 = 0; w0 * L < Gs; w0 += W) {
+            const unsigned long long* p = src + (size_t)(j + L * w0) * mstride + (size_t)(p0 * kk + vc);
+            const size_t step = (size_t)L * mstride;
+            unsigned pend = 0u;
+#pragma unroll
+            for (int i = 0; i < W; ++i) pend |= (active && j + L * (w0 + i) < Gs) ? (1u << i) : 0u;
+            const unsigned mine = pend;
+            unsigned long long v[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) v[i] = 0ull;
+            if constexpr (POLL) {
+                for (;; ++spins) {
+#pragma unroll
+                    for (int i = 0; i < W; ++i)
+                        if ((pend >> i) & 1u) {
+                            v[i] = __hip_atomic_load(p + i * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (v[i]) pend &= ~(1u << i);
+                        }
+                    if (__ballot(pend != 0u) == 0ull) break;
+                    int expired = 0;
+                    if ((spins & 31) == 31 || spins > GRP_TIMEOUT_SPINS) {
+                        const long long now = wall_clock64();
+                        if (t0 == 0) t0 = now;
+                        expired = (now - t0 > tmo || spins > GRP_TIMEOUT_SPINS) ? 1 : 0;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(expired)) {
+                        if ((tid & 63) == 0) atomicOr(sh_code, 1);
+                        return;
+                    }
+                    if (spins < 2) __builtin_amdgcn_s_sleep(8);
+                    else if (spins < 6) __builtin_amdgcn_s_sleep(32);
+                    else __builtin_amdgcn_s_sleep(64);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < W; ++i)
+                    if ((mine >> i) & 1u) v[i] = __hip_atomic_load(p + i * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i)
+                if ((mine >> i) & 1u) {                  // member order, whatever the arrival order was
+                    if (is_pair) {
+                        float a, b2;
+                        unpack_pair(~v[i], a, b2);
+                        amn = pmin(amn, a);
+                        amx = pmax(amx, b2);
+                    } else {
+                        acc += sum_of_slot(v[i]);
+                    }
+                }
+        }
+        for (int m = L >> 1; m >= 1; m >>= 1) {
+            acc += shfl_xor_d(acc, m);
+            amn = pmin(amn, shfl_xor_f(amn, m));
+            amx = pmax(amx, shfl_xor_f(amx, m));
+        }
+        if (active && j == 0) {
+            if (is_pair) { sh_mn[ch] = amn; sh_mx[ch] = amx; }
+            else out[(size_t)(pl - (p0 == 0 ? 1 : 0)) * MAXCH + ch] = acc;
+        }
+    }
+}
+
+template <int A, int KR, int KL, bool RELU>
+__global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_stats_group(const float* __restrict__ x, const Geo g, const int Gs,
+                                                                                        const GWs ws, const St1Args sa, const unsigned flags) {
+    constexpr int K = KR + KL;
+    constexpr int NP1 = RELU ? 5 : 3;
+    static_assert(MAXCH <= TPB, "one lane per channel");
+    __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
+    __shared__ double l_a[TPB * A];
+    __shared__ double sh_q[4 * MAXCH];            // phase 1: sum, sum of squares, relu sums; phase 2: sum |x - mean|, sum z^4
+    __shared__ float sh_mn[MAXCH], sh_mx[MAXCH], sh_mean[MAXCH], sh_isd[MAXCH];
+    __shared__ int sh_code;
+    const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const RBlk rb = rblk_of(g, Gs);
+    const Blk& b = rb.b;
+    const int tid = threadIdx.x;
+    const int nch = b.c1 - b.c0;
+    const bool ok = b.col0 + tid < b.col1;
+    const unsigned colc = (unsigned)(ok ? b.col0 + tid : b.col0);      // idle lanes re-read the block's first column; results discarded
+    const int nrows = b.n1 - b.n0;                                     // 1 .. K
+    const size_t base = (size_t)b.n0 * (size_t)g.P + (size_t)colc * 4;
+    const int kk = (g.mode == 1) ? 1 : g.k;
+    const int NPK = SG_NP * kk;
+    if (tid == 0) sh_code = ((flags & MMQ_FLAG_TEST_HOOK) ? 2 : 0) | ((st0 & 1u) ? 4 : 0);
+
+    // ---- the tile: K 16-byte loads per lane back to back, the first KL of them straight into LDS
+    float v[KR][4];
+    if constexpr (KL > 0) {
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const int r = l < nrows ? l : nrows - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + base + (size_t)r * (size_t)g.P),
+                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+        const int r = KL + j < nrows ? KL + j : nrows - 1;
+        ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- phase 1, rows in order (LDS rows first: they were issued first)
+    SgAcc<A, RELU> ac;
+    ac.init();
+    if constexpr (KL > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            if (l < nrows) {
+                const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                const float t[4] = {q.x, q.y, q.z, q.w};
+                ac.add(t);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KR; ++j)
+        if (KL + j < nrows) ac.add(v[j]);
+    sg_reduce1<A, RELU>(g, b, ok, ac, l_a, sh_mn, sh_mx, sh_q);
+
+    // a member's tile from x again (the cold path), with that member's own lane mapping
+    auto cold_phase1 = [&](const RBlk& mb) {
+        const int mcol = mb.b.col0 + tid;
+        const bool mok = mcol < mb.b.col1;
+        const int mcolc = mok ? mcol : mb.b.col0;
+        const int mrows = mb.b.n1 - mb.b.n0;
+        SgAcc<A, RELU> a2;
+        a2.init();
+        for (int jj = 0; jj < K; ++jj) {
+            float t[4];
+            const int r = jj < mrows ? jj : mrows - 1;
+            ldv<4>(x + ((size_t)(mb.b.n0 + r) * (size_t)g.P + (size_t)mcolc * 4), t);
+            if (jj < mrows) a2.add(t);
+        }
+        sg_reduce1<A, RELU>(g, mb.b, mok, a2, l_a, sh_mn, sh_mx, sh_q);
+    };
+    // the tile's per-channel words of planes [p0, p0 + np) out of the LDS tables into a member's block at dst
+    auto emit = [&](unsigned long long* dst, int p0, int np) {
+        for (int vc = tid; vc < np * kk; vc += TPB) {
+            const int pl = vc / kk, ch = vc - pl * kk;
+            if (ch < nch) {
+                const int p = p0 + pl;
+                const unsigned long long wv = (p == 0) ? slot_of(sh_mn[ch], sh_mx[ch]) : slot_of_sum(sh_q[(size_t)(p - (p0 == 0 ? 1 : p0)) * MAXCH + ch]);
+                __hip_atomic_store(dst + (size_t)p * kk + ch, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    unsigned long long* lines = ws.slots + (size_t)rb.group * ws.gstride;      // zero at rest
+    unsigned long long* tab = ws.part + (size_t)rb.group * ws.gstride;         // the cold path's copy of the same block
+    emit(lines + (size_t)rb.member * NPK, 0, NP1);
+    __syncthreads();                                   // sh_code is set; the tables are free again
+    const long long tmo = (sh_code & 4) ? GRP_TIMEOUT_SHORT : GRP_TIMEOUT_TICKS;
+    if (!(sh_code & 2)) sg_fold<4, true>(lines, Gs, kk, nch, 0, NP1, tmo, sh_q, sh_mn, sh_mx, &sh_code);
+    __syncthreads();
+    bool cold = (sh_code & 3) != 0;
+    if (cold) {
+        if (tid == 0) atomicOr(ws.status, (unsigned)(sh_code & 3));
+        for (int m = 0; m < Gs; ++m) {
+            const RBlk mb = rblk_at(g, rb.group, m);
+            cold_phase1(mb);
+            emit(tab + (size_t)m * NPK, 0, NP1);       // every workgroup that lands here writes the same values
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sg_fold<4, false>(tab, Gs, kk, nch, 0, NP1, 0, sh_q, sh_mn, sh_mx, &sh_code);
+        __syncthreads();
+    }
+    // ---- mean / std / std_pos of the owned channels: identical in every member (the formulas of k_combine)
+    if (tid < nch) {
+        const int c = b.c0 + tid;
+        const MomSum r{(double)sh_mn[tid], (double)sh_mx[tid], sh_q[tid], sh_q[MAXCH + tid], sa.count, RELU ? sh_q[2 * MAXCH + tid] : 0.,
+                       RELU ? sh_q[3 * MAXCH + tid] : 0.};
+        const float mean = mean_of(r), sd = std_of(r);
+        sh_mean[tid] = mean;
+        sh_isd[tid] = sa.need_kurt ? 1.f / sd : 0.f;
+        if (rb.member == 0) {
+            float std_pos = 0.f;
+            if constexpr (RELU) {
+                double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
+                if (rv < 0.) rv = 0.;
+                std_pos = (float)sqrt(rv);
+            }
+            const size_t C = (size_t)g.C;
+            sa.stats[(size_t)CNNQ_STAT_MIN * C + c] = sh_mn[tid];
+            sa.stats[(size_t)CNNQ_STAT_MAX * C + c] = sh_mx[tid];
+            sa.stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean;
+            sa.stats[(size_t)CNNQ_STAT_STD * C + c] = sd;
+            sa.stats[(size_t)CNNQ_STAT_STD_POS * C + c] = std_pos;
+            if (!sa.need_dev) {
+                sa.stats[(size_t)CNNQ_STAT_B * C + c] = 0.f;
+                sa.stats[(size_t)CNNQ_STAT_KURT * C + c] = 0.f;
+            }
+            if (sa.mom) {
+                sa.mom[(size_t)CNNQ_MOM_MIN * C + c] = r.mn;
+                sa.mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
+                sa.mom[(size_t)CNNQ_MOM_SUM * C + c] = r.s;
+                sa.mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = r.ss;
+                sa.mom[(size_t)CNNQ_MOM_COUNT * C + c] = sa.count;
+                sa.mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = r.rs;
+                sa.mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = r.rss;
+            }
+        }
+    }
+    __syncthreads();
+    if (sa.need_dev) {
+        // ---- phase 2 (k_absdev's arithmetic: fp32 difference, reciprocal of the std, fp64 sums)
+        auto dev_add = [&](const float (&t)[4], const float (&mean)[A], const float (&isd)[A], double (&da)[A], double (&dk)[A]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = A == 1 ? 0 : e;
+                const float d = t[e] - mean[a];
+                da[a] += (double)fabsf(d);
+                const float z = d * isd[a];
+                const float z2 = z * z;
+                dk[a] += (double)(z2 * z2);
+            }
+        };
+        auto reduce2 = [&](const Blk& bb, bool bok, const double (&da)[A], const double (&dk)[A]) {
+            wg_channel_sums<A>(g, bb, bok, da, l_a, sh_q);
+            wg_channel_sums<A>(g, bb, bok, dk, l_a, sh_q + MAXCH);
+        };
+        bool published = false;
+        if (!cold) {
+            // out of the registers.  (On the cold path the tile is NOT used again: its registers are free there.)
+            int tidq = threadIdx.x;
+            asm volatile("" : "+v"(tidq));             // the lane's channel indices again, not carried across the meeting
+            const unsigned colq = (unsigned)(b.col0 + tidq < b.col1 ? b.col0 + tidq : b.col0);
+            float mean[A], isd[A];
+            double da[A], dk[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const int chl = (int)((colq * 4u + (unsigned)a) / (unsigned)g.HW) - b.c0;
+                mean[a] = sh_mean[chl];
+                isd[a] = sh_isd[chl];
+                da[a] = 0.;
+                dk[a] = 0.;
+            }
+            if constexpr (KL > 0) {
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    if (l < nrows) {
+                        const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                        const float t[4] = {q.x, q.y, q.z, q.w};
+                        dev_add(t, mean, isd, da, dk);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KR; ++j)
+                if (KL + j < nrows) dev_add(v[j], mean, isd, da, dk);
+            reduce2(b, ok, da, dk);
+            emit(lines + (size_t)rb.member * NPK, 5, 2);
+            published = true;
+            __syncthreads();
+            sg_fold<4, true>(lines, Gs, kk, nch, 5, 2, tmo, sh_q, sh_mn, sh_mx, &sh_code);
+            __syncthreads();
+            cold = (sh_code & 3) != 0;
+            if (cold && tid == 0) atomicOr(ws.status, (unsigned)(sh_code & 3));
+        }
+        if (cold) {
+            for (int m = 0; m < Gs; ++m) {
+                const RBlk mb = rblk_at(g, rb.group, m);
+                const int mcol = mb.b.col0 + tid;
+                const bool mok = mcol < mb.b.col1;
+                const int mcolc = mok ? mcol : mb.b.col0;
+                const int mrows = mb.b.n1 - mb.b.n0;
+                float mean[A], isd[A];
+                double da[A], dk[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    const int chl = (int)(((unsigned)mcolc * 4u + (unsigned)a) / (unsigned)g.HW) - mb.b.c0;
+                    mean[a] = sh_mean[chl];
+                    isd[a] = sh_isd[chl];
+                    da[a] = 0.;
+                    dk[a] = 0.;
+                }
+                for (int jj = 0; jj < K; ++jj) {
+                    float t[4];
+                    const int r = jj < mrows ? jj : mrows - 1;
+                    ldv<4>(x + ((size_t)(mb.b.n0 + r) * (size_t)g.P + (size_t)mcolc * 4), t);
+                    if (jj < mrows) dev_add(t, mean, isd, da, dk);
+                }
+                reduce2(mb.b, mok, da, dk);
+                emit(tab + (size_t)m * NPK, 5, 2);
+                if (m == rb.member && !published) emit(lines + (size_t)rb.member * NPK, 5, 2);    // the others wait for this member's words whatever happened to it
+                __syncthreads();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            sg_fold<4, false>(tab, Gs, kk, nch, 5, 2, 0, sh_q, sh_mn, sh_mx, &sh_code);
+            __syncthreads();
+        }
+        if (tid < nch && rb.member == 0) {
+            const size_t C = (size_t)g.C;
+            const int c = b.c0 + tid;
+            sa.stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sh_q[tid] / sa.count);
+            sa.stats[(size_t)CNNQ_STAT_KURT * C + c] = sa.need_kurt ? (float)(sh_q[MAXCH + tid] / sa.count - 3.) : 0.f;
+        }
+    }
+    // ---- leave the group; the last member out re-arms the group's block
+    __syncthreads();
+    if (tid == 0) sh_code = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
+    __syncthreads();
+    if (sh_code)
+        for (int m = tid; m < Gs * NPK; m += TPB) __hip_atomic_store(lines + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace

@@ -132,8 +132,10 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
  * tile of x in registers (and LDS) across pass A and pass B, and the workgroups of a channel exchange their partial sums twice
  * through the slot region of the exchange workspace (cnnq_group_ws_alloc) - 4 instead of 8 bytes per element, one launch
  * instead of three; the same per-element arithmetic and final formulas as the chain, a different (fixed) order of the fp64
- * additions.  Flat-tile geometries (H*W % 4 == 0, H*W / 4 >= 128 and not a multiple of 256, 2 .. 512 tiles per channel);
- * CNNQ_ENOTSUP otherwise, and for more than 128 tiles per channel (the chain is faster there; flags bit 3 lifts that, tests).
+ * additions.  Flat-tile geometries (H*W % 4 == 0, H*W / 4 >= 128 and not a multiple of 256, 2 .. 512 tiles per channel), and
+ * the row-piece tiles of cnnq_pc_minmax_qdq_group for shorter rows (k_stats_group).  CNNQ_ENOTSUP where the chain is faster:
+ * more than 128 tiles per channel, row-piece geometries below 256 MB or with channels straddling the 16-byte loads (flags
+ * bit 3 lifts these three rules: tests), and where there is no 16-byte tiling at all.
  * flags: 0 (tests: 1 = skip the waits and recompute).  cnnq_pc_stats_auto: this when it applies,
  * else cnnq_pc_stats (ws as there). */
 int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,

@@ -5,7 +5,9 @@ that reads x once (cnnq_pc_stats_single, csrc/cnnq_stats1.hip.h).  What must hol
   chain (the same per-element arithmetic and final formulas, another fixed order of the fp64 additions);
 * determinism: the forced recompute path == the meeting == a second run, bit for bit; workspace zero at rest;
 * NaN semantics of the chain: a NaN poisons exactly its channel;
-* shapes without a flat plan answer None and ops.pc_stats takes the chain.
+* short channel rows (14x14, 7x7 with channels straddling the 16-byte loads, rows that are whole multiples of the workgroup)
+  through the row-piece tiles (k_stats_group), every tile height; shapes no single-launch plan takes answer None and
+  ops.pc_stats takes the chain.
 Needs an MI355X: `pytest -m gpu`."""
 import ctypes
 
@@ -36,23 +38,38 @@ def acts(shape, seed):
 def ref64(x):
     from cnn_quantization_amd import _lib as L
     C = x.shape[1]
-    t = x.double().transpose(0, 1).reshape(C, -1)
+    t = x.cuda().double().transpose(0, 1).reshape(C, -1)
     mean, std = t.mean(1), t.std(1, unbiased=True)
-    out = torch.zeros(L.NSTAT, C, dtype=torch.float64)
+    out = torch.zeros(L.NSTAT, C, dtype=torch.float64, device='cuda')
     out[L.STAT_MIN], out[L.STAT_MAX], out[L.STAT_MEAN], out[L.STAT_STD] = t.min(1)[0], t.max(1)[0], mean, std
     m32, s32 = mean.float().double(), std.float().double()
     out[L.STAT_B] = (t - m32[:, None]).abs().mean(1)
     out[L.STAT_KURT] = (((t - m32[:, None]) / s32[:, None]) ** 4).mean(1) - 3
     out[L.STAT_STD_POS] = t.clamp(min=0).std(1, unbiased=True)
-    return out
+    return out.cpu()
 
 
 SHAPES = [(40, 6, 56, 56), (33, 5, 28, 28), (8, 4, 112, 112), (300, 3, 56, 56), (64, 7, 56, 56), (16, 3, 28, 28), (300, 2, 112, 112)]
+# row-piece tiles: whole channels per workgroup (14x14), channels straddling the loads (7x7: one channel per element), a row
+# that is a whole multiple of the workgroup (64x64: column blocks of one channel), ragged sample splits, and the tile heights
+# the planner picks at full size (K = 16: [512,160,14,14]; K = 32 with eight rows in LDS: [512,320,14,14], [512,1320,7,7])
+GROUP_SHAPES = [(12, 24, 14, 14), (70, 12, 14, 14), (64, 37, 14, 14), (40, 44, 7, 7), (33, 12, 7, 7), (6, 3, 64, 64), (300, 8, 7, 7), (130, 20, 14, 14)]
+BIG_GROUP_SHAPES = [(512, 160, 14, 14), (512, 320, 14, 14), (512, 1320, 7, 7)]
 
 
-@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('shape', SHAPES + GROUP_SHAPES)
 @pytest.mark.parametrize('need', [(True, True, True), (True, False, False), (False, False, False), (False, False, True)])
 def test_single_launch_statistics(ops, shape, need):
+    check_statistics(ops, shape, need)
+
+
+@pytest.mark.parametrize('shape', BIG_GROUP_SHAPES)
+@pytest.mark.parametrize('need', [(True, True, True), (True, False, False)])
+def test_single_launch_statistics_full_tile_heights(ops, shape, need):
+    check_statistics(ops, shape, need)
+
+
+def check_statistics(ops, shape, need):
     from cnn_quantization_amd import _lib as L
     need_b, need_kurt, need_relu = need
     N, C = shape[:2]
@@ -77,10 +94,10 @@ def test_single_launch_statistics(ops, shape, need):
     if need_relu:
         np.testing.assert_allclose(st[L.STAT_STD_POS].cpu().double(), ref[L.STAT_STD_POS], rtol=3e-6, atol=1e-7)
     # the merged moment record: count exact, sums to fp64 rounding
-    t = x.double().transpose(0, 1).reshape(C, -1)
+    t = xd.double().transpose(0, 1).reshape(C, -1)
     assert torch.equal(mom[L.MOM_COUNT].cpu(), torch.full((C,), float(N * HW), dtype=torch.float64))
-    np.testing.assert_allclose(mom[L.MOM_SUM].cpu(), t.sum(1), rtol=1e-7, atol=1e-3)      # fp32 4-sums accumulated in fp64 (Mom::add4)
-    np.testing.assert_allclose(mom[L.MOM_SUMSQ].cpu(), (t * t).sum(1), rtol=1e-7)
+    np.testing.assert_allclose(mom[L.MOM_SUM].cpu(), t.sum(1).cpu(), rtol=1e-7, atol=1e-3)      # fp32 4-sums accumulated in fp64 (Mom::add4)
+    np.testing.assert_allclose(mom[L.MOM_SUMSQ].cpu(), (t * t).sum(1).cpu(), rtol=1e-7)
     # ... and the chain on the same tensor
     ops._ACIQ_SINGLE = False
     try:
@@ -92,7 +109,7 @@ def test_single_launch_statistics(ops, shape, need):
     assert ops.group_status(xd) == 0
 
 
-@pytest.mark.parametrize('shape', SHAPES[:4])
+@pytest.mark.parametrize('shape', SHAPES[:4] + GROUP_SHAPES + BIG_GROUP_SHAPES[1:])
 def test_recompute_path_and_reruns_give_the_same_bits(ops, shape):
     N, C = shape[:2]
     HW = shape[2] * shape[3]
@@ -117,28 +134,29 @@ def test_recompute_path_and_reruns_give_the_same_bits(ops, shape):
     assert torch.equal(y, yc)
 
 
-def test_nan_poisons_its_channel_only(ops):
+@pytest.mark.parametrize('shape', [(40, 6, 56, 56), (40, 6, 14, 14), (40, 8, 7, 7)])
+def test_nan_poisons_its_channel_only(ops, shape):
     from cnn_quantization_amd import _lib as L
-    shape = (40, 6, 56, 56)
     x = acts(shape, 9)
-    x[3, 2, 5, 7] = float('nan')
+    x[3, 2, 5, 3] = float('nan')
     xd = x.cuda()
-    st, _ = ops.pc_stats_single(xd, 40, 6, 56 * 56, True, True, True)
+    HW = shape[2] * shape[3]
+    st, _ = ops.pc_stats_single(xd, shape[0], shape[1], HW, True, True, True)
     st = st.cpu()
     for row in (L.STAT_MIN, L.STAT_MAX, L.STAT_MEAN, L.STAT_STD, L.STAT_B, L.STAT_KURT):
         assert bool(torch.isnan(st[row, 2])), row
-    keep = torch.tensor([0, 1, 4, 5])
+    keep = torch.tensor([c for c in range(shape[1]) if c not in (2, shape[1] // 2)])     # (the constant channel's kurtosis is 0 / 0)
     assert not bool(torch.isnan(st[:, keep]).any())
     ops._ACIQ_SINGLE = False                                   # the chain's pattern (relu(NaN) = 0: its std_pos stays finite)
     try:
-        st0, _ = ops.pc_stats(xd, 40, 6, 56 * 56, need_b=True, need_kurt=True, need_relu=True)
+        st0, _ = ops.pc_stats(xd, shape[0], shape[1], HW, need_b=True, need_kurt=True, need_relu=True)
     finally:
         ops.reload_switches()
     assert torch.equal(torch.isnan(st), torch.isnan(st0.cpu()))
 
 
-def test_shapes_without_a_flat_plan(ops):
-    x = acts((12, 24, 14, 14), 1).cuda()
-    assert ops.pc_stats_single(x, 12, 24, 196, True, True, True) is None
-    st, _ = ops.pc_stats(x, 12, 24, 196, need_b=True)            # the chain
+def test_shapes_without_a_single_launch_plan(ops):
+    x = acts((12, 5, 7, 7), 1).cuda()                            # neither H*W nor C*H*W a multiple of 4: no 16-byte tiling
+    assert ops.pc_stats_single(x, 12, 5, 49, True, True, True) is None
+    st, _ = ops.pc_stats(x, 12, 5, 49, need_b=True)              # the chain
     assert torch.equal(st[1].cpu(), x.cpu().amax(dim=(0, 2, 3)))
