@@ -322,6 +322,7 @@ int cnnq_pc_dequantize_u8(const uint8_t* codes, float* y, int64_t N, int64_t C, 
 }
 
 // variable-width packed codes (bit allocation as the stored format)
+constexpr bool PACK_FLAT_DEFAULT = false;      // form 0 of the store direction stays k_pack_lean: k_pack_flat measured equal (cnnq_pack4.hip.h)
 static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, int64_t N, int64_t C, int64_t HW,
                          const float* qp, const float* bits, const uint32_t* rowoff, void* stream, int form = 0) {
     if (!packed || !qp || !bits || !rowoff || N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
@@ -341,6 +342,20 @@ static int packed_launch(bool quant, const float* x, float* y, uint8_t* packed, 
     if (k * ngroups >= (int64_t)1 << 24) return CNNQ_ERANGE;   // the in-loop index arithmetic is exact in fp32 below that
     // round 3: the lean form (one channel per wave, scalar parameters) for whole-float4 rows; form 1 forces the general
     // kernel, 2 the lean one (CNNQ_ENOTSUP when the geometry does not allow it)
+    if (quant && (form == 0 || form == 3)) {
+        // round 5: one-shot workgroups in address order of x (k_pack_flat); form 3 forces it (CNNQ_ENOTSUP for rows that are
+        // not whole float4s, an unaligned x or stream, or 2^32 groups of 32 codes and more)
+        const int64_t fgroups = (HW / 4 + 7) / 8, ftotal = N * C * fgroups;
+        constexpr int FU = 4;
+        const bool flat_ok = HW % 4 == 0 && al16(x) && ((uintptr_t)packed & 3) == 0 && ftotal < ((int64_t)1 << 32) - 32 * FU &&
+                             fgroups < ((int64_t)1 << 24) - 32 * FU && N * C < ((int64_t)1 << 31);
+        if (flat_ok && (PACK_FLAT_DEFAULT || form == 3)) {
+            hipLaunchKernelGGL((k_pack_flat<FU>), dim3((unsigned)((ftotal + 32 * FU - 1) / (32 * FU))), dim3(TPB), 0, (hipStream_t)stream, x, packed,
+                               (unsigned)(N * C), (int)C, (int)HW, (unsigned)fgroups, (unsigned)ftotal, qp, bits, rowoff);
+            return launch_status();
+        }
+        if (form == 3) return CNNQ_ENOTSUP;
+    }
     if (quant && form != 1) {
         const int64_t nsl = 2 * ngroups;
         const int64_t rpc = nsl <= 128 ? 128 / nsl : 1;
@@ -437,7 +452,7 @@ int cnnq_pc_quantize_packed(const float* x, uint8_t* packed, int64_t N, int64_t 
 // lean kernel (one channel per wave; CNNQ_ENOTSUP for rows of fewer than 8 elements, or whole-float4 rows of an x that is not 16-byte aligned).  Same bytes.
 int cnnq_pc_quantize_packed_form(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
                                  const float* bits, const uint32_t* rowoff, int form, void* stream) {
-    if (!x || form < 0 || form > 2) return CNNQ_EINVAL;
+    if (!x || form < 0 || form > 3) return CNNQ_EINVAL;
     return packed_launch(true, x, nullptr, packed, N, C, HW, qp, bits, rowoff, stream, form);
 }
 

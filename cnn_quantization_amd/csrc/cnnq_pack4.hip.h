@@ -848,4 +848,125 @@ __global__ void __launch_bounds__(TPB) k_unpack_flat(const uint8_t* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_pack_flat (round 5): the store direction as ONE-SHOT workgroups in address order of x, the mirror of k_unpack_flat.
+// k_pack_lean keeps one channel per wave and walks it chunk by chunk with one chunk of loads ahead (two 16-byte loads
+// per lane in flight); here a workgroup owns U * 32 consecutive GROUPS (a group = 8 float4 slots of one row = 32 codes =
+// bits[c] whole dwords of the row's stream, so every group starts on a dword of the output whatever the width) and issues
+// all of its U loads per lane, and the gathers of the channels' tables, before the first is consumed.  Lane (g, j) = (tid / 8,
+// tid % 8) quantizes slot j of its group to 4 b code bits and ORs them into the group's window of the wave's LDS strip
+// (8 dwords per group; ds_or_b32, at most two per lane); lane (g, j) then takes dword j of the window back (an exchange with
+// zero: the strip is clean for the next step) and stores it - groups of a row are consecutive dwords, so a wave's stores
+// are one or two runs of consecutive dwords.  Waves never talk (a wave's LDS operations execute in order).  Rows of whole
+// float4s only (H*W % 4 == 0); the other rows keep k_pack_lean.  Same bytes as k_packed<true> / k_pack_lean (tests compare).
+// Measured (ResNet-50 b512, 53 tensors one by one, three boxes): 5.25-5.50 ms against k_pack_lean's 5.13-5.32 - the same
+// rate from the opposite structure; U = 1 / 2 / 4 / 8: 6.76 / 5.74 / 5.25 / 5.63 ms.  The ablation builds (PACK_FLAT_ABL) say
+// what the 4.9 TB/s is made of: without the stores 4.75 ms, with trivial codes instead of the quantization 4.59 ms, with both
+// 3.60 ms (7.1 TB/s: the reads alone run at the chip's read-streaming rate) - ten percent each for the 0.5 B/elem of stores
+// and for the ~10 vector operations per element of the exact quotient, neither hidden behind the other at this arithmetic
+// intensity.  Kept as form 3 of cnnq_pc_quantize_packed_form; form 0 stays k_pack_lean.
+#ifndef PACK_FLAT_ABL
+#define PACK_FLAT_ABL 0      // development builds (timing, WRONG results): 1 - no stores, 2 - trivial codes instead of the quantization
+#endif
+template <int U>
+__global__ void __launch_bounds__(TPB) k_pack_flat(const float* __restrict__ x, uint8_t* __restrict__ packed, const unsigned nrows,
+                                                   const int C, const int HW, const unsigned ngroups, const unsigned total_groups,
+                                                   const float* __restrict__ qp, const float* __restrict__ bits,
+                                                   const uint32_t* __restrict__ rowoff) {
+    __shared__ unsigned sh_strip[TPB];                     // [wave][group of the wave][8 dwords]
+    const int tid = threadIdx.x;
+    const unsigned j = (unsigned)tid & 7u;
+    const unsigned nslots = (unsigned)HW / 4u;
+    sh_strip[tid] = 0u;                                    // a lane's own wave reads and writes this entry only
+    const unsigned G0 = (unsigned)blockIdx.x * (32u * U);  // the workgroup's first group (uniform: scalar divisions)
+    const unsigned row0 = G0 / ngroups, gi0 = G0 - row0 * ngroups;
+    const unsigned n0 = row0 / (unsigned)C, c0 = row0 - n0 * (unsigned)C;
+    const float rg = 1.0f / (float)ngroups, rc = 1.0f / (float)C;
+    const uint32_t plane = rowoff[C];
+    unsigned cc[U], nn[U], gi[U];
+    bool live[U], rowok[U];
+    float v[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned t = gi0 + (unsigned)u * 32u + ((unsigned)tid >> 3);     // < 2^24: the float quotient is exact +- 1
+        unsigned w = (unsigned)((float)t * rg);
+        w -= (w * ngroups > t) ? 1u : 0u;
+        w += ((w + 1u) * ngroups <= t) ? 1u : 0u;
+        gi[u] = t - w * ngroups;
+        const unsigned cl = c0 + w;                                            // < C + 32 U
+        unsigned dn = (unsigned)((float)cl * rc);
+        dn -= (dn * (unsigned)C > cl) ? 1u : 0u;
+        dn += ((dn + 1u) * (unsigned)C <= cl) ? 1u : 0u;
+        cc[u] = cl - dn * (unsigned)C;
+        nn[u] = n0 + dn;
+        const unsigned slot = gi[u] * 8u + j;
+        rowok[u] = row0 + w < nrows;                                           // the same for the 8 lanes of a group
+        live[u] = rowok[u] && slot < nslots;
+        // unconditional loads (a branch around a load serialises the loads): dead lanes read the tensor's first float4
+        const size_t off = live[u] ? (size_t)(row0 + w) * (size_t)HW + (size_t)slot * 4 : (size_t)0;
+        ldv_nt<4>(x + off, v[u]);
+    }
+    // the channels' tables (L1 / L2 resident; a wave spans one or two channels when rows are long)
+    int b[U];
+    float sc[U], zp[U], qm[U];
+    uint32_t roff[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned c = cc[u];
+        b[u] = (int)bits[c];
+        sc[u] = qp[(size_t)CNNQ_QP_SCALE * C + c];
+        zp[u] = qp[(size_t)CNNQ_QP_ZP * C + c];
+        qm[u] = qp[(size_t)CNNQ_QP_QMAX * C + c];
+        roff[u] = rowoff[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned* strip = sh_strip + (tid & ~7);               // the group's window
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // the codes without the hardware divide (qdq1_fast) when every lane of the wave has its parameters and its four
+        // values inside the domain (the test of k_pack_lean, per lane here: the sum of the squares is at most 2^120 - every
+        // |x| <= 2^60, no NaN, no inf); otherwise qdq1 for the whole wave
+        const float rs = 1.0f / sc[u];
+        float t0 = v[u][0] * v[u][0], t1 = v[u][1] * v[u][1];
+        t0 = __builtin_fmaf(v[u][2], v[u][2], t0);
+        t1 = __builtin_fmaf(v[u][3], v[u][3], t1);
+        const bool dom = sc[u] >= 0x1p-30f && sc[u] <= 0x1p30f && fabsf(zp[u]) <= 0x1p30f && qm[u] >= 0.f && qm[u] <= 255.f && t0 + t1 <= 0x1p120f;
+        const bool fast = __builtin_amdgcn_ballot_w64(live[u] && b[u] > 0 && !dom) == 0ull;
+        unsigned cds[4];
+        if (PACK_FLAT_ABL & 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cds[e] = __float_as_uint(v[u][e]) & 7u;
+        } else if (fast) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float cd;
+                (void)qdq1_fast(v[u][e], sc[u], rs, zp[u], qm[u], cd);
+                cds[e] = (unsigned)cd;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float cd;
+                (void)qdq1(v[u][e], sc[u], zp[u], qm[u], cd);
+                cds[e] = (unsigned)cd;
+            }
+        }
+        const unsigned ub = (unsigned)b[u];
+        unsigned h = cds[0] | (cds[1] << ub) | (cds[2] << (2u * ub)) | (cds[3] << (3u * ub));      // 4 b <= 32 bits
+        h = (live[u] && ub > 0u) ? h : 0u;
+        const unsigned bit = j * 4u * ub, d0 = bit >> 5, s = bit & 31u;                            // inside the 32 b bits of the group
+        const unsigned lo = h << s, hi = s ? h >> (32u - s) : 0u;
+        if (lo) __hip_atomic_fetch_or(strip + d0, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (hi) __hip_atomic_fetch_or(strip + d0 + 1u, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const unsigned mine = __hip_atomic_exchange(strip + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // dword j of the group: dword gi * b + j of the row's stream, while inside the row's bytes
+        const unsigned rowdw = ((unsigned)HW * ub + 31u) / 32u;
+        if (rowok[u] && j < ub && gi[u] * ub + j < rowdw && (!(PACK_FLAT_ABL & 1) || mine == 0xdeadbeefu))
+            *reinterpret_cast<uint32_t*>(packed + (size_t)nn[u] * plane + roff[u] + (size_t)(gi[u] * ub + j) * 4) = mine;
+    }
+}
+
 }  // namespace

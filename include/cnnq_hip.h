@@ -231,9 +231,10 @@ int cnnq_pc_quantize_packed(const float* x, uint8_t* packed, int64_t N, int64_t 
 /* The same pass with its kernel form spelled out (tests, measurements): form 0 = the library's choice, 1 = the general
  * kernel (any geometry), 2 = the lean kernel of round 3 (one channel per wave, scalar parameters; CNNQ_ENOTSUP for rows
  * of fewer than 8 elements, or whole-float4 rows (H*W % 4 == 0) of an x that is not 16-byte aligned).  Every form writes
- * the same bytes / the same floats; the load direction's lean form also needs a 4-byte aligned packed buffer.  Load direction
- * only, form 3 (round 4; the library's choice when it applies): one-shot workgroups in address order of y, per-lane channel
- * parameters (CNNQ_ENOTSUP unless y is 16-byte aligned, the stream 4-byte aligned and the tensor below 2^32 elements). */
+ * the same bytes / the same floats; the load direction's lean form also needs a 4-byte aligned packed buffer.  Form 3: one-shot
+ * workgroups in address order of the fp32 tensor, per-lane channel parameters - load direction (round 4; the library's choice
+ * when it applies): CNNQ_ENOTSUP unless y is 16-byte aligned, the stream 4-byte aligned and the tensor below 2^32 elements;
+ * store direction (round 5, k_pack_flat): CNNQ_ENOTSUP unless H*W % 4 == 0, x is 16-byte and the stream 4-byte aligned. */
 int cnnq_pc_quantize_packed_form(const float* x, uint8_t* packed, int64_t N, int64_t C, int64_t HW, const float* qp,
                                  const float* bits, const uint32_t* rowoff, int form, void* stream);
 int cnnq_pc_dequantize_packed_form(const uint8_t* packed, float* y, int64_t N, int64_t C, int64_t HW, const float* qp,

@@ -423,6 +423,12 @@ def test_packed_forms_write_the_same_bytes(ops, shape):
         d, ro_d = ops.quantize_packed(x, qp, bits, rowoff=ops.packed_layout(bits, H * W))   # the layout handed in
         assert torch.equal(ro_d, ro_a) and torch.equal(d, a)
         assert torch.equal(ro_a, ro_b) and torch.equal(a, b) and torch.equal(a, c), shape
+        if (H * W) % 4 == 0:                # round 5: one-shot workgroups in address order of x (k_pack_flat), rows of whole float4s
+            e, _ = ops.quantize_packed(x, qp, bits, form=3)
+            assert torch.equal(a, e), shape
+        else:
+            with pytest.raises(L.CnnqError):
+                ops.quantize_packed(x, qp, bits, form=3)
         ref = ops.pc_qdq(x, N, C, H * W, qp)
         for form in (0, 1, 2, 3):           # the load direction: the general, the lean and the flat (round 4) kernel, the same floats
             assert torch.equal(ops.dequantize_packed(b, shape, qp, bits, ro_b, form=form), ref), (shape, form)
