@@ -1168,11 +1168,7 @@ int cnnq_pt_minmax_qdq_fused(const float* x, float* y, int64_t n, int rows, int 
     w.rows = reinterpret_cast<unsigned*>(base + 256);
     w.recs = reinterpret_cast<uint4*>(reinterpret_cast<char*>(gws) + GRP_WS_PAIRS);   // write-before-read: garbage-tolerant
     static_assert(PTF_OFF + 256 + (size_t)PTF_MAX_ROWS * 16 <= GRP_WS_HDR, "the fused per-tensor region must fit the header");
-    static const int cus = [] {
-        int dev = 0, c = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
-        return c;
-    }();
+    const int cus = chip_cus();
     // a co-resident grid: 4 workgroups per CU of the 5 that fit (83 VGPRs, 13 KB of LDS), fewer when the tensor is small
     const int64_t ntiles = tpr * rows;
     int64_t G = (int64_t)cus * 4;

@@ -154,6 +154,22 @@ inline int res_min_wgs() {
 }
 #define RES_MIN_WGS res_min_wgs()
 
+// How many members a group may have and still be co-resident: the K = 32 tiles run three workgroups per CU, and the bounds the
+// kernels were tuned with - GRP_GS_MAX = 512 of the 768 slots of a 256-CU part, GRP_GS_BIG = 704 for the 160 KB tiles of a channel
+// that is alone on the chip - scale with the CUs of the device the process runs on (a partitioned part, a smaller one), read
+// once.  Without a device (the planner tests on a CPU box) the 256 CUs of an MI355X in SPX mode are assumed.  A group that is
+// not co-resident after all is slow (bounded waits, then the exact recompute), never wrong.
+inline int chip_cus() {
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        return c;
+    }();
+    return cus;
+}
+inline int64_t grp_gs_max() { const int64_t v = (int64_t)chip_cus() * 2; return v < GRP_GS_MAX ? v : GRP_GS_MAX; }
+inline int64_t grp_gs_big() { const int64_t v = (int64_t)chip_cus() * 3 - chip_cus() / 4; return v < GRP_GS_BIG ? v : GRP_GS_BIG; }
+
 struct WPlan {
     int A, T, K;   // parameter sets per float4, threads per workgroup, samples (16-byte loads) per lane
     WGeo g;
@@ -298,7 +314,7 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, int lds_rows, bool all
         for (K = 32; K > 8; K >>= 1)
             if (C * ((total + TPB * K - 1) / (TPB * K)) >= target) break;
     }
-    while (K < 32 && (total + TPB * K - 1) / (TPB * K) > GRP_GS_MAX) K <<= 1;
+    while (K < 32 && (total + TPB * K - 1) / (TPB * K) > grp_gs_max()) K <<= 1;
     // a channel in more than ~8 members pays for the meeting more than for the fewer workgroups of a higher tile (round 5, the
     // 64-sample shard: [64,64,56,56] K = 8 / 16 / 32 -> 25 / 13 / 7 members: 23.9 / 21.7 / 19.4 us)
     if (!forceK)
@@ -307,11 +323,11 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, int lds_rows, bool all
     // on the packed single launch with the counter meeting, nothing with the slot meeting, -1 % on the b512 step
     int KL = (K == 32 && lds_rows == 2) ? 8 : 0;
     int64_t Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
-    int64_t gs_max = GRP_GS_MAX;
-    if (Gs > GRP_GS_MAX && K == 32 && lds_rows >= 1) {          // a big channel: 160 KB tiles, the channel alone on the chip
+    int64_t gs_max = grp_gs_max();
+    if (Gs > gs_max && K == 32 && lds_rows >= 1) {          // a big channel: 160 KB tiles, the channel alone on the chip
         KL = 8;
         Gs = (total + TPB * (K + KL) - 1) / (TPB * (K + KL));
-        gs_max = GRP_GS_BIG;
+        gs_max = grp_gs_big();
     }
     if (Gs > gs_max || Gs < 2) return CNNQ_ENOTSUP;
     const int64_t rows = (TPB * (K + KL)) / cpc + 3;             // samples a tile can touch, with slack
@@ -334,7 +350,7 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, int lds_rows, bool all
     // chip reads runs of 4 channel rows together (A/B on one box, three rounds: the b512 step 9.14 -> 9.05 ms, k_mmq_flat
     // 0.640 -> 0.651 of peak; 2 and 4 alike, 8 and more no better).  CNNQ_GRP_CB=1: member fastest (development knob).
     static const int cb_knob = env_int("CNNQ_GRP_CB", 4);
-    const int64_t cb_fit = 384 / Gs;                             // a block's groups must be resident together: half of the 768 slots at K = 32
+    const int64_t cb_fit = ((int64_t)chip_cus() * 3 / 2) / Gs;   // a block's groups must be resident together: half of the slots at K = 32 (384 of 768)
     f.cb = (int)(cb_knob > 1 ? (cb_fit < cb_knob ? (cb_fit < 1 ? 1 : cb_fit) : cb_knob) : 1);
     // describe(): a Geo that tells the same story
     p->g = Geo{};
@@ -417,9 +433,9 @@ int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p) {
         for (K = 32; K > 4; K >>= 1)   // the largest tile that still yields `target` workgroups
             if ((int64_t)g.ncb * ((N + K - 1) / K) >= target) break;
     }
-    while (K < 32 && ((N + K - 1) / K) * members_per_split > GRP_GS_MAX) K <<= 1;   // groups stay co-resident
+    while (K < 32 && ((N + K - 1) / K) * members_per_split > grp_gs_max()) K <<= 1;   // groups stay co-resident
     const int64_t S = (N + K - 1) / K;
-    if (S * members_per_split > GRP_GS_MAX) return CNNQ_ENOTSUP;
+    if (S * members_per_split > grp_gs_max()) return CNNQ_ENOTSUP;
     if (S * g.ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
     g.S = (int)S;
     p->K = K;
