@@ -246,7 +246,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
     static_assert(TPB == 256, "wg_sum1 folds four waves");
     __shared__ double l_s[TPB / 64];
     __shared__ double sh_tot;
-    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MTF_REP) : 1];
+    extern __shared__ unsigned cnnq_dyn_lds[];     // MODE 0, OUT == 1: nbins x HREP words, sized by the launch (xhist_lds_bytes)
+    __shared__ unsigned sh_hist_mt[(OUT == 1 && MODE == 1) ? MT_W * MTF_REP : 1];
+    unsigned* const sh_hist = MODE == 0 ? cnnq_dyn_lds : sh_hist_mt;
     __shared__ unsigned sh_cnt[4];            // MODE 1 histogram: NaN / clamped-low, clamped-high counts of the channel
     __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
     const cnnq_params_cfg& cfg = fa.cfg;
@@ -658,7 +660,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
     static_assert(MODE == 0 || A == 1, "the mid-tread form has no straddling instance");
     __shared__ double l_a[TPB * A];
     __shared__ double sh_sum[MAXCH];
-    __shared__ unsigned sh_hist[OUT == 1 ? (MODE == 0 ? 256 * HREP : MT_W * MTF_REP) : 1];
+    extern __shared__ unsigned cnnq_dyn_lds[];     // MODE 0, OUT == 1: nbins x HREP words, sized by the launch (xhist_lds_bytes)
+    __shared__ unsigned sh_hist_mt[(OUT == 1 && MODE == 1) ? MT_W * MTF_REP : 1];
+    unsigned* const sh_hist = MODE == 0 ? cnnq_dyn_lds : sh_hist_mt;
     __shared__ unsigned sh_clo[(MODE == 1 && OUT == 1) ? MAXCH : 1], sh_chi[(MODE == 1 && OUT == 1) ? MAXCH : 1];
     const cnnq_params_cfg& cfg = aa.cfg;
     const bool ba = MODE == 0 && cfg.bit_alloc && cfg.num_bits <= 4;

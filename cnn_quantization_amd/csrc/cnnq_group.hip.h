@@ -469,7 +469,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{},
     const XRank xr = XRank{}) {
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
-    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    extern __shared__ unsigned cnnq_dyn_lds[];     // OUT == 1 with a histogram: 2^min(num_bits, 8) bins x HREP replicas, sized by the launch (xhist_lds_bytes)
+    unsigned* const sh_hist = cnnq_dyn_lds;
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }
@@ -780,7 +781,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}, const XRank xr = XRank{}) {
     static_assert(TPB == 256, "wg_minmax1 folds four waves");
     __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
-    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    extern __shared__ unsigned cnnq_dyn_lds[];     // OUT == 1 with a histogram: 2^min(num_bits, 8) bins x HREP replicas, sized by the launch (xhist_lds_bytes)
+    unsigned* const sh_hist = cnnq_dyn_lds;
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // ordered before the first count by the barriers of the exchange
     }

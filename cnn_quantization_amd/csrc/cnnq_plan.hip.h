@@ -245,12 +245,13 @@ int launch_whole(const float* x, float* y, const WPlan& p, int num_bits, int pos
     const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: the cross-rank stage of cnnq_xrank.hip.h (y, or y + codes / histogram)
     if (xrank && out == 2) return CNNQ_ENOTSUP;
     const XRank xr = xrank ? *xrp : XRank{};
+    const size_t hb = xhist_lds_bytes(out, xo.hist, 1 << (num_bits < 8 ? num_bits : 8));
 #define LAUNCH_W(A, T, K)                                                                                                     \
     do {                                                                                                                      \
-        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
+        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1, true>), grid, dim3(T), hb, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
         else if (xrank) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0, true>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo, xr); \
         else if (out == 0) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 0>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);      \
-        else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo); \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_whole<A, T, K, 1>), grid, dim3(T), hb, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_whole<A, T, K, 2>), grid, dim3(T), 0, st, x, y, p.g, num_bits, positive, qp, mm, flags, xo);               \
     } while (0)
     if (p.A == 1) {
@@ -457,6 +458,7 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     const bool xrank = xrp && xrp->world > 0;
     if (xrank && out == 2) return CNNQ_ENOTSUP;
     const XRank xr = xrank ? *xrp : XRank{};
+    const size_t hb = xhist_lds_bytes(out, xo.hist, 1 << (num_bits < 8 ? num_bits : 8));
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
@@ -481,10 +483,10 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
         if (out == 2 && !cb_forced) fg.cb = 1;
 #define LAUNCH_F(K)                                                                                                                  \
     do {                                                                                                                             \
-        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1, true>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1, true>), fgrid, block, hb, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
         else if (xrank) hipLaunchKernelGGL((k_mmq_flat<K, 0, true>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo, xr); \
         else if (out == 0) hipLaunchKernelGGL((k_mmq_flat<K, 0>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);      \
-        else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo); \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_flat<K, 1>), fgrid, block, hb, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_flat<K, 2>), fgrid, block, 0, st, x, y, fg, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)
         if (p.K == 32 && p.KL == 8) {
@@ -497,10 +499,10 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
     }
 #define LAUNCH_G(A, K)                                                                                                                     \
     do {                                                                                                                                   \
-        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
+        if (xrank && out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1, true>), grid, block, hb, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
         else if (xrank) hipLaunchKernelGGL((k_mmq_group<A, K, 0, true>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo, xr); \
         else if (out == 0) hipLaunchKernelGGL((k_mmq_group<A, K, 0>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);      \
-        else if (out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo); \
+        else if (out == 1) hipLaunchKernelGGL((k_mmq_group<A, K, 1>), grid, block, hb, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo); \
         else hipLaunchKernelGGL((k_mmq_group<A, K, 2>), grid, block, 0, st, x, y, p.g, p.Gs, num_bits, positive, w, qp, mm, flags, xo);               \
     } while (0)
     if (p.v.A == 4) {
@@ -521,6 +523,9 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
     if (mode == 1 && !p.flat && p.v.A != 1) return CNNQ_ENOTSUP;      // no straddling mid-tread instance
     if (p.KL && mode == 0 && out == 1) return CNNQ_ENOTSUP;          // 32 KB of LDS rows + the 32 KB code table: two workgroups per CU, a big channel needs three
     flags |= mmq_env_flags();
+    // mode 0 counts codes in the table of the config-2 kernels: 256 bins with bit allocation (a channel's width is its own), else 2^bits
+    const bool ba = fa.cfg.bit_alloc && fa.cfg.num_bits <= 4;
+    const size_t hb = mode == 0 ? xhist_lds_bytes(out, xo.hist, ba ? 256 : 1 << (fa.cfg.num_bits < 8 ? fa.cfg.num_bits : 8)) : 0;
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
@@ -532,7 +537,7 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
 #define LAUNCH_FF(K, KL)                                                                                                   \
     do {                                                                                                                   \
-        if (mode == 0 && out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, 0, 0>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);   \
+        if (mode == 0 && out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, 0, 0>), fgrid, block, hb, st, x, y, p.fg, w, fa, flags, xo);   \
         else if (mode == 0) hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 0>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);         \
         else if (out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, KL, 1>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);          \
         else hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 1>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);                        \
@@ -547,7 +552,7 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb));
 #define LAUNCH_FG(A, K, MODE)                                                                                                   \
     do {                                                                                                                        \
-        if (out == 1) hipLaunchKernelGGL((k_fused_group<A, K, 1, MODE>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo);   \
+        if (out == 1) hipLaunchKernelGGL((k_fused_group<A, K, 1, MODE>), grid, block, (MODE == 0 ? hb : 0), st, x, y, p.g, p.Gs, w, fa, flags, xo);   \
         else hipLaunchKernelGGL((k_fused_group<A, K, 0, MODE>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo);            \
     } while (0)
     if (mode == 1) {

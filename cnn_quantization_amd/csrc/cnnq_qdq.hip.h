@@ -242,6 +242,9 @@ constexpr int XHIST_REPLICAS = 64;
 
 // nbins = 2^num_bits (<= 256): only the bins the codes can reach are zeroed and flushed - 16 instead of 256 for int4,
 // i.e. 2 KB of LDS traffic per workgroup instead of 64
+// dynamic LDS of a launch that counts codes: the table the kernel zeroes and flushes, nothing when there is no histogram - a
+// static 256-bin table (32 KB) cost the small-tile instances their occupancy ([512,512,7,7] with -me: 45 instead of 25 us)
+inline size_t xhist_lds_bytes(int out, const void* hist, int nbins) { return (out == 1 && hist) ? (size_t)nbins * HREP * sizeof(unsigned) : 0; }
 __device__ __forceinline__ void xhist_zero(unsigned* sh_hist, int nbins) {
     for (int i = threadIdx.x; i < nbins * HREP; i += blockDim.x) sh_hist[i] = 0u;
 }

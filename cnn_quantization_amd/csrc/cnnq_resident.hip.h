@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
     __shared__ float sh_rs[MAXCH];
     __shared__ int sh_slow;
     if (threadIdx.x == 0) sh_slow = 0;      // the barriers of the reductions come before its writers
-    __shared__ unsigned sh_hist[OUT == 1 ? 256 * HREP : 1];
+    extern __shared__ unsigned cnnq_dyn_lds[];     // OUT == 1 with a histogram: 2^min(num_bits, 8) bins x HREP replicas, sized by the launch (xhist_lds_bytes)
+    unsigned* const sh_hist = cnnq_dyn_lds;
     if constexpr (OUT == 1) {
         if (xo.hist) xhist_zero(sh_hist, 1 << (num_bits < 8 ? num_bits : 8));      // the barriers of the reductions below order it before the first count
     }
