@@ -62,6 +62,8 @@ SIGNATURES = {
     'cnnq_pc_minmax_qdq_xrank': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, ctypes.c_size_t, _P, _I, _I, _I, ctypes.c_uint32, _P, _L,
                                       _P]),
     'cnnq_pc_minmax_qdq_xrank_dev': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, ctypes.c_size_t, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
+    'cnnq_pc_minmax_qdq_xrank_seq': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, _P, ctypes.c_size_t, _P, _I, _I, _I, ctypes.c_uint32, _P, _I, _P, _L,
+                                          _P, _P, _P]),
     'cnnq_hist_replicas_fold': (_I, [_P, _P, _P]),
     'cnnq_pc_minmax': (_I, [_P, _L, _L, _L, _P, _P]),
     'cnnq_pc_minmax_strided': (_I, [_P, _L, _L, _L, _L, _P, _P]),

@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const int num_bits, const int positive,
     const GWs ws, float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{},
     const XRank xr = XRank{}) {
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back, the sequence mirror
     __shared__ float l_mn[TPB * A], l_mx[TPB * A];
     extern __shared__ unsigned cnnq_dyn_lds[];     // OUT == 1 with a histogram: 2^min(num_bits, 8) bins x HREP replicas, sized by the launch (xhist_lds_bytes)
     unsigned* const sh_hist = cnnq_dyn_lds;
@@ -780,6 +781,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     const float* __restrict__ x, float* __restrict__ y, const FGeo g, const int num_bits, const int positive, const GWs ws,
     float* __restrict__ qp, float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{}, const XRank xr = XRank{}) {
     static_assert(TPB == 256, "wg_minmax1 folds four waves");
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back, the sequence mirror
     __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
     extern __shared__ unsigned cnnq_dyn_lds[];     // OUT == 1 with a histogram: 2^min(num_bits, 8) bins x HREP replicas, sized by the launch (xhist_lds_bytes)
     unsigned* const sh_hist = cnnq_dyn_lds;

@@ -756,9 +756,12 @@ int cnnq_xrank_alloc(int world, int cmax, void** window, unsigned char handle[64
     return 0;
 }
 
+// seq != 0: host numbering (seq_dev, if given, mirrors it; with `lean` no kernel is enqueued behind the launch: the caller passes
+// zero_c, the channel count of the launch two back, and workgroup 0 cleans up); seq == 0: device numbering (k_xr_finish behind it)
 static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive, float* ws, void* gws,
                         size_t gws_bytes, void* const* windows, int rank, int world, int cmax, uint32_t seq, uint32_t* seq_dev,
-                        uint32_t* status, int64_t timeout_ticks, uint8_t* codes, uint64_t* hist_rep, void* stream) {
+                        uint32_t* status, int64_t timeout_ticks, uint8_t* codes, uint64_t* hist_rep, void* stream, int zero_c = 0,
+                        bool lean = false) {
     if (!x || !y || !ws || num_bits < 1 || num_bits > 32 || C <= 0) return CNNQ_EINVAL;
     if (!windows || !status || world <= 0 || rank < 0 || rank >= world || (!seq && !seq_dev) || C > cmax || timeout_ticks <= 0) return CNNQ_EINVAL;
     if (gws && ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
@@ -771,8 +774,11 @@ static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t 
     xr.windows = windows;
     xr.rank = rank;
     xr.world = world;
+    if (zero_c < 0 || zero_c > cmax || (lean && !seq)) return CNNQ_EINVAL;
     xr.seq = seq;
-    xr.seq_dev = seq_dev;
+    xr.seq_dev = seq ? nullptr : seq_dev;
+    xr.seq_mirror = (seq && lean) ? seq_dev : nullptr;
+    xr.zero_c = zero_c;
     xr.cmax = cmax;
     xr.status = status;
     xr.timeout = timeout_ticks;
@@ -808,10 +814,25 @@ static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t 
         }
     }
     if (rc) return rc;
+    if (lean) return 0;                                   // host numbering, cleaned up by workgroup 0 of the launch after next
     // behind the launch: the slots of its parity back to zero (every reader of this rank is done), the device-side launch
     // number advanced
-    hipLaunchKernelGGL(k_xr_finish, dim3(1), dim3(1024), 0, st, windows, rank, world, cmax, (int)C, seq, seq_dev);
+    hipLaunchKernelGGL(k_xr_finish, dim3(1), dim3(1024), 0, st, windows, rank, world, cmax, (int)C, seq, seq ? nullptr : seq_dev);
     return launch_status();
+}
+
+// Round 5: ONE launch per tensor on the eager path.  seq: the host's launch number (1, 2, 3, ... the same on every rank);
+// zero_c: the channel count C of the launch two back on this stream (0 for the first two launches): workgroup 0 zeroes the slots
+// that launch used; seq_dev (may be NULL): device word that follows the host's count, so that a later captured launch
+// (cnnq_pc_minmax_qdq_xrank_dev on the same word) continues the numbering.  seq == 0: device numbering as
+// cnnq_pc_minmax_qdq_xrank_dev, plus the clean-up of zero_c (the first two launches after the switch).
+int cnnq_pc_minmax_qdq_xrank_seq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                                 float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                                 uint32_t seq, uint32_t* seq_dev, int zero_c, uint32_t* status, int64_t timeout_ticks, uint8_t* codes,
+                                 uint64_t* hist_rep, void* stream) {
+    if (!seq && !seq_dev) return CNNQ_EINVAL;
+    return xrank_launch(x, y, N, C, HW, num_bits, positive, ws, gws, gws_bytes, windows, rank, world, cmax, seq, seq_dev, status,
+                        timeout_ticks, codes, hist_rep, stream, zero_c, seq != 0);
 }
 
 int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,

@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
                                                  const int num_bits, const int positive, float* __restrict__ qp,
                                                  float* __restrict__ mm, const unsigned flags, const XOut xo = XOut{},
                                                  const XRank xr = XRank{}) {
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back, the sequence mirror
     __shared__ float l_mn[T * A], l_mx[T * A];
     __shared__ float sh_rs[MAXCH];
     __shared__ int sh_slow;

@@ -134,6 +134,7 @@ class XRankExchange:
         self.seq = 0
         self.calls = 0
         self.captured = 0                               # launches recorded into HIP graphs
+        self.c_hist = [0, 0]                            # channel counts of the last two launches (their slots are cleaned two launches later)
         self.stream = None
         ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
         self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
@@ -180,9 +181,11 @@ class XRankExchange:
     def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st, codes=None, hist_rep=None):
         """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm (the GLOBAL extrema) land at the
         start of the workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes).  codes / hist_rep: this rank's codes and
-        code counts (the replica tables of the single-launch kernels).  The launch's sequence number lives in device memory
-        (cnnq_pc_minmax_qdq_xrank_dev), so the call may be captured into a HIP graph - every rank then replays its graph
-        the same number of times, and checks healthy() after its replays."""
+        code counts (the replica tables of the single-launch kernels).  ONE launch per tensor (cnnq_pc_minmax_qdq_xrank_seq:
+        the host numbers the launches, workgroup 0 cleans up behind the launch two back).  The call may be captured into a
+        HIP graph: from the first captured launch on the sequence number lives in the device word and a one-workgroup kernel
+        behind each launch advances it - every rank then replays its graph the same number of times, and checks healthy()
+        after its replays."""
         capturing = torch.cuda.is_current_stream_capturing()
         if self.stream is None:
             self.stream = st
@@ -195,17 +198,22 @@ class XRankExchange:
         self.seq += 1                                   # launches ENQUEUED here (a replayed graph advances the device word, not this)
         self.calls += 1
         self.captured += 1 if capturing else 0
+        # Host numbering - ONE launch per tensor, the slots of the launch two back cleaned by its workgroup 0 - until the first
+        # captured launch; from then on the device word numbers the launches (a replay advances it, not self.seq) and the small
+        # kernel behind each launch is back.  zero_c: the channel count of the launch two back (harmless when redundant).
+        zero_c, self.c_hist = self.c_hist[0], [self.c_hist[1], int(C)]
+        host_seq = 0 if self.captured else self.seq
         if not capturing and self.calls % self.CHECK_EVERY == 0 and not self.healthy_so_far():      # periodic host check (no synchronisation)
             raise self.L.CnnqError('XRankExchange: a wait for a peer expired; results since the last check are invalid')
         if self.fail_at and self.calls == self.fail_at:
             raise self.L.CnnqError('XRankExchange: CNNQ_XRANK_TEST_FAIL_AT (test hook)')
-        rc = self.lib.cnnq_pc_minmax_qdq_xrank_dev(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
+        rc = self.lib.cnnq_pc_minmax_qdq_xrank_seq(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
                                                    ws_ptr, gws, gws_bytes, self.windows.data_ptr(), self.rank, self.world,
-                                                   self.CMAX, self.seq_dev.data_ptr(), self.status.data_ptr(), self.timeout,
-                                                   codes.data_ptr() if codes is not None else None,
+                                                   self.CMAX, host_seq, self.seq_dev.data_ptr(), zero_c, self.status.data_ptr(),
+                                                   self.timeout, codes.data_ptr() if codes is not None else None,
                                                    hist_rep.data_ptr() if hist_rep is not None else None, st)
         if rc:
-            self.L.check(rc, 'cnnq_pc_minmax_qdq_xrank_dev')
+            self.L.check(rc, 'cnnq_pc_minmax_qdq_xrank_seq')
 
     def verify(self, rounds=12):
         """Config 2 of random shards through the in-launch exchange and through the collective path, bit for bit, on

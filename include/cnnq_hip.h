@@ -399,6 +399,20 @@ int cnnq_pc_minmax_qdq_xrank_dev(const float* x, float* y, int64_t N, int64_t C,
                                  float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
                                  uint32_t* seq_dev, uint32_t* status, int64_t timeout_ticks, uint8_t* codes, uint64_t* hist_rep,
                                  void* stream);
+/* ONE launch per tensor on the eager path (round 5): host numbering without the kernel behind the launch.
+ *   seq       the host's launch number (1, 2, 3, ... the same on every rank, one per launch of the stream); 0: device numbering
+ *             exactly as cnnq_pc_minmax_qdq_xrank_dev (seq_dev required), plus the clean-up of zero_c.
+ *   zero_c    the channel count C of the launch TWO BACK on this stream (0 for the first two launches): workgroup 0 zeroes the
+ *             slots that launch used - no reader of this rank is left and no peer can be pushing there yet (csrc/cnnq_xrank.hip.h).
+ *   seq_dev   (may be NULL with seq != 0) device word that follows the host's count, so that a later captured launch with device
+ *             numbering on the same word continues it.  A stream that switches to device numbering (its first captured launch)
+ *             stays there, and passes the channel counts of its last two host-numbered launches as zero_c of its first two
+ *             device-numbered ones.
+ * The windows hold four parities (cnnq_xrank_window_bytes accounts for them). */
+int cnnq_pc_minmax_qdq_xrank_seq(const float* x, float* y, int64_t N, int64_t C, int64_t HW, int num_bits, int positive,
+                                 float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
+                                 uint32_t seq, uint32_t* seq_dev, int zero_c, uint32_t* status, int64_t timeout_ticks, uint8_t* codes,
+                                 uint64_t* hist_rep, void* stream);
 int cnnq_hist_replicas_fold(uint64_t* hist_rep, uint64_t* hist, void* stream);
 
 /* The dynamic ACIQ configurations (config 3: iq.py:327-352 + 409-451, statistics of this very tensor) behind
