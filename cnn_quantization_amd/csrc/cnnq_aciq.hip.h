@@ -199,6 +199,10 @@ constexpr int MTF_REP = 32;
 // the histogram cost the long-lived workgroups 9-16 % of the launch before.
 __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni, bool hi_ni, int wstart, unsigned* sh_hist,
                                          unsigned* sh_nan, unsigned long long* hist, int C, unsigned& nlo, unsigned& nhi) {
+#ifndef MT_CNT_ABL
+#define MT_CNT_ABL 0      // development builds (timing, WRONG histograms): bit 0 - no counting, bit 1 - no flush, bit 2 - no LDS atomic (the arithmetic stays)
+#endif
+    if (MT_CNT_ABL & 1) return;
     const int k = (int)t;                       // saturating; NaN -> 0
     const unsigned kk = (unsigned)(k - wstart);
     const bool inwin = ((float)k == t) && kk < (unsigned)MT_W;
@@ -207,7 +211,7 @@ __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni
     nhi += at_hi ? 1u : 0u;
     nlo += at_lo ? 1u : 0u;
     if (inwin) {
-        atomicAdd(&sh_hist[kk * MTF_REP + ((unsigned)threadIdx.x & (MTF_REP - 1))], 1u);
+        if (!(MT_CNT_ABL & 4) || t == 12345.f) atomicAdd(&sh_hist[kk * MTF_REP + ((unsigned)threadIdx.x & (MTF_REP - 1))], 1u);
     } else if (!(at_hi || at_lo)) {             // rare
         if (t == rintf(t)) {                    // integer code outside the window (or inf)
             if (t >= (float)(-MT_NB / 2) && t < (float)(MT_NB / 2)) atomicAdd(&hist[(int)t + MT_NB / 2], 1ull);
@@ -222,6 +226,7 @@ __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni
 __device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* hist, int C, int wstart) {
     const int tid = threadIdx.x;
     __syncthreads();
+    if (MT_CNT_ABL & 2) return;
     unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C + (size_t)(blockIdx.x & (MT_GR - 1)) * MT_W;
     for (int i = tid; i < MT_W; i += TPB) {
         unsigned tot = 0;
