@@ -33,6 +33,7 @@
 // that member's own lane mapping and folds them the same way: the same bits again, which the min / max kernels get for
 // free from exactness.
 #pragma once
+#include <type_traits>
 #include "cnnq_common.hip.h"
 #include "cnnq_group.hip.h"
 #include "cnnq_midtread.hip.h"
@@ -191,6 +192,9 @@ __device__ __forceinline__ float mt_qdq1(float x, float d, float rd, float lo, f
 // whatever the code: conflict-free by construction, as the code table of config 2) - 16 KB per workgroup, affordable because
 // these workgroups are long-lived (k_mt_qdq's short tiles keep MT_REP = 8: 4 KB to zero and flush per 56 KB of x)
 constexpr int MTF_REP = 32;
+#ifndef MT_CNT_ABL
+#define MT_CNT_ABL 0      // development builds (timing, WRONG histograms): bit 0 - no counting, bit 1 - no flush, bit 2 - no LDS atomic (the arithmetic stays)
+#endif
 // one code into the histogram.  Common case, branch-free: an integer code inside the window is one LDS atomic (zero included:
 // with a replica per lane of the LDS service group the mode of the distribution no longer serialises on one address, so the
 // register count k_mt_qdq keeps for it - and its compares - are not needed here); a code clamped to a NON-integer bound is
@@ -199,9 +203,6 @@ constexpr int MTF_REP = 32;
 // the histogram cost the long-lived workgroups 9-16 % of the launch before.
 __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni, bool hi_ni, int wstart, unsigned* sh_hist,
                                          unsigned* sh_nan, unsigned long long* hist, int C, unsigned& nlo, unsigned& nhi) {
-#ifndef MT_CNT_ABL
-#define MT_CNT_ABL 0      // development builds (timing, WRONG histograms): bit 0 - no counting, bit 1 - no flush, bit 2 - no LDS atomic (the arithmetic stays)
-#endif
     if (MT_CNT_ABL & 1) return;
     const int k = (int)t;                       // saturating; NaN -> 0
     const unsigned kk = (unsigned)(k - wstart);
@@ -222,6 +223,36 @@ __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni
         }
     }
 }
+// The same in the fast domain of the quantization (mt_fast_domain: no NaN, no inf) with clamp bounds below 2^24 in magnitude,
+// where a code is an integer or EXACTLY one of the clamp bounds: ten vector operations less per element - the store phase
+// of these kernels has no slack, the arithmetic of the count was 1.16 ms of VGG-16 b512's 17.3.  off:
+// (lane & 31) - wstart * MTF_REP, so that k * MTF_REP + off is the word of the window (as unsigned: out of range when
+// outside).  nni counts the codes that are not integers (clamped to a non-integer bound, either one), nhi those equal to hi
+// (meaningful when hi is not an integer; the caller sorts it out: mt_counts_of).
+__device__ __forceinline__ void mt_count_fast(float t, float hi, int off, unsigned* sh_hist, unsigned long long* hist, int C,
+                                              unsigned& nni, unsigned& nhi) {
+    if (MT_CNT_ABL & 1) return;
+    const int k = (int)t;
+    const bool nonint = (float)k != t;
+    const unsigned addr = (unsigned)(k * MTF_REP + off);
+    nni += nonint ? 1u : 0u;
+    nhi += (t == hi) ? 1u : 0u;
+    if (!nonint) {
+        if (addr < (unsigned)(MT_W * MTF_REP)) {
+            atomicAdd(&sh_hist[addr], 1u);
+        } else {                                    // an integer code outside the window: rare
+            if (k >= -MT_NB / 2 && k < MT_NB / 2) atomicAdd(&hist[k + MT_NB / 2], 1ull);
+            else atomicAdd(&hist[k < 0 ? MT_NB : MT_NB + 1], 1ull);
+            atomicAdd(&hist[mt_flag_word(C)], 1ull);
+        }
+    }
+}
+// (nni, nhi) of mt_count_fast -> the lane's counts of "clamped to the non-integer lower / upper bound"
+__device__ __forceinline__ void mt_counts_of(unsigned nni, unsigned nhi_raw, bool hi_ni, unsigned& nlo, unsigned& nhi) {
+    nhi = hi_ni ? nhi_raw : 0u;                     // an integer upper bound is a code like any other (counted in the window)
+    nlo = nni - nhi;                                // what is not an integer and not hi was clamped to lo
+}
+inline __device__ bool mt_count_fast_ok(float lo, float hi) { return fabsf(lo) < 0x1p24f && fabsf(hi) < 0x1p24f; }
 // end of the workgroup: the LDS window into the replica window (blockIdx picks the replica)
 __device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* hist, int C, int wstart) {
     const int tid = threadIdx.x;
@@ -454,7 +485,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         const float omega = fa.mt[(size_t)CNNQ_MT_OMEGA * g.C + c], am = fa.mt[(size_t)CNNQ_MT_ALPHA * g.C + c];
         const MtChan mc = mt_channel(fa.mcfg, omega, am, vmin, vmax, vmean, vb);
         const float d = mc.delta, lo = mc.cmin, hi = mc.cmax;
-        const bool fast = mt_fast_domain(vmin, vmax, d) && !(flags & MMQ_FLAG_IEEE_DIVIDE);
+        // (with the histogram the divide-free path also wants clamp bounds its lean count can take: mt_count_fast)
+        const bool fast = mt_fast_domain(vmin, vmax, d) && !(flags & MMQ_FLAG_IEEE_DIVIDE) && (!want_hist || mt_count_fast_ok(lo, hi));
         if (member == 0 && tid == 0) {
             fa.mt[(size_t)CNNQ_MT_DELTA * g.C + c] = d;
             fa.mt[(size_t)CNNQ_MT_CMIN * g.C + c] = lo;
@@ -463,7 +495,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         }
         const int wstart = want_hist ? (int)fa.mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
         const bool hi_ni = hi != rintf(hi), lo_ni = lo != rintf(lo);     // a non-integer bound is a value of its own
-        unsigned nlo = 0u, nhi = 0u;
+        unsigned nlo = 0u, nhi = 0u, nni = 0u;
+        const int hoff = (tid & (MTF_REP - 1)) - wstart * MTF_REP;
         auto emit = [&](const float (&t)[4], bool isfast, float rd) {
             float o[4], cd[4];
 #pragma unroll
@@ -472,8 +505,13 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                 stv_nt<4>(reinterpret_cast<float*>(yb + (w.ro + w.co)), o);
                 if constexpr (OUT == 1) {
                     if (want_hist) {
+                        if (isfast) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_cnt[0], fa.hist, g.C, nlo, nhi);
+                            for (int e = 0; e < 4; ++e) mt_count_fast(cd[e], hi, hoff, sh_hist, fa.hist, g.C, nni, nhi);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_cnt[0], fa.hist, g.C, nlo, nhi);
+                        }
                     }
                 }
             }
@@ -505,6 +543,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         }
         if constexpr (OUT == 1) {
             if (want_hist) {
+                if (__builtin_amdgcn_readfirstlane((int)fast)) mt_counts_of(nni, nhi, hi_ni, nlo, nhi);
                 if (nlo) atomicAdd(&sh_cnt[0], nlo);
                 if (nhi) atomicAdd(&sh_cnt[1], nhi);
                 mt_flush(sh_hist, fa.hist, g.C, wstart);      // (its barrier orders the counters too)
@@ -828,7 +867,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
             sh_zp[ch] = mc.cmin;
             sh_qm[ch] = mc.cmax;
             sh_rs[ch] = 1.0f / mc.delta;
-            if (!mt_fast_domain(vmin, vmax, mc.delta) || (flags & MMQ_FLAG_IEEE_DIVIDE)) sh_slow = 1;
+            if (!mt_fast_domain(vmin, vmax, mc.delta) || (flags & MMQ_FLAG_IEEE_DIVIDE) || (want_hist && !mt_count_fast_ok(mc.cmin, mc.cmax))) sh_slow = 1;
             if (rb.member == 0) {
                 aa.mt[(size_t)CNNQ_MT_DELTA * g.C + c] = mc.delta;
                 aa.mt[(size_t)CNNQ_MT_CMIN * g.C + c] = mc.cmin;
@@ -900,31 +939,38 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
         const float rd = fastq ? sh_rs[chl[0]] : 0.f;
         const int wstart = want_hist ? (int)aa.mt[(size_t)CNNQ_MT_WSTART * g.C] : 0;
         const bool hi_ni = hi != rintf(hi), lo_ni = lo != rintf(lo);
-        unsigned nlo = 0u, nhi = 0u;
+        unsigned nlo = 0u, nhi = 0u, nni = 0u;
+        const int hoff = (tidq & (MTF_REP - 1)) - wstart * MTF_REP;
+        // (two copies of the row loop behind ONE uniform branch: with the fast / general choice inside every unrolled row the
+        //  allocator spilled the tile - 528 bytes of scratch)
+        auto rows_out = [&](auto isfast_t) {
+            constexpr bool ISFAST = decltype(isfast_t)::value;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (j < nrows) {
-                float o[4], cd[4];
-                if (fastq) {
+            for (int j = 0; j < K; ++j) {
+                if (j < nrows) {
+                    float o[4], cd[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = mt_qdq1<true>(v[j][e], d, rd, lo, hi, cd[e]);
-                } else {
+                    for (int e = 0; e < 4; ++e) o[e] = mt_qdq1<ISFAST>(v[j][e], d, rd, lo, hi, cd[e]);
+                    if (okq) {
+                        stv_nt<4>(y + baseq + (size_t)j * (size_t)g.P, o);
+                        if constexpr (OUT == 1) {
+                            if (want_hist) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = mt_qdq1<false>(v[j][e], d, rd, lo, hi, cd[e]);
-                }
-                if (okq) {
-                    stv_nt<4>(y + baseq + (size_t)j * (size_t)g.P, o);
-                    if constexpr (OUT == 1) {
-                        if (want_hist) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_clo[chl[0]], aa.hist, g.C, nlo, nhi);
+                                for (int e = 0; e < 4; ++e) {
+                                    if constexpr (ISFAST) mt_count_fast(cd[e], hi, hoff, sh_hist, aa.hist, g.C, nni, nhi);
+                                    else mt_count(cd[e], lo, hi, lo_ni, hi_ni, wstart, sh_hist, &sh_clo[chl[0]], aa.hist, g.C, nlo, nhi);
+                                }
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (fastq) rows_out(std::true_type{});
+        else rows_out(std::false_type{});
         if constexpr (OUT == 1) {
             if (want_hist) {
+                if (fastq) mt_counts_of(nni, nhi, hi_ni, nlo, nhi);
                 if (nlo) atomicAdd(&sh_clo[chl[0]], nlo);
                 if (nhi) atomicAdd(&sh_chi[chl[0]], nhi);
                 mt_flush(sh_hist, aa.hist, g.C, wstart);      // (its barrier orders the clamp counters too)
