@@ -644,9 +644,12 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_grou
         for (int j = 0; j < K; ++j) {
             if (j < nrows) {
                 float o[4], cd[4];
+                if constexpr (A == 1) {
+                    qdq4_fast(v[j], sc[0], rs[0], zp[0], qm, o, cd);          // two elements per instruction, the same bits (as k_mmq_flat)
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = qdq1_fast(v[j][e], sc[A == 1 ? 0 : e], rs[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm, cd[e]);
+                    for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], sc[e], rs[e], zp[e], qm, cd[e]);
+                }
                 if (ok FLAT_ABL_NOSTORE(o))
                     xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, (base + (size_t)j * (size_t)g.P) * 4, o,
                                    cd, sh_hist, zp, nzp);

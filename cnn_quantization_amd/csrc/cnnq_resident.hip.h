@@ -185,10 +185,11 @@ __global__ void __launch_bounds__(T) k_mmq_whole(const float* __restrict__ x, fl
         for (int j = 0; j < K; ++j) {
             const int n = rlc + j * g.RL;
             float o[4], cd[4];
+            if constexpr (A == 1) {
+                qdq4_fast(v[j], sc[0], rs[0], zp[0], qm, o, cd);              // two elements per instruction, the same bits (as k_mmq_flat)
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int a = (A == 1 ? 0 : e);
-                o[e] = qdq1_fast(v[j][e], sc[a], rs[a], zp[a], qm, cd[e]);
+                for (int e = 0; e < 4; ++e) o[e] = qdq1_fast(v[j][e], sc[e], rs[e], zp[e], qm, cd[e]);
             }
             if (active && n < g.N)
                 xstore<OUT, A>(xo, reinterpret_cast<char*>(y), xo.codes, xo.packed, ((size_t)n * (size_t)g.P + colbase) * 4, o, cd,
