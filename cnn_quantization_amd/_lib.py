@@ -33,6 +33,13 @@ class ParamsCfg(ctypes.Structure):
                 ('target', ctypes.c_double), ('round_mode', ctypes.c_int32), ('direct_range', ctypes.c_int32)]
 
 
+class XRankCtx(ctypes.Structure):
+    """cnnq_xrank_ctx of include/cnnq_hip.h"""
+    _fields_ = [('windows', ctypes.c_void_p), ('rank', ctypes.c_int32), ('world', ctypes.c_int32), ('cmax', ctypes.c_int32),
+                ('seq', ctypes.c_uint32), ('seq_dev', ctypes.c_void_p), ('status', ctypes.c_void_p),
+                ('timeout_ticks', ctypes.c_int64)]
+
+
 # every symbol include/cnnq_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     'cnnq_version': (ctypes.c_char_p, []),
@@ -94,6 +101,12 @@ SIGNATURES = {
     'cnnq_pc_aciq_qdq_single': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P,
                                      ctypes.c_uint32, _P]),
     'cnnq_pc_aciq_qdq_auto': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P]),
+    'cnnq_pc_aciq_fused_xrank': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P, ctypes.c_size_t, _P, _P,
+                                      ctypes.POINTER(XRankCtx), ctypes.c_uint32, _P]),
+    'cnnq_pc_midtread_fused_xrank': (_I, [_P, _P, _L, _L, _L, ctypes.c_double, _I, _P, _I, _P, _P, _P, _P, ctypes.c_size_t, _P,
+                                          _P, ctypes.POINTER(XRankCtx), ctypes.c_uint32, _P]),
+    'cnnq_pc_stats_xrank': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, ctypes.c_size_t, _P, _P, ctypes.POINTER(XRankCtx), ctypes.c_uint32,
+                                 _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),
     'cnnq_pc_bcorr_sums': (_I, [_P, _P, _L, _L, _L, _I, _P, _P]),
     'cnnq_pc_qdq_bcorr_sums': (_I, [_P, _L, _L, _L, _P, _I, _P, _P]),

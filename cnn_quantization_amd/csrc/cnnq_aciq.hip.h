@@ -32,6 +32,13 @@
 // bit, run after run.  The cold path (a wait expired / the test hook) recomputes the partial sum of EVERY member with
 // that member's own lane mapping and folds them the same way: the same bits again, which the min / max kernels get for
 // free from exactness.
+//
+// Round 6 - XR = true: the batch is sharded over W GPUs (cnnq_xrank.hip.h).  Pass A's records travel through the collective as
+// before (the merged table in fa.stats is the GLOBAL batch's, fa.count its element count per channel); the partial sums of
+// |x - mean| of the ranks meet INSIDE this launch: after the local meeting one thread per channel pushes the rank's sum into every
+// rank's window (member 0 only) and adds the W ranks' sums in rank order - every member of every rank derives the same b, hence the
+// same parameters, bit for bit, and x is still read once (12 bytes per element sharded too, where the chain reads it three times
+// around two collectives).
 #pragma once
 #include <type_traits>
 #include "cnnq_common.hip.h"
@@ -53,18 +60,14 @@ __global__ void __launch_bounds__(PTPB) k_bitalloc(const float* __restrict__ pri
     bit_alloc_block(prior, C, cfg, bits_ws, sh);
 }
 
-// a partial sum in a slot: the complement of its bits, NaNs made canonical first (a stored word is never zero: zero
-// means "not arrived"; the sum 0.0 of a dead channel becomes all ones)
-__device__ __forceinline__ unsigned long long slot_of_sum(double s) {
-    const unsigned long long b = (s != s) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(s);
-    return ~b;
-}
-__device__ __forceinline__ double sum_of_slot(unsigned long long v) { return __longlong_as_double((long long)~v); }
+// (slot_of_sum / sum_of_slot - a partial sum as a slot word, complemented, NaNs canonical - live in cnnq_xrank.hip.h since round 6)
 
 // MODE 0: ACIQ clipping + GEMMLOWP Q/DQ (config 3).  MODE 1: mid-tread quantization with bin allocation (config 5).
 struct FusedArgs {
     float* stats;            // [CNNQ_NSTAT][C]: rows MIN, MAX, MEAN, STD from pass A; row B is written here
     double count;            // N * H*W: elements per channel
+    const double* count_dev; // XR: [C] the GLOBAL batch's elements per channel (row COUNT of the merged moment record: the shards'
+                             // sizes are known to the device, not to this rank's host)
     // MODE 0
     const float* bits;       // [C] allocated widths (k_bitalloc), or null: cfg.num_bits everywhere
     float* qp;               // [CNNQ_NQP][C] out
@@ -300,11 +303,12 @@ __device__ __forceinline__ void mt_flush(unsigned* sh_hist, unsigned long long* 
 }
 
 // ---- flat tiles (the geometry of k_mmq_flat: a group is ONE channel, a member 256 (K + KL) consecutive float4 of it) -----
-template <int K, int OUT, int KL, int MODE>
+template <int K, int OUT, int KL, int MODE, bool XR = false>
 __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_flat(
     const float* __restrict__ x, float* __restrict__ y, const FGeo g, const GWs ws, const FusedArgs fa, const unsigned flags,
-    const XOut xo = XOut{}) {
+    const XOut xo = XOut{}, const XRank xr = XRank{}) {
     static_assert(TPB == 256, "wg_sum1 folds four waves");
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back
     __shared__ double l_s[TPB / 64];
     __shared__ double sh_tot;
     extern __shared__ unsigned cnnq_dyn_lds[];     // MODE 0, OUT == 1: nbins x HREP words, sized by the launch (xhist_lds_bytes)
@@ -434,12 +438,18 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
     if (tid < 64) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) tsum += shfl_xor_d(tsum, m);
-        if (tid == 0) sh_tot = tsum;
+        if (tid == 0) {
+            // the batch is sharded: the ranks' sums, added in rank order (cnnq_xrank.hip.h); NaN when a peer never came
+            if constexpr (XR) (void)xr_merge_sum(xr, c, member == 0, tsum);
+            sh_tot = tsum;
+        }
     }
     __syncthreads();
 
     // ---- b and the channel's parameters: every lane derives the same values from the same inputs
-    const float vb = (float)(sh_tot / fa.count);
+    double cnt = fa.count;
+    if constexpr (XR) cnt = fa.count_dev[c];          // (uniform address: a scalar load)
+    const float vb = (float)(sh_tot / cnt);
     w = w0;
     asm volatile("" : "+v"(w.ro), "+v"(w.co));      // the walk repeated and hidden from the optimiser, as in k_mmq_flat
     if constexpr (MODE == 0) {
@@ -726,11 +736,16 @@ __device__ __forceinline__ void group_fold_sums(const unsigned long long* src, i
 }
 
 // MODE 1 (mid-tread): sh_sc = delta, sh_zp = c_min, sh_qm = c_max, sh_rs = 1 / delta; A == 1 only (no VGG layer straddles)
-template <int A, int K, int OUT, int MODE>
-__global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_group(
+// (waves per SIMD the K = 32 tile is compiled for: three - 168 registers - except the one instance that does not fit them, the
+//  mid-tread form with the histogram AND the cross-rank stage, which takes two: no instance of the library uses scratch)
+template <int K, int OUT, int MODE, bool XR>
+constexpr int fused_group_waves() { return K != 32 ? 1 : (XR && OUT == 1 && MODE == 1) ? 2 : GRP_K32_WAVES; }
+template <int A, int K, int OUT, int MODE, bool XR = false>
+__global__ void __launch_bounds__(TPB, (fused_group_waves<K, OUT, MODE, XR>())) k_fused_group(
     const float* __restrict__ x, float* __restrict__ y, const Geo g, const int Gs, const GWs ws, const FusedArgs aa,
-    const unsigned flags, const XOut xo = XOut{}) {
+    const unsigned flags, const XOut xo = XOut{}, const XRank xr = XRank{}) {
     static_assert(MODE == 0 || A == 1, "the mid-tread form has no straddling instance");
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back
     __shared__ double l_a[TPB * A];
     __shared__ double sh_sum[MAXCH];
     extern __shared__ unsigned cnnq_dyn_lds[];     // MODE 0, OUT == 1: nbins x HREP words, sized by the launch (xhist_lds_bytes)
@@ -863,11 +878,23 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
         wg_channel_sums<1>(g, b, true, one, l_a, sh_sum);
     }
 
+    if constexpr (XR) {
+        // the batch is sharded: every rank's sum of the owned channels, added in rank order (cnnq_xrank.hip.h); a loop of its own -
+        // next to the parameter arithmetic below its state cost the K = 32 tile registers it does not have.  (Lane tid reads
+        // sh_sum[tid] back below: no barrier.)
+        for (int ch = tid; ch < nch; ch += TPB) {
+            double csum = sh_sum[ch];
+            (void)xr_merge_sum(xr, b.c0 + ch, rb.member == 0, csum);
+            sh_sum[ch] = csum;
+        }
+    }
     // ---- b and the parameters of the owned channels: identical in every member
     for (int ch = tid; ch < nch; ch += TPB) {
         const int c = b.c0 + ch;
         const float vmin = aa.stats[(size_t)CNNQ_STAT_MIN * g.C + c], vmax = aa.stats[(size_t)CNNQ_STAT_MAX * g.C + c];
-        const float vb = (float)(sh_sum[ch] / aa.count);
+        double cnt = aa.count;
+        if constexpr (XR) cnt = aa.count_dev[c];
+        const float vb = (float)(sh_sum[ch] / cnt);
         if constexpr (MODE == 0) {
             const float vstd = aa.stats[(size_t)CNNQ_STAT_STD * g.C + c];
             const float bits = ba ? aa.bits[c] : (float)cfg.num_bits;
@@ -910,6 +937,10 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
     // cost registers the K = 32 tile does not leave (spills)
     int tidq = threadIdx.x;
     asm volatile("" : "+v"(tidq));
+    // ... and the row count: the compiler otherwise keeps the K results of `j < nrows` of the first phase as 64-bit masks for this
+    // one - 64 scalar registers, spilled into lanes of two vector registers the tile needs (round 6)
+    int nrows_q = nrows;
+    asm volatile("" : "+s"(nrows_q));
     const bool okq = b.col0 + tidq < b.col1;
     const unsigned colq = (unsigned)(okq ? b.col0 + tidq : b.col0);
     const size_t baseq = (size_t)b.n0 * (size_t)g.P + (size_t)colq * 4;
@@ -936,7 +967,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
             for (int a = 0; a < A; ++a) rs[a] = sh_rs[chl[a]];
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                if (j < nrows) {
+                if (j < nrows_q) {
                     float o[4], cd[4];
                     if constexpr (A == 1) {
                         qdq4_fast(v[j], sc[0], rs[0], zp[0], qm[0], o, cd);      // two elements per instruction, the same bits
@@ -952,7 +983,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
         } else {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                if (j < nrows) {
+                if (j < nrows_q) {
                     float o[4], cd[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc[A == 1 ? 0 : e], zp[A == 1 ? 0 : e], qm[A == 1 ? 0 : e], cd[e]);
@@ -979,7 +1010,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_gr
             constexpr bool ISFAST = decltype(isfast_t)::value;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                if (j < nrows) {
+                if (j < nrows_q) {
                     float o[4], cd[4];
                     if constexpr (ISFAST) {
                         mt_qdq4_fast(v[j], d, rd, lo, hi, o, cd);

@@ -360,7 +360,7 @@ int plan_flat(int64_t N, int64_t C, int64_t HW, GPlan* p, int lds_rows, bool all
     return 0;
 }
 
-int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, int lds_rows);
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, int lds_rows, int a4_kmax);
 
 // the lds_rows argument of the config-2 kernels' plans: k_mmq_flat has KL = 8 instances for the plain and the packed output
 // (<32, 0 / 2, false, 8>), none for the codes output and the cross-rank stage; CNNQ_FLAT_KL=8 (development knob): every
@@ -372,18 +372,21 @@ inline int flat_lds_rows(int out, bool xrank) {
 
 // plans are pure functions of their arguments (the development knobs are read once): the hot call asks for the same
 // handful of geometries over and over, so each host thread remembers the last 64
-int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true, int lds_rows = 0) {
+// a4_kmax: the tallest tile of the straddling row pieces (A = 4): 32 for the extrema kernels; the kernels that carry SUMS across
+// the meeting (k_fused_group, k_stats_group) hold per-element accumulators and parameters next to the tile and take 16 (plan_sums
+// below) - their K = 32 instances spilled a tile row (round 6: no instance of the library uses scratch)
+int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat = true, int lds_rows = 0, int a4_kmax = 32) {
     struct Entry { int64_t N, C, HW; int key, rc; GPlan plan; };
     constexpr int SLOTS = 64;
     thread_local Entry cache[SLOTS];
     thread_local int used = 0, next = 0;
-    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0) | (lds_rows << 2);
+    const int key = (aligned16 ? 1 : 0) | (allow_flat ? 2 : 0) | (lds_rows << 2) | (a4_kmax << 4);
     for (int i = 0; i < used; ++i)
         if (cache[i].N == N && cache[i].C == C && cache[i].HW == HW && cache[i].key == key) {
             *p = cache[i].plan;
             return cache[i].rc;
         }
-    const int rc = plan_group_compute(N, C, HW, aligned16, p, allow_flat, lds_rows);
+    const int rc = plan_group_compute(N, C, HW, aligned16, p, allow_flat, lds_rows, a4_kmax);
     Entry& e = cache[next];
     e.N = N; e.C = C; e.HW = HW; e.key = key; e.rc = rc; e.plan = *p;
     next = (next + 1) % SLOTS;
@@ -391,15 +394,19 @@ int plan_group(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool 
     return rc;
 }
 
-int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p);
+int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p, int a4_kmax = 32);
+// the plan of the single-launch kernels that exchange sums (configs 3 / 4 / 5)
+inline int plan_sums(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, int lds_rows) {
+    return plan_group(N, C, HW, aligned16, p, true, lds_rows, 16);
+}
 
-int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, int lds_rows) {
+int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* p, bool allow_flat, int lds_rows, int a4_kmax) {
     if (N <= 0 || C <= 0 || HW <= 0) return CNNQ_EINVAL;
     if (!aligned16) return CNNQ_ENOTSUP;
     p->flat = 0;
     p->KL = 0;
     if (allow_flat && plan_flat(N, C, HW, p, lds_rows, false) == 0) return 0;
-    const int rc = plan_rows(N, C, HW, p);
+    const int rc = plan_rows(N, C, HW, p, a4_kmax);
     if (rc != CNNQ_ENOTSUP || !allow_flat || lds_rows == 0) return rc;
     // neither fits: a channel too populous for 512 plain tiles - flat tiles with eight more rows in LDS, if that is enough
     GPlan q;
@@ -409,7 +416,7 @@ int plan_group_compute(int64_t N, int64_t C, int64_t HW, bool aligned16, GPlan* 
 }
 
 // the row-piece tiling of k_mmq_group
-int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p) {
+int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p, int a4_kmax) {
     p->flat = 0;
     p->KL = 0;
     if (HW % 4 == 0) {
@@ -434,7 +441,9 @@ int plan_rows(int64_t N, int64_t C, int64_t HW, GPlan* p) {
         for (K = 32; K > 4; K >>= 1)   // the largest tile that still yields `target` workgroups
             if ((int64_t)g.ncb * ((N + K - 1) / K) >= target) break;
     }
-    while (K < 32 && ((N + K - 1) / K) * members_per_split > grp_gs_max()) K <<= 1;   // groups stay co-resident
+    if (p->v.A == 4 && K > a4_kmax) K = a4_kmax;
+    const int kcap = p->v.A == 4 ? a4_kmax : 32;
+    while (K < kcap && ((N + K - 1) / K) * members_per_split > grp_gs_max()) K <<= 1;   // groups stay co-resident
     const int64_t S = (N + K - 1) / K;
     if (S * members_per_split > grp_gs_max()) return CNNQ_ENOTSUP;
     if (S * g.ncb >= (int64_t)1 << 31) return CNNQ_ERANGE;
@@ -516,8 +525,12 @@ int launch_group(const float* x, float* y, const GPlan& p, int num_bits, int pos
 
 // the single-launch ACIQ / mid-tread kernels (cnnq_aciq.hip.h; mode 0 / 1) on the plan and the workspace of launch_group;
 // slot meeting only.  out: mode 0 - 1 with codes / histogram (xo); mode 1 - 1 with the code histogram (fa.hist)
+// xrp (round 6): the batch is sharded - the instances with the cross-rank stage (y only in mode 0; y / y + histogram in mode 1)
 int launch_fused(int mode, const float* x, float* y, const GPlan& p, const FusedArgs& fa, void* ws, unsigned flags, hipStream_t st,
-                 int out, const XOut& xo) {
+                 int out, const XOut& xo, const XRank* xrp = nullptr) {
+    const bool xrank = xrp && xrp->world > 0;
+    if (xrank && mode == 0 && out == 1) return CNNQ_ENOTSUP;
+    const XRank xr = xrank ? *xrp : XRank{};
     if ((size_t)p.ngroups * p.gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
     if (p.KL && !(p.flat && p.K == 32 && p.KL == 8)) return CNNQ_ENOTSUP;
     if (mode == 1 && !p.flat && p.v.A != 1) return CNNQ_ENOTSUP;      // no straddling mid-tread instance
@@ -537,7 +550,10 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
         const dim3 fgrid((unsigned)((int64_t)p.fg.C * p.fg.Gs));
 #define LAUNCH_FF(K, KL)                                                                                                   \
     do {                                                                                                                   \
-        if (mode == 0 && out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, 0, 0>), fgrid, block, hb, st, x, y, p.fg, w, fa, flags, xo);   \
+        if (xrank && mode == 0) hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 0, true>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo, xr);       \
+        else if (xrank && out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, KL, 1, true>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo, xr);   \
+        else if (xrank) hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 1, true>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo, xr);               \
+        else if (mode == 0 && out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, 0, 0>), fgrid, block, hb, st, x, y, p.fg, w, fa, flags, xo);   \
         else if (mode == 0) hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 0>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);         \
         else if (out == 1) hipLaunchKernelGGL((k_fused_flat<K, 1, KL, 1>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);          \
         else hipLaunchKernelGGL((k_fused_flat<K, 0, KL, 1>), fgrid, block, 0, st, x, y, p.fg, w, fa, flags, xo);                        \
@@ -552,13 +568,16 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb));
 #define LAUNCH_FG(A, K, MODE)                                                                                                   \
     do {                                                                                                                        \
-        if (out == 1) hipLaunchKernelGGL((k_fused_group<A, K, 1, MODE>), grid, block, (MODE == 0 ? hb : 0), st, x, y, p.g, p.Gs, w, fa, flags, xo);   \
+        if (xrank && out == 1) { if constexpr (MODE == 1) hipLaunchKernelGGL((k_fused_group<A, K, 1, MODE, true>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo, xr); } \
+        else if (xrank) hipLaunchKernelGGL((k_fused_group<A, K, 0, MODE, true>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo, xr);   \
+        else if (out == 1) hipLaunchKernelGGL((k_fused_group<A, K, 1, MODE>), grid, block, (MODE == 0 ? hb : 0), st, x, y, p.g, p.Gs, w, fa, flags, xo);   \
         else hipLaunchKernelGGL((k_fused_group<A, K, 0, MODE>), grid, block, 0, st, x, y, p.g, p.Gs, w, fa, flags, xo);            \
     } while (0)
     if (mode == 1) {
         if (p.K == 32) LAUNCH_FG(1, 32, 1); else if (p.K == 16) LAUNCH_FG(1, 16, 1); else if (p.K == 8) LAUNCH_FG(1, 8, 1); else LAUNCH_FG(1, 4, 1);
     } else if (p.v.A == 4) {
-        if (p.K == 32) LAUNCH_FG(4, 32, 0); else if (p.K == 16) LAUNCH_FG(4, 16, 0); else if (p.K == 8) LAUNCH_FG(4, 8, 0); else LAUNCH_FG(4, 4, 0);
+        if (p.K == 32) return CNNQ_ENOTSUP;      // plan_sums never plans it (no such instance: it spilled)
+        if (p.K == 16) LAUNCH_FG(4, 16, 0); else if (p.K == 8) LAUNCH_FG(4, 8, 0); else LAUNCH_FG(4, 4, 0);
     } else {
         if (p.K == 32) LAUNCH_FG(1, 32, 0); else if (p.K == 16) LAUNCH_FG(1, 16, 0); else if (p.K == 8) LAUNCH_FG(1, 8, 0); else LAUNCH_FG(1, 4, 0);
     }
@@ -567,7 +586,10 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
 }
 
 // the single-read statistics kernel (cnnq_stats1.hip.h) on a flat plan and the workspace of launch_group
-int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* ws, unsigned flags, bool ntl, hipStream_t st) {
+int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* ws, unsigned flags, bool ntl, hipStream_t st,
+                      const XRank* xrp = nullptr) {
+    const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: both phases' folds exchanged inside the launch
+    const XRank xr = xrank ? *xrp : XRank{};
     if (!p.flat || p.KL) return CNNQ_ENOTSUP;
     if ((size_t)p.ngroups * p.gstride * ST_LINE * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
     GWs w;
@@ -581,7 +603,11 @@ int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* w
     fg.cb = 1;          // member fastest: with nothing to write the launch is bound by how long a group's members wait for each other
 #define LAUNCH_SF(KR, KL)                                                                                              \
     do {                                                                                                               \
-        if (sa.need_relu && ntl) hipLaunchKernelGGL((k_stats_flat<KR, KL, true, true>), grid, block, 0, st, x, fg, w, sa, flags);   \
+        if (xrank) {                                                                                                   \
+            if (sa.need_relu) hipLaunchKernelGGL((k_stats_flat<KR, KL, true, false, true>), grid, block, 0, st, x, fg, w, sa, flags, xr);   \
+            else hipLaunchKernelGGL((k_stats_flat<KR, KL, false, false, true>), grid, block, 0, st, x, fg, w, sa, flags, xr);                \
+        }                                                                                                              \
+        else if (sa.need_relu && ntl) hipLaunchKernelGGL((k_stats_flat<KR, KL, true, true>), grid, block, 0, st, x, fg, w, sa, flags);   \
         else if (sa.need_relu) hipLaunchKernelGGL((k_stats_flat<KR, KL, true, false>), grid, block, 0, st, x, fg, w, sa, flags);    \
         else if (ntl) hipLaunchKernelGGL((k_stats_flat<KR, KL, false, true>), grid, block, 0, st, x, fg, w, sa, flags);             \
         else hipLaunchKernelGGL((k_stats_flat<KR, KL, false, false>), grid, block, 0, st, x, fg, w, sa, flags);                     \
@@ -612,7 +638,8 @@ int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* 
         else hipLaunchKernelGGL((k_stats_group<A, KR, KL, false>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags);              \
     } while (0)
     if (p.v.A == 4) {
-        if (p.K == 32) LAUNCH_SG(4, 24, 8); else if (p.K == 16) LAUNCH_SG(4, 16, 0); else if (p.K == 8) LAUNCH_SG(4, 8, 0); else LAUNCH_SG(4, 4, 0);
+        if (p.K == 32) return CNNQ_ENOTSUP;      // plan_sums never plans it (no such instance: it spilled)
+        if (p.K == 16) LAUNCH_SG(4, 16, 0); else if (p.K == 8) LAUNCH_SG(4, 8, 0); else LAUNCH_SG(4, 4, 0);
     } else {
         if (p.K == 32) LAUNCH_SG(1, 24, 8); else if (p.K == 16) LAUNCH_SG(1, 16, 0); else if (p.K == 8) LAUNCH_SG(1, 8, 0); else LAUNCH_SG(1, 4, 0);
     }

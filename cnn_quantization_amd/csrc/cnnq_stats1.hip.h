@@ -19,6 +19,12 @@
 // only the order of the fp64 additions differs, as it does between any two tilings: results agree with the chain to fp64
 // rounding, and are bit-identical run after run and between the meeting and the recompute path (the cold path recomputes
 // EVERY member's words with that member's own lane mapping and folds them in the same order).
+//
+// Round 6 - XR = true (k_stats_flat): the batch is sharded over W GPUs (cnnq_xrank.hip.h).  After each phase's LOCAL meeting the
+// folded words of the rank - phase 1: the pair, the sums, and the rank's element count; phase 2: the two sums - are exchanged with
+// the other ranks inside the launch (lane w of wave 0 takes word w: one polling loop for all of them; member 0 pushes, every
+// member reads its own rank's window) and folded in rank order, so every rank writes the row of the GLOBAL batch from one read
+// of its shard.  Slots: word w of channel c in slot w * C + c (phase 1: words 0..5, phase 2: 6..7).
 #pragma once
 #include "cnnq_aciq.hip.h"
 #include "cnnq_common.hip.h"
@@ -30,6 +36,8 @@ namespace {
 constexpr int ST_W1 = 5;     // phase-1 words of a member: {min, max} pair, sum, sum of squares, relu sum, relu sum of squares
 constexpr int ST_W2 = 2;     // phase-2 words: sum |x - mean|, sum z^4
 constexpr int ST_LINE = 8;   // words per member line (64 bytes: one store instruction of lanes 0..4 covers a phase's words)
+constexpr int ST_XW_COUNT = 5;   // cross-rank words of phase 1 (XR): 0..4 as above, 5 the rank's element count; phase 2: 6, 7
+constexpr int ST_XW = 8;         // slots per channel a sharded launch uses
 
 struct St1Args {
     float* stats;            // [CNNQ_NSTAT][C] out: every row
@@ -141,11 +149,14 @@ struct StWords {
 
 // KR steps of the tile in registers, the first KL in LDS (LDS-DMA: no staging registers) - the 128 KB tile is 24 + 8: with
 // all 32 steps in registers next to the accumulators of two phases the allocator spilled six of them
-template <int KR, int KL, bool RELU, bool NTL>
+template <int KR, int KL, bool RELU, bool NTL, bool XR = false>
 __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_stats_flat(const float* __restrict__ x, const FGeo g, const GWs ws,
-                                                                                       const St1Args sa, const unsigned flags) {
+                                                                                       const St1Args sa, const unsigned flags,
+                                                                                       const XRank xr = XRank{}) {
     static_assert(TPB == 256, "four waves");
     constexpr int K = KR + KL;
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back
+    __shared__ double sh_count;                        // XR: the global batch's elements per channel
     __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
     __shared__ float l_mn[TPB / 64], l_mx[TPB / 64];
     __shared__ double l_d[4][TPB / 64];
@@ -308,11 +319,32 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         st_fold_finish(fold, NW1, true, sh_out, sh_mm);
         __syncthreads();
     }
+    if constexpr (XR) {
+        // the batch is sharded: lane w of wave 0 exchanges word w of the rank's fold with the other ranks (word 0: the pair; 1 ..
+        // NW1 - 1: sums; ST_XW_COUNT: the rank's element count) - rank order, the same bits on every rank
+        if (tid <= ST_XW_COUNT && (tid < NW1 || tid == ST_XW_COUNT)) {
+            unsigned long long bits;
+            if (tid == 0) bits = (unsigned long long)__float_as_uint(sh_mm[0]) | ((unsigned long long)__float_as_uint(sh_mm[1]) << 32);
+            else bits = (unsigned long long)__double_as_longlong(tid == ST_XW_COUNT ? sa.count : sh_out[tid]);
+            (void)xr_merge_word(xr, tid * g.C + c, member == 0, tid == 0, bits);
+            if (tid == 0) {
+                sh_mm[0] = __uint_as_float((unsigned)(bits & 0xffffffffull));
+                sh_mm[1] = __uint_as_float((unsigned)(bits >> 32));
+            } else if (tid == ST_XW_COUNT) {
+                sh_count = __longlong_as_double((long long)bits);
+            } else {
+                sh_out[tid] = __longlong_as_double((long long)bits);
+            }
+        }
+        __syncthreads();
+    }
+    // (re-read from LDS at every use under XR: a double held across phase 2 next to the tile is a spill candidate)
+    auto count_of = [&]() -> double { if constexpr (XR) return sh_count; else return sa.count; };
     // mean / std / std_pos: every lane derives the same values (the formulas of k_combine); the folded words stay in LDS for
     // the final row - seven doubles held across phase 2 next to the tile were spilled
     float mean, sd, std_pos = 0.f;
     {
-        const MomSum r{(double)sh_mm[0], (double)sh_mm[1], sh_out[1], sh_out[2], sa.count, RELU ? sh_out[3] : 0., RELU ? sh_out[4] : 0.};
+        const MomSum r{(double)sh_mm[0], (double)sh_mm[1], sh_out[1], sh_out[2], count_of(), RELU ? sh_out[3] : 0., RELU ? sh_out[4] : 0.};
         mean = mean_of(r);
         sd = std_of(r);
         if constexpr (RELU) {
@@ -393,8 +425,16 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             st_fold_finish(fold, ST_W2, false, sh_out2, sh_mm);
             __syncthreads();
         }
-        vb = (float)(sh_out2[0] / sa.count);
-        kurt = sa.need_kurt ? (float)(sh_out2[1] / sa.count - 3.) : 0.f;
+        if constexpr (XR) {
+            if (tid < ST_W2) {
+                double s2 = sh_out2[tid];
+                (void)xr_merge_sum(xr, (ST_XW_COUNT + 1 + tid) * g.C + c, member == 0, s2);
+                sh_out2[tid] = s2;
+            }
+            __syncthreads();
+        }
+        vb = (float)(sh_out2[0] / count_of());
+        kurt = sa.need_kurt ? (float)(sh_out2[1] / count_of() - 3.) : 0.f;
     }
     if (member == 0 && tid == 0) {
         const size_t C = (size_t)g.C;
@@ -410,7 +450,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             sa.mom[(size_t)CNNQ_MOM_MAX * C + c] = (double)sh_mm[1];
             sa.mom[(size_t)CNNQ_MOM_SUM * C + c] = sh_out[1];
             sa.mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = sh_out[2];
-            sa.mom[(size_t)CNNQ_MOM_COUNT * C + c] = sa.count;
+            sa.mom[(size_t)CNNQ_MOM_COUNT * C + c] = count_of();
             sa.mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = RELU ? sh_out[3] : 0.;
             sa.mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = RELU ? sh_out[4] : 0.;
         }

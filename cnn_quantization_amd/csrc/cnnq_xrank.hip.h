@@ -31,6 +31,14 @@
 //     host numbering (zero_c: redundant zeroing of slots nobody is using is harmless).  A wait gives up after `timeout` ticks of the 100 MHz clock: the channel's outputs are then NaN and bit 2 of
 // the status word is raised (a peer that never launches would otherwise hang the device); once raised, later waits give up
 // at once.  The host checks the word (periodically, without synchronising) and falls back to the collective.
+//
+// Round 6: the same windows carry SUMS (configs 3 / 4 / 5 sharded: k_fused_flat / k_fused_group / k_stats_flat with the cross-rank
+// stage).  A slot is one 8-byte word whatever it holds; a launch addresses its slots as [word][channel] (word * C + channel: up
+// to 8 C slots for the two phases of the statistics kernel), a sum travels as the complement of its fp64 bits (xr_merge_sum) and
+// the W ranks' words are added in RANK order by every reader: the same bits on every rank.  And the clean-up no longer depends
+// on what the host remembers: workgroup 0 of a launch records the number of slots the launch uses in the device array
+// cdev[parity] and zeroes the slots cdev[(parity + 2) & 3] recorded two launches back - eager and captured launches, replays in
+// any order and a switch from host to device numbering all leave the same trail.
 #pragma once
 #include "cnnq_common.hip.h"
 
@@ -43,7 +51,9 @@ struct XRank {
     const unsigned* seq_dev;   // device-side numbering (round 4): the launch's number is *seq_dev + 1; k_xr_finish advances the
                                // word behind the launch, so a captured graph replays with fresh numbers
     unsigned* seq_mirror;      // host-side numbering: workgroup 0 stores seq here (the device word a later capture continues from)
-    int zero_c;                // channels of the launch two back: workgroup 0 zeroes its slots (0: nothing to clean)
+    int zero_c;                // slots of the launch two back: workgroup 0 zeroes them (0: nothing to clean); only without cdev
+    unsigned* cdev;            // [4] slots in use per parity, kept by the launches themselves (round 6; null: zero_c from the host)
+    int nslots;                // slots this launch uses per rank (C for the extrema; words * C for the sums)
     int cmax;                  // channels a window holds per (parity, rank)
     unsigned* status;          // |= XR_STATUS_PEER_TIMEOUT
     long long timeout;         // ticks of the 100 MHz clock
@@ -61,73 +71,122 @@ __device__ __forceinline__ unsigned long long xr_slot_of(float mn, float mx) {
     return ~((unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32));
 }
 
+// a partial sum in a slot: the complement of its bits, NaNs made canonical first (a stored word is never zero: zero
+// means "not arrived"; the sum 0.0 of a dead channel becomes all ones)
+__device__ __forceinline__ unsigned long long slot_of_sum(double s) {
+    const unsigned long long b = (s != s) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(s);
+    return ~b;
+}
+__device__ __forceinline__ double sum_of_slot(unsigned long long v) { return __longlong_as_double((long long)~v); }
+
 __device__ __forceinline__ unsigned long long* xr_slot(void* win, unsigned parity, int world, int cmax, int r, int c) {
     return reinterpret_cast<unsigned long long*>(win) + ((size_t)((int)parity * world + r) * (size_t)cmax + (size_t)c);
 }
 
-// One thread per channel: push the local extrema (if `push`), then wait for every rank's and fold them.  Returns false
-// when a wait expired (mn / mx are NaN then and the status word is raised).
-__device__ __forceinline__ bool xr_merge(const XRank& xr, int c, bool push, float& mn, float& mx) {
-    // the word is only written by k_xr_finish, between launches of one stream: every thread of a launch reads the same value
-    const unsigned seq = xr.seq_dev ? __hip_atomic_load(xr.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : xr.seq;
-    const unsigned par = seq & (XR_PARITIES - 1u);
+// the launch's number: the host's, or the device word + 1 (written only between launches of one stream: every thread of a launch
+// reads the same value)
+__device__ __forceinline__ unsigned xr_seq(const XRank& xr) {
+    return xr.seq_dev ? __hip_atomic_load(xr.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : xr.seq;
+}
+
+// One thread per slot: push this rank's word (if `push`) into slot s of every rank's window, wait for the W words of the own
+// window and fold them in rank order - `bits` in and out: a {min, max} pair as two fp32 (is_pair: NaN-propagating min / max,
+// exact) or the fp64 bits of a partial sum (added in rank order: the same total on every rank, bit for bit).  What travels is
+// the complement, NaNs canonical first, so a published slot is never zero.  Returns false when a wait expired (the result is
+// NaN then and the status word is raised).  Lanes of one wave may call it together with different slots and kinds (one loop).
+__device__ __forceinline__ bool xr_merge_word(const XRank& xr, int s, bool push, bool is_pair, unsigned long long& bits) {
+    const unsigned par = xr_seq(xr) & (XR_PARITIES - 1u);
     if (push) {
         // The windows are uncached (fine-grained) memory: every access goes to the owner's memory - no release / acquire
         // fences, which at system scope write back and invalidate the whole L2 (measured: the b512 forward 2.3 ms slower)
-        const unsigned long long v = xr_slot_of(mn, mx);
+        unsigned long long v;
+        if (is_pair) v = xr_slot_of(__uint_as_float((unsigned)(bits & 0xffffffffull)), __uint_as_float((unsigned)(bits >> 32)));
+        else v = slot_of_sum(__longlong_as_double((long long)bits));
         for (int r = 0; r < xr.world; ++r)
-            __hip_atomic_store(xr_slot(xr.windows[r], par, xr.world, xr.cmax, xr.rank, c), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(xr_slot(xr.windows[r], par, xr.world, xr.cmax, xr.rank, s), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     void* own = xr.windows[xr.rank];
     float a = INFINITY, b = -INFINITY;
+    double acc = 0.;
     // one expired wait poisons every later one (a peer that is gone would otherwise cost `timeout` per channel)
     bool ok = !(__hip_atomic_load(xr.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & XR_STATUS_PEER_TIMEOUT);
     const long long t0 = wall_clock64();
     for (int r = 0; r < xr.world && ok; ++r) {
-        const unsigned long long* s = xr_slot(own, par, xr.world, xr.cmax, r, c);
+        const unsigned long long* p = xr_slot(own, par, xr.world, xr.cmax, r, s);
         unsigned long long v;
         int polls = 0;
-        while ((v = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0ull) {
+        while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0ull) {
             if ((++polls & 31) == 0 && wall_clock64() - t0 > xr.timeout) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         if (ok) {
             v = ~v;
-            const float p = __uint_as_float((unsigned)(v & 0xffffffffull)), q = __uint_as_float((unsigned)(v >> 32));
-            a = pmin(a, p);
-            b = pmax(b, q);
+            if (is_pair) {
+                a = pmin(a, __uint_as_float((unsigned)(v & 0xffffffffull)));
+                b = pmax(b, __uint_as_float((unsigned)(v >> 32)));
+            } else {
+                acc += __longlong_as_double((long long)v);      // rank order, whatever the arrival order was
+            }
         }
     }
     if (!ok) {
         atomicOr(xr.status, XR_STATUS_PEER_TIMEOUT);
         a = NAN;
         b = NAN;
+        acc = NAN;
     }
-    mn = a;
-    mx = b;
+    bits = is_pair ? ((unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32))
+                   : (unsigned long long)__double_as_longlong(acc);
+    return ok;
+}
+
+// the extrema of a channel (config 2): push the local pair, fold every rank's
+__device__ __forceinline__ bool xr_merge(const XRank& xr, int c, bool push, float& mn, float& mx) {
+    unsigned long long bits = (unsigned long long)__float_as_uint(mn) | ((unsigned long long)__float_as_uint(mx) << 32);
+    const bool ok = xr_merge_word(xr, c, push, true, bits);
+    mn = __uint_as_float((unsigned)(bits & 0xffffffffull));
+    mx = __uint_as_float((unsigned)(bits >> 32));
+    return ok;
+}
+
+// a partial sum (round 6: configs 3 / 4 / 5): push this rank's, add every rank's in rank order
+__device__ __forceinline__ bool xr_merge_sum(const XRank& xr, int s, bool push, double& sum) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
+    const bool ok = xr_merge_word(xr, s, push, false, bits);
+    sum = __longlong_as_double((long long)bits);
     return ok;
 }
 
 // Workgroup 0 of every exchanging launch, before anything else: the slots of the launch two back are zeroed (see the header of
-// this file for why nobody can be using them), and with host numbering the device word follows the host's count.
+// this file for why nobody can be using them), and with host numbering the device word follows the host's count.  With `cdev`
+// the launches keep the books themselves: cdev[parity] = slots in use; this launch zeroes what cdev[(parity + 2) & 3] says, clears
+// that entry and records its own count - whatever the host captured, replayed or ran eagerly in between.
 __device__ __forceinline__ void xr_prologue(const XRank& xr) {
     if (blockIdx.x != 0) return;
-    if (xr.zero_c > 0) {
-        const unsigned seq = xr.seq_dev ? __hip_atomic_load(xr.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : xr.seq;
-        const unsigned par = (seq + 2u) & (XR_PARITIES - 1u);
+    const unsigned seq = xr_seq(xr);
+    const unsigned par = (seq + 2u) & (XR_PARITIES - 1u);
+    const int zc = xr.cdev ? (int)__hip_atomic_load(xr.cdev + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xr.zero_c;
+    if (zc > 0) {
         void* own = xr.windows[xr.rank];
-        for (int i = (int)threadIdx.x; i < xr.world * xr.zero_c; i += (int)blockDim.x) {
-            const int r = i / xr.zero_c, c = i - r * xr.zero_c;
+        for (int i = (int)threadIdx.x; i < xr.world * zc; i += (int)blockDim.x) {
+            const int r = i / zc, c = i - r * zc;
             __hip_atomic_store(xr_slot(own, par, xr.world, xr.cmax, r, c), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (xr.cdev) {
+        __syncthreads();                               // every thread of workgroup 0 has read the count before it is cleared
+        if (threadIdx.x == 0) {
+            xr.cdev[par] = 0u;
+            xr.cdev[seq & (XR_PARITIES - 1u)] = (unsigned)xr.nslots;
         }
     }
     if (xr.seq_mirror && threadIdx.x == 0) *xr.seq_mirror = xr.seq;      // nobody reads the word under host numbering
 }
 
 // device numbering: enqueued behind every exchanging launch (ONE workgroup): every reader of this rank is done, so the slots of
-// the launch's parity are zeroed, and the device-side launch number advances
+// the launch's parity are zeroed (nslots per rank), its cdev entry cleared, and the device-side launch number advances
 __global__ void __launch_bounds__(1024) k_xr_finish(void* const* windows, const int rank, const int world, const int cmax, const int C,
-                                                    const unsigned seq, unsigned* seq_dev) {
+                                                    const unsigned seq, unsigned* seq_dev, unsigned* cdev) {
     void* own = windows[rank];
     const unsigned par = (seq_dev ? *seq_dev + 1u : seq) & (XR_PARITIES - 1u);
     __syncthreads();                                   // everybody has read the word before thread 0 advances it
@@ -135,7 +194,10 @@ __global__ void __launch_bounds__(1024) k_xr_finish(void* const* windows, const 
         const int r = i / C, c = i - r * C;
         __hip_atomic_store(xr_slot(own, par, world, cmax, r, c), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (seq_dev && threadIdx.x == 0) *seq_dev += 1u;
+    if (threadIdx.x == 0) {
+        if (cdev) cdev[par] = 0u;
+        if (seq_dev) *seq_dev += 1u;
+    }
 }
 
 // the exchange alone, for a rank whose shard has no single-launch kernel: mm[2][C] local extrema in, folded extrema out
@@ -147,6 +209,22 @@ __global__ void __launch_bounds__(TPB) k_xr_exchange(float* __restrict__ mm, con
     (void)xr_merge(xr, c, true, mn, mx);
     mm[c] = mn;
     mm[C + c] = mx;
+}
+
+// ... and for sums (round 6): vals[nw][C] this rank's partial sums in, the W ranks' sums added in rank order out; word w of
+// channel c travels in slot (w0 + w) * C + c - the layout of the single-launch kernels, so a rank whose shard has no single-launch
+// plan speaks the same protocol around the chain's passes.  pair0: word 0 is a {min, max} pair stored as two floats in vals[0][c]
+// (the statistics kernel's phase 1) and folds like the extrema.
+__global__ void __launch_bounds__(TPB) k_xr_exchange_sums(double* __restrict__ vals, const int C, const int nw, const int w0, const int pair0,
+                                                          const int prologue, const XRank xr) {
+    if (prologue) xr_prologue(xr);
+    const int i = (int)blockIdx.x * TPB + (int)threadIdx.x;
+    if (i >= nw * C) return;
+    const int w = i / C, c = i - w * C;
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(vals);
+    unsigned long long bits = words[i];
+    (void)xr_merge_word(xr, (w0 + w) * C + c, true, pair0 && w == 0, bits);
+    words[i] = bits;
 }
 
 }  // namespace

@@ -87,7 +87,8 @@ class XRankExchange:
     the exchange against the collective path on every rank and must pass before use.  One stream per group, every rank issues
     the same launches in the same order.  Launches CAN be captured into a HIP graph (the sequence number is a device word);
     the windows of an exchange whose launches were captured stay mapped after close() so that a stale replay cannot fault."""
-    CMAX = 4096                                         # channels per (parity, rank) record block: 1 MB at 8 ranks
+    CMAX = 16384                                        # slots per (parity, rank) block: 4 MB at 8 ranks (config 2 and the fused clipping
+                                                        # kernels use C slots per launch, the statistics kernel 8 C: 2048 channels fit)
     TIMEOUT_TICKS = 6000000000                          # 60 s of the 100 MHz clock
     CHECK_EVERY = 64                                    # launches between two host checks of the status word (about one per
                                                         # ResNet-50 forward)
@@ -134,13 +135,15 @@ class XRankExchange:
         self.seq = 0
         self.calls = 0
         self.captured = 0                               # launches recorded into HIP graphs
-        self.c_hist = [0, 0]                            # channel counts of the last two launches (their slots are cleaned two launches later)
         self.stream = None
         ms = os.environ.get('CNNQ_XRANK_TIMEOUT_MS')
         self.timeout = int(float(ms) * 1e5) if ms else self.TIMEOUT_TICKS
-        self.seq_dev = None                             # the device-side sequence word (allocated at the first launch)
+        self.seq_dev = None                             # eight device words: [0] the sequence word, [4..7] the slots in use per parity
+                                                        # (kept by the launches themselves; allocated at the first launch)
         fa = os.environ.get('CNNQ_XRANK_TEST_FAIL_AT')    # tests: rank 0 reports an expired wait at its n-th launch
         self.fail_at = int(fa) if (fa and self.rank == 0) else 0
+        ea = os.environ.get('CNNQ_XRANK_TEST_EXPIRE_AT')  # tests: rank 0's status word reports an expired wait from its n-th launch on
+        self.expire_at = int(ea) if (ea and self.rank == 0) else 0
 
     def _all_agree(self, flag):
         """Group-wide AND of a local boolean (a collective)."""
@@ -152,8 +155,9 @@ class XRankExchange:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(t.item()))
 
-    def fits(self, C):
-        return 0 < C <= self.CMAX
+    def fits(self, C, words=1):
+        """A launch over C channels with `words` slots per channel fits the windows."""
+        return 0 < C * words <= self.CMAX
 
     def healthy(self):
         """Host check (synchronises): no wait for a peer has expired so far.  Call it at synchronisation points and after
@@ -178,14 +182,12 @@ class XRankExchange:
         self._snap = snap
         return ok
 
-    def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st, codes=None, hist_rep=None):
-        """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm (the GLOBAL extrema) land at the
-        start of the workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes).  codes / hist_rep: this rank's codes and
-        code counts (the replica tables of the single-launch kernels).  ONE launch per tensor (cnnq_pc_minmax_qdq_xrank_seq:
-        the host numbers the launches, workgroup 0 cleans up behind the launch two back).  The call may be captured into a
-        HIP graph: from the first captured launch on the sequence number lives in the device word and a one-workgroup kernel
-        behind each launch advances it - every rank then replays its graph the same number of times, and checks healthy()
-        after its replays."""
+    def _next_launch(self, st):
+        """The bookkeeping every exchanging launch shares (all four kinds draw from ONE sequence per stream): returns the host's
+        launch number, or 0 from the first captured launch on (device numbering: a replay advances the device word, not
+        self.seq, and a one-workgroup kernel behind each launch zeroes its slots).  Which slots a launch leaves behind is
+        recorded on the device by the launch itself (round 6; ADVICE r5: the host's memory of the last two channel counts was
+        wrong for a graph captured after eager launches with more channels, replayed out of order, ...)."""
         capturing = torch.cuda.is_current_stream_capturing()
         if self.stream is None:
             self.stream = st
@@ -194,22 +196,42 @@ class XRankExchange:
         if self.seq_dev is None:
             if capturing:
                 raise self.L.CnnqError('XRankExchange: run one launch eagerly before capturing (the sequence word is allocated at first use)')
-            self.seq_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.seq += 1                                   # launches ENQUEUED here (a replayed graph advances the device word, not this)
+            self.seq_dev = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.seq += 1                                   # launches ENQUEUED here
         self.calls += 1
         self.captured += 1 if capturing else 0
-        # Host numbering - ONE launch per tensor, the slots of the launch two back cleaned by its workgroup 0 - until the first
-        # captured launch; from then on the device word numbers the launches (a replay advances it, not self.seq) and the small
-        # kernel behind each launch is back.  zero_c: the channel count of the launch two back (harmless when redundant).
-        zero_c, self.c_hist = self.c_hist[0], [self.c_hist[1], int(C)]
-        host_seq = 0 if self.captured else self.seq
-        if not capturing and self.calls % self.CHECK_EVERY == 0 and not self.healthy_so_far():      # periodic host check (no synchronisation)
+        if (_RECOVERY == 'raise' and not capturing and self.calls % self.CHECK_EVERY == 0
+                and not self.healthy_so_far()):         # periodic host check (no synchronisation); 'checkpoint': the program checks itself
             raise self.L.CnnqError('XRankExchange: a wait for a peer expired; results since the last check are invalid')
         if self.fail_at and self.calls == self.fail_at:
             raise self.L.CnnqError('XRankExchange: CNNQ_XRANK_TEST_FAIL_AT (test hook)')
+        if self.expire_at and self.calls == self.expire_at and not capturing:
+            self.status.fill_(4)                        # test hook: as if a wait for a peer had expired in the previous launch
+        return 0 if self.captured else self.seq
+
+    def ctx(self, st):
+        """The cnnq_xrank_ctx of the NEXT launch on stream st (consumes a launch number)."""
+        c = self.L.XRankCtx()
+        c.windows = self.windows.data_ptr()
+        c.rank, c.world, c.cmax = self.rank, self.world, self.CMAX
+        c.seq = self._next_launch(st)
+        c.seq_dev = self.seq_dev.data_ptr()
+        c.status = self.status.data_ptr()
+        c.timeout_ticks = self.timeout
+        return c
+
+    def minmax_qdq(self, x, y, N, C, HW, num_bits, positive, ws_ptr, gws, gws_bytes, st, codes=None, hist_rep=None):
+        """Enqueue config 2 of this rank's shard x -> y with the in-launch exchange; qp / mm (the GLOBAL extrema) land at the
+        start of the workspace at `ws_ptr` (cnnq_pc_minmax_qdq_workspace bytes).  codes / hist_rep: this rank's codes and
+        code counts (the replica tables of the single-launch kernels).  ONE launch per tensor (cnnq_pc_minmax_qdq_xrank_seq:
+        the host numbers the launches, workgroup 0 cleans up behind the launch two back).  The call may be captured into a
+        HIP graph: from the first captured launch on the sequence number lives in the device word and a one-workgroup kernel
+        behind each launch advances it - every rank then replays its graph the same number of times, and checks healthy()
+        after its replays."""
+        host_seq = self._next_launch(st)
         rc = self.lib.cnnq_pc_minmax_qdq_xrank_seq(x.data_ptr(), y.data_ptr(), N, C, HW, int(num_bits), 1 if positive else 0,
                                                    ws_ptr, gws, gws_bytes, self.windows.data_ptr(), self.rank, self.world,
-                                                   self.CMAX, host_seq, self.seq_dev.data_ptr(), zero_c, self.status.data_ptr(),
+                                                   self.CMAX, host_seq, self.seq_dev.data_ptr(), 0, self.status.data_ptr(),
                                                    self.timeout, codes.data_ptr() if codes is not None else None,
                                                    hist_rep.data_ptr() if hist_rep is not None else None, st)
         if rc:
@@ -231,6 +253,13 @@ class XRankExchange:
             ok = ok and bool(torch.equal(ref, got))
         return self._all_agree(ok and self.healthy())
 
+    def _unmap(self):
+        for w in self.mapped:
+            self.lib.cnnq_xrank_close(w)
+        if self.own is not None:
+            self.lib.cnnq_xrank_free(self.own)
+        self.mapped, self.own = [], None
+
     def close(self):
         """Collective: unmap the peers' windows and free the own one once nobody uses them any more.  When launches of this
         exchange were captured into HIP graphs the windows stay mapped (a few MB, for the life of the process): a replay of
@@ -239,11 +268,10 @@ class XRankExchange:
         torch.cuda.synchronize()
         dist.barrier(group=self.group)
         if not self.captured:
-            for w in self.mapped:
-                self.lib.cnnq_xrank_close(w)
-            if self.own is not None:
-                self.lib.cnnq_xrank_free(self.own)
-        self.mapped, self.own, self.ok = [], None, False
+            self._unmap()
+        else:
+            _RETIRED.append(self)                        # release_retired_exchanges() once the graphs are gone
+        self.ok = False
         for k in [k for k, v in _XRANK.items() if v is self]:    # a closed exchange must not be handed out again
             del _XRANK[k]
         from . import ops
@@ -252,6 +280,16 @@ class XRankExchange:
 
 _XRANK = {}
 _XRANK_MODE = None
+_RECOVERY = 'raise'
+_RETIRED = []       # closed exchanges whose launches live on in captured graphs: their windows stay mapped
+
+
+def release_retired_exchanges():
+    """Unmap / free the windows of closed exchanges that were kept because HIP graphs held launches of them.  Call it once
+    those graphs have been destroyed (a replay afterwards would fault); local, synchronises the device."""
+    torch.cuda.synchronize()
+    while _RETIRED:
+        _RETIRED.pop()._unmap()
 
 
 def set_xrank_mode(mode):
@@ -266,13 +304,15 @@ def set_xrank_mode(mode):
 
 
 def xrank_mode():
-    """Which exchange a batch-sharded config 2 uses.  '0' (DEFAULT): the collective - statistics launch, RCCL all_gather on
-    the compute stream, Q/DQ launch; host-side skew between the ranks is harmless there.  '1': the in-launch exchange whenever
-    a group exchanges (also ranks that share a GPU, also a forced 1-rank exchange).  'auto': the in-launch exchange when the
-    group has several ranks and one GPU per rank (backend nccl = RCCL) - ranks that share a device cannot count on their
-    launches running together.  From set_xrank_mode, else CNNQ_XRANK."""
+    """Which exchange the batch-sharded single-launch paths use (config 2's extrema; since round 6 the sums of configs 3 / 4 / 5).
+    'auto' (DEFAULT since round 6): the in-launch exchange when the group has several ranks and one GPU per rank (backend nccl =
+    RCCL), after it reproduced the collective's bits on every rank (XRankExchange.verify) - ranks that share a device (the gloo
+    rigs of the tests) cannot count on their launches running together and keep the collective.  '0': the collective -
+    statistics launch, RCCL all_gather on the compute stream, Q/DQ launch; host-side skew between the ranks is harmless there.
+    '1': the in-launch exchange whenever a group exchanges (also ranks that share a GPU, also a forced 1-rank exchange).  From
+    set_xrank_mode, else CNNQ_XRANK.  The recovery that makes 'auto' a safe default is xrank_checkpoint()."""
     import os
-    m = _XRANK_MODE if _XRANK_MODE is not None else os.environ.get('CNNQ_XRANK', '0')
+    m = _XRANK_MODE if _XRANK_MODE is not None else os.environ.get('CNNQ_XRANK', 'auto')
     return m if m in ('1', 'auto') else '0'
 
 
@@ -299,6 +339,40 @@ def xrank_exchange(group=None):
             ex.close()
         _XRANK[key] = ex if good else None
     return _XRANK[key]
+
+
+def set_xrank_recovery(mode):
+    """How an expired wait of the in-launch exchange surfaces.  'raise' (default): the exchange looks at its status word every
+    CHECK_EVERY launches without synchronising and raises CnnqError on the rank that saw the expiry - like a collective's
+    timeout, the job ends.  'checkpoint': the program calls xrank_checkpoint() at its own synchronisation points (every rank,
+    together) and redoes the work since the last one when it returns False; nothing raises in between, so no rank leaves the
+    lock-step of the collectives on its own.  harness/inference_sim.py uses 'checkpoint'."""
+    global _RECOVERY
+    if mode not in ('raise', 'checkpoint'):
+        raise ValueError(mode)
+    _RECOVERY = mode
+
+
+def xrank_checkpoint(group=None):
+    """The recovery of the in-launch exchange, for the program's own synchronisation points (the end of a forward pass, after
+    the replays of a captured graph).  COLLECTIVE and synchronising: every rank of `group` calls it at the same point.  True:
+    no wait for a peer has expired on any rank since the last checkpoint - everything computed since then stands.  False: some
+    rank's wait expired (its outputs of that launch and of its later launches are NaN): the group's exchange has been closed on
+    every rank - the collective serves the group from now on - and the caller redoes the work since the last checkpoint
+    (harness/inference_sim.py re-runs the batch).  Without an exchange (mode '0', one rank, ranks sharing a GPU) it returns
+    True without synchronising."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    ex = _XRANK.get(key)
+    if ex is None:
+        return True
+    ok = ex._all_agree(ex.healthy())
+    if not ok:
+        if rank(group) == 0:
+            print('cnn_quantization_amd: a wait of the in-launch exchange expired on some rank; the group continues on the collective')
+        disable_xrank(group)
+    return ok
 
 
 def disable_xrank(group=None):

@@ -173,6 +173,12 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
     in rank order on every rank, so all ranks hold the statistics of the GLOBAL batch."""
     x = _dev_f32(x, 'x')
     world = 1 if local_only else D.world_size(group)
+    if not local_only and (world > 1 or D.forced_exchange()) and _ACIQ_SINGLE and _RESIDENT:
+        # the batch is sharded and the group has a (verified) in-launch exchange: the table of the GLOBAL batch from one read of
+        # this rank's shard (cnnq_pc_stats_xrank; round 6) - every rank takes this route or none does
+        res = _pc_stats_xrank(x, N, C, HW, need_b, need_kurt, need_relu, group)
+        if res is not None:
+            return res
     if world == 1:
         # one C call, one cached workspace (cnnq_pc_stats_auto)
         lib = L.load()
@@ -200,6 +206,122 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
             part2 = D.all_gather_records(dev_local, group)
         pc_combine_dev(part2, mom, stats, need_kurt)
     return stats, mom
+
+
+def _xrank_for(group, C, words=1):
+    """The group's in-launch exchange (D.xrank_exchange: opt-in mode, verified against the collective on every rank) when a launch
+    over C channels with `words` slots per channel fits its windows, else None.  Depends on the group and the layer only - never
+    on this rank's shard - so all ranks decide alike."""
+    if not _XRANK_ON:
+        return None
+    xr = D.xrank_exchange(group)
+    return xr if (xr is not None and xr.fits(C, words)) else None
+
+
+def _pc_stats_xrank(x, N, C, HW, need_b, need_kurt, need_relu, group, flags=0):
+    """Config 4 of a batch shard in ONE launch and one read of x (k_stats_flat with the cross-rank stage; a shard without a
+    flat-tile plan runs the chain's passes around the same window slots inside the call).  Returns (stats, mom) of the GLOBAL
+    batch, or None when the group has no in-launch exchange."""
+    xr = _xrank_for(group, C, 8)
+    if xr is None:
+        return None
+    lib = L.load()
+    st = _raw_stream(x.device.index)
+    al = int(x.data_ptr() % 16 == 0)
+    nbytes = lib.cnnq_pc_stats_workspace(N, C, HW, al)
+    if nbytes == 0:
+        L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+    gws = _group_workspace(x, st)
+    stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
+    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
+    ws = _scratch(x, 'stats', nbytes + 16 * C * 8, st)
+    ctx = xr.ctx(st)
+    L.check(lib.cnnq_pc_stats_xrank(x.data_ptr(), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)), ws.data_ptr(),
+                                    gws, GROUP_WS_BYTES if gws is not None else 0, mom.data_ptr(), stats.data_ptr(), ctypes.byref(ctx),
+                                    int(flags), st), 'cnnq_pc_stats_xrank')
+    return stats, mom
+
+
+def _global_pass_a(x, N, C, HW, group, st):
+    """Pass A of a batch shard made global: this shard's moment records, merged, all-gathered (one collective of 7 C doubles per
+    rank) and merged in rank order.  Returns (stats [NSTAT + NQP + NDIAG, C] fp32 with rows MIN, MAX, MEAN, STD filled, mom
+    [NMOM, C] fp64 of the global batch)."""
+    lib = L.load()
+    part = pc_moments(x, N, C, HW)
+    mom_local = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_pc_combine(part.data_ptr(), part.shape[0], C, 0, mom_local.data_ptr(), None, st), 'cnnq_pc_combine')
+    gathered = D.all_gather_records(mom_local, group)
+    tabs = torch.empty((L.NSTAT + L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
+    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
+    L.check(lib.cnnq_pc_combine(gathered.data_ptr(), gathered.shape[0], C, 0, mom.data_ptr(), tabs.data_ptr(), st), 'cnnq_pc_combine')
+    return tabs, mom
+
+
+def _aciq_workspace(x, N, C, HW, st):
+    lib = L.load()
+    al = int(x.data_ptr() % 16 == 0)
+    key = ('aciq', N, C, HW, al)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WS_BYTES[key] = (lib.cnnq_pc_aciq_workspace(N, C, HW, al) + 15) // 16 * 16
+    return _scratch(x, 'aciq', nbytes + (L.NQP + L.NDIAG) * C * 4, st)
+
+
+def _aciq_qdq_xrank(x, N, C, HW, cfg, group, want_parts, out, flags=0):
+    """Config 3 of a batch shard (Laplace clipping, optional bit allocation on the 'gaus' prior): pass A -> all_gather of the
+    moment records -> merge -> (bit allocation) -> ONE launch that reads x once and exchanges the ranks' sums of |x - mean| through
+    the windows (cnnq_pc_aciq_fused_xrank; round 6): 12 bytes per element and one collective where the chain moves 16 around two.
+    Returns y [, parts], or None when the group has no in-launch exchange (the caller takes the chain)."""
+    xr = _xrank_for(group, C)
+    if xr is None:
+        return None
+    lib = L.load()
+    st = _raw_stream(x.device.index)
+    y = _out_like(x, out)
+    tabs, mom = _global_pass_a(x, N, C, HW, group, st)
+    stats, qp, diag = tabs[:L.NSTAT], tabs[L.NSTAT:L.NSTAT + L.NQP], tabs[L.NSTAT + L.NQP:]
+    gws = _group_workspace(x, st)
+    ws = _aciq_workspace(x, N, C, HW, st)
+    ctx = xr.ctx(st)
+    L.check(lib.cnnq_pc_aciq_fused_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), stats.data_ptr(),
+                                         mom[L.MOM_COUNT].data_ptr(), ws.data_ptr(), gws, GROUP_WS_BYTES if gws is not None else 0,
+                                         qp.data_ptr(), diag.data_ptr(), ctypes.byref(ctx), int(flags), st), 'cnnq_pc_aciq_fused_xrank')
+    if want_parts:
+        return y, dict(stats=stats, qp=qp, diag=diag)
+    return y
+
+
+def _mid_tread_qdq_xrank(x, N, C, HW, target, sym, tabs_mt, group, want_entropy, want_parts, flags=0):
+    """Config 5 of a batch shard: as _aciq_qdq_xrank with the bin allocation and MODE 1 of the fused kernels
+    (cnnq_pc_midtread_fused_xrank); the ranks' code counts are summed before the entropy.  Returns what mid_tread_qdq returns, or
+    None when the group has no in-launch exchange."""
+    xr = _xrank_for(group, C)
+    if xr is None:
+        return None
+    lib = L.load()
+    st = _raw_stream(x.device.index)
+    y = torch.empty_like(x)
+    tabs, mom = _global_pass_a(x, N, C, HW, group, st)
+    stats = tabs[:L.NSTAT]
+    mt = torch.empty((L.NMT, C), dtype=torch.float32, device=x.device)
+    hist = torch.empty(L.mt_hist_words(C), dtype=torch.int64, device=x.device) if want_entropy else None     # zeroed by the call
+    gws = _group_workspace(x, st)
+    ws = _aciq_workspace(x, N, C, HW, st)
+    ctx = xr.ctx(st)
+    L.check(lib.cnnq_pc_midtread_fused_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, float(target), int(bool(sym)), tabs_mt.data_ptr(),
+                                             tabs_mt.shape[1], stats.data_ptr(), mom[L.MOM_COUNT].data_ptr(), ws.data_ptr(), gws,
+                                             GROUP_WS_BYTES if gws is not None else 0, mt.data_ptr(), _ptr(hist), ctypes.byref(ctx),
+                                             int(flags), st), 'cnnq_pc_midtread_fused_xrank')
+    entropy = None
+    if want_entropy:
+        D.all_reduce_sum_(hist, group)
+        ent = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.check(lib.cnnq_midtread_entropy(_ptr(hist), _ptr(mt), C, x.numel() * D.world_size(group), _ptr(ent), st), 'cnnq_midtread_entropy')
+        entropy = ent[0]
+    res = [y, entropy]
+    if want_parts:
+        res.append(dict(stats=stats, mt=mt, hist=hist))
+    return tuple(res)
 
 
 def pc_stats_single(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, flags=8):
@@ -972,9 +1094,17 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         return res
     # Laplace clipping with dynamic statistics on one GPU: pass B, the parameters and the Q/DQ in ONE launch that reads
     # x once (cnnq_pc_aciq_qdq_single: 12 instead of 16 bytes per element) when the shape has a single-launch plan
-    single = (_ACIQ_SINGLE and _RESIDENT and stats is None and world == 1 and bcorr is None and clip == 'laplace'
+    exchanging = group is not False and (world > 1 or D.forced_exchange())     # x is this rank's shard of the batch
+    single = (_ACIQ_SINGLE and _RESIDENT and stats is None and bcorr is None and clip == 'laplace'
               and not whole_tensor and not (use_ba and prior_is_b) and num_bits <= 8)
-    if (stats is None and world == 1 and bcorr is None and not (want_codes or want_entropy or want_parts)):
+    if single and exchanging and not (want_codes or want_entropy):
+        # sharded: the ranks' sums meet inside the single launch (round 6); None: no in-launch exchange for this group - the chain
+        cfg = _params_cfg(num_bits, positive, clip, use_ba, prior_is_b, target, round_mode, whole_tensor)
+        res = _aciq_qdq_xrank(x, N, C, HW, cfg, group, want_parts, out)
+        if res is not None:
+            return res
+    single = single and not exchanging
+    if (stats is None and not exchanging and bcorr is None and not (want_codes or want_entropy or want_parts)):
         # one host call for the whole pipeline (cnnq_pc_aciq_qdq_auto: four launches through the single-launch kernel,
         # else the five of the chain), one cached workspace (statistics partials, then the parameter and diagnostic
         # tables, which nobody outside the call reads)
@@ -1110,8 +1240,14 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
     local = group is False
     grp = None if local else group
     tabs = _midtread_tables(x.device)
+    exchanging = not local and (D.world_size(grp) > 1 or D.forced_exchange())
+    if _ACIQ_SINGLE and _RESIDENT and clip and not whole_tensor and per_channel_dim == 1 and not want_codes and exchanging:
+        # sharded: pass A through the collective, the ranks' sums of |x - mean| inside the single launch (round 6)
+        res = _mid_tread_qdq_xrank(x, N, C, HW, target, sym, tabs, grp, want_entropy, want_parts)
+        if res is not None:
+            return res
     if (_ACIQ_SINGLE and _RESIDENT and clip and not whole_tensor and per_channel_dim == 1 and not want_codes
-            and (local or D.world_size(grp) == 1)):
+            and not exchanging):
         # pass B, the step sizes / clamp bounds and the quantization in ONE launch that reads x once
         # (cnnq_pc_midtread_qdq_single: 12 instead of 16 bytes per element) when the shape has a single-launch plan
         res = mid_tread_qdq_single(x, N, C, HW, target, sym, tabs, want_entropy, want_parts)

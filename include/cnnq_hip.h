@@ -388,7 +388,8 @@ int cnnq_pc_minmax_qdq_xrank(const float* x, float* y, int64_t N, int64_t C, int
                              float* ws, void* gws, size_t gws_bytes, void* const* windows, int rank, int world, int cmax,
                              uint32_t seq, uint32_t* status, int64_t timeout_ticks, void* stream);
 /* The same with DEVICE-side sequence numbers and the optional outputs of cnnq_pc_minmax_qdq_single (round 4):
- *   seq_dev   device word (zero at start, one per rank): the launch's number is *seq_dev + 1 and the small kernel
+ *   seq_dev   EIGHT device words (zero at start, one block per rank; round 6: words [4..7] hold the slots in use per parity,
+ *             kept by the launches themselves): the launch's number is seq_dev[0] + 1 and the small kernel
  *             enqueued behind the launch advances the word - nothing about the call changes from launch to launch, so it
  *             can be captured into a HIP graph and replayed (every rank replays the same graph the same number of times).
  *   codes / hist_rep   as for cnnq_pc_minmax_qdq_single (num_bits <= 8): this rank's codes, and this rank's code counts in
@@ -402,8 +403,10 @@ int cnnq_pc_minmax_qdq_xrank_dev(const float* x, float* y, int64_t N, int64_t C,
 /* ONE launch per tensor on the eager path (round 5): host numbering without the kernel behind the launch.
  *   seq       the host's launch number (1, 2, 3, ... the same on every rank, one per launch of the stream); 0: device numbering
  *             exactly as cnnq_pc_minmax_qdq_xrank_dev (seq_dev required), plus the clean-up of zero_c.
- *   zero_c    the channel count C of the launch TWO BACK on this stream (0 for the first two launches): workgroup 0 zeroes the
- *             slots that launch used - no reader of this rank is left and no peer can be pushing there yet (csrc/cnnq_xrank.hip.h).
+ *   zero_c    only without seq_dev: the channel count C of the launch TWO BACK on this stream (0 for the first two launches):
+ *             workgroup 0 zeroes the slots that launch used - no reader of this rank is left and no peer can be pushing there yet
+ *             (csrc/cnnq_xrank.hip.h).  With seq_dev (eight words) the launches keep these counts on the device and zero_c is
+ *             ignored (round 6, ADVICE r5: captured, replayed and eager launches in any order leave the same trail).
  *   seq_dev   (may be NULL with seq != 0) device word that follows the host's count, so that a later captured launch with device
  *             numbering on the same word continues it.  A stream that switches to device numbering (its first captured launch)
  *             stays there, and passes the channel counts of its last two host-numbered launches as zero_c of its first two
@@ -440,6 +443,47 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
 /* cnnq_pc_aciq_qdq_single when it applies, else cnnq_pc_aciq_qdq: one call, same ws. */
 int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
                           void* gws, size_t gws_bytes, float* qp, float* diag, void* stream);
+
+/* Round 6 - configs 3 / 5 / 4 of a BATCH SHARD with the cross-rank exchange inside the single launch (csrc/cnnq_xrank.hip.h,
+ * csrc/cnnq_aciq.hip.h, csrc/cnnq_stats1.hip.h): the sharded forms of cnnq_pc_aciq_qdq_single, cnnq_pc_midtread_qdq_single and
+ * cnnq_pc_stats_single.  The reference has no counterpart (its DataParallel replicas quantize with their own sub-batch's
+ * statistics, inference_sim.py:196-200); these reproduce int_quantizer.py:327-359 / 185-225 and
+ * statistic_manager_perchannel.py:45-79 on the GLOBAL batch from one read of each rank's shard.
+ *   cnnq_xrank_ctx   the exchange of config 2 (same windows, same launch numbering, same status word - the launches of all
+ *                    four entry points share ONE sequence per stream):
+ *       windows / rank / world / cmax   as cnnq_pc_minmax_qdq_xrank; a launch needs C slots per rank (the statistics kernel 8 C)
+ *       seq       the host's launch number (1, 2, 3, ...); 0: device numbering (captured launches), see _xrank_dev
+ *       seq_dev   EIGHT device words, zeroed once (one block per rank and stream): [0] the launch number, [4..7] the slots in
+ *                 use per parity - the launches record and clean them themselves (no host bookkeeping; also used by
+ *                 cnnq_pc_minmax_qdq_xrank_seq / _dev since round 6, which therefore need the eight words too)
+ *       status / timeout_ticks   as cnnq_pc_minmax_qdq_xrank: bit 2 when a wait for a peer expired (outputs NaN)
+ * Sums travel as the complement of their fp64 bits and every reader adds the W ranks' words in RANK order: all ranks derive
+ * the same b / mean / std, hence the same parameters, bit for bit.  A shard without a single-launch plan runs the chain's
+ * passes around the same slots, so the ranks need not agree on their plans; every call consumes exactly one launch number. */
+typedef struct cnnq_xrank_ctx {
+    void* const* windows;
+    int32_t rank, world, cmax;
+    uint32_t seq;
+    uint32_t* seq_dev;
+    uint32_t* status;
+    int64_t timeout_ticks;
+} cnnq_xrank_ctx;
+/* stats: rows MIN, MAX, MEAN, STD of the GLOBAL batch in (pass A merged over the ranks by the caller), row B out; count: [C] device
+ * doubles, the global batch's elements per channel (row CNNQ_MOM_COUNT of the merged moment record); ws: cnnq_pc_aciq_workspace bytes; qp / diag out as cnnq_pc_params (the same on every
+ * rank).  Laplace clipping, bit allocation on the 'gaus' prior, num_bits <= 8 (else CNNQ_ENOTSUP: nothing enqueued). */
+int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, float* stats,
+                             const double* count, void* ws, void* gws, size_t gws_bytes, float* qp, float* diag, const cnnq_xrank_ctx* xc,
+                             unsigned flags, void* stream);
+/* mid-tread with clipping; mt[CNNQ_NMT][C] out; hist (optional, CNNQ_MT_HIST_WORDS(C), zeroed here) counts THIS rank's codes:
+ * sum the ranks' tables before cnnq_midtread_entropy (total = the global element count). */
+int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, double target, int sym, const double* tables,
+                                 int ntab, float* stats, const double* count, void* ws, void* gws, size_t gws_bytes, float* mt, uint64_t* hist,
+                                 const cnnq_xrank_ctx* xc, unsigned flags, void* stream);
+/* the seven statistics (and the merged moment record, mom may be NULL) of the GLOBAL batch on every rank; 8 C <= cmax;
+ * ws: cnnq_pc_stats_workspace + 16 C doubles; flags as cnnq_pc_stats_single (bit 0: recompute path, bit 3: also channels
+ * of more than 128 tiles). */
+int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
+                        size_t gws_bytes, double* mom, float* stats, const cnnq_xrank_ctx* xc, unsigned flags, void* stream);
 
 /* Weight bias / variance correction after quantization (iqm.py:374-391), in place on
  * wq[C][HW]: vcorr: wq = (wq - mean_q) * std_w/(std_q + 1e-8) + mean_q; bcorr: wq = wq - mean_q + mean_w

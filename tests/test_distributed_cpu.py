@@ -82,14 +82,16 @@ def _worker(rank, world, port, tmp):
     m = D.merge_row_minmax(st, rows, True, None)
     assert m.shape == (7, 10)
     assert torch.equal(m[0], per_sample_min) and torch.equal(m[1], per_sample_max)
-    # the exchange selection: the in-launch exchange is opt-in ('0' unless asked for); auto never starts it on a backend
-    # whose ranks may share a GPU; nothing here touches a device
+    # the exchange selection: 'auto' is the default (round 6: the recovery lives in the product, D.xrank_checkpoint); auto never
+    # starts the in-launch exchange on a backend whose ranks may share a GPU; nothing here touches a device
     for mode in ('auto', '0', 'bogus'):
         os.environ['CNNQ_XRANK'] = mode
         assert D.xrank_mode() == ('auto' if mode == 'auto' else '0')
         assert D.xrank_exchange(None) is None
     os.environ.pop('CNNQ_XRANK')
-    assert D.xrank_mode() == '0'
+    assert D.xrank_mode() == 'auto'
+    assert D.xrank_exchange(None) is None
+    assert D.xrank_checkpoint(None) is True                 # no exchange: nothing to check, no synchronisation
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, 'ok%d' % rank), 'w').write('ok')
@@ -124,8 +126,13 @@ def test_xrank_mode_without_a_process_group(monkeypatch):
         assert D.xrank_mode() == want
         assert D.xrank_exchange(None) is None
     monkeypatch.delenv('CNNQ_XRANK')
-    assert D.xrank_mode() == '0'                       # opt-in: the default sharded route is the collective
-    D.set_xrank_mode('auto')                           # a program that implements the recovery opts in for itself
-    assert D.xrank_mode() == 'auto' and D.xrank_exchange(None) is None
+    assert D.xrank_mode() == 'auto'                    # round 6: the default (D.xrank_checkpoint is the recovery)
+    D.set_xrank_mode('0')                              # a program may still rule the in-launch exchange out for itself
+    assert D.xrank_mode() == '0' and D.xrank_exchange(None) is None
     D.set_xrank_mode(None)
-    assert D.xrank_mode() == '0'
+    assert D.xrank_mode() == 'auto'
+    assert D.xrank_checkpoint(None) is True            # no process group: nothing to check
+    for mode in ('raise', 'checkpoint', 'raise'):
+        D.set_xrank_recovery(mode)
+    with pytest.raises(ValueError):
+        D.set_xrank_recovery('bogus')
