@@ -292,12 +292,10 @@ def main():
     from cnn_quantization_amd import ops, _lib
     from cnn_quantization_amd import distributed as D
     _lib.load()                                         # fail loudly if the HIP library is missing
-    if 'CNNQ_XRANK' not in os.environ:
-        # The library's default for a sharded run is the collective route.  This program opts into 'auto' - with one GPU per
-        # rank, try the in-launch exchange first - because it implements what that takes: both routes are probed before the
-        # warm-up and the faster one is kept, and if a wait for a peer expires all ranks drop to the collective together and
-        # the job is timed again (below).
-        D.set_xrank_mode('auto')
+    # The library's default for a sharded run is 'auto' since round 6 (with one GPU per rank the in-launch exchange, verified at
+    # first use; distributed.xrank_checkpoint is the recovery).  This program adds what a benchmark owes on top: both routes are
+    # probed before the warm-up and the faster one is kept, and if a wait for a peer expires all ranks drop to the collective
+    # together and the job is timed again (below).
     if args.scaling == 'strong':
         n0, n1 = D.shard_batch(args.batch, rank, world)
         per_rank = n1 - n0
@@ -421,7 +419,8 @@ def main():
             sustained = {'steps': ksus, 'seconds': dts, 'ms_per_step': dts * 1e3 / ksus, 'value': total_elems * ksus / dts,
                          'path_frac_hbm_peak_8B': total_elems / world * ksus / dts * BYTES_QDQ / 1e9 / HBM_PEAK_GBS,
                          'note': 'the timed step repeated for ~%.0f s right after the timed region (max over ranks); '
-                                 'path_frac_hbm_peak_8B prices every element at the 8 bytes the single launch moves' % args.sustained_secs}
+                                 'path_frac_hbm_peak_8B prices every element at the 8 bytes the single launch moves (what the line\'s '
+                                 'path_frac_hbm_peak does for the timed steps on the single-launch routes)' % args.sustained_secs}
     if world == 1 and not args.force_exchange:
         exchange_name = 'none (1 GPU)'
     elif D.xrank_exchange(group) is not None:
@@ -449,8 +448,9 @@ def main():
         v = torch.tensor([1 if verified else 0], device=device if backend == 'nccl' else 'cpu', dtype=torch.int32)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(int(v.item()))
-    dominant, objs = roofline_objects(layers, per_rank, world, single_launch=((world == 1 and not args.force_exchange)
-                                                                              or D.xrank_exchange(group) is not None))
+    single_route = (world == 1 and not args.force_exchange) or D.xrank_exchange(group) is not None
+    bytes_moved = BYTES_QDQ if single_route else BYTES_PATH
+    dominant, objs = roofline_objects(layers, per_rank, world, single_launch=single_route)
     out = {
         'metric': 'activation elements/sec (and % HBM peak) for per-channel int4 Q/DQ, ResNet-50 b512',
         'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -464,15 +464,29 @@ def main():
                    'parallelism': 'batch-sharded dp%d, %s' % (world, 'per-channel extrema exchanged inside the launch' if (xrank_info or {}).get('used') else 'per-channel stats all_gather'),
                    'exchange': exchange_name, 'launch': launch_form},
         'verified': verified, 'group_status': group_status, 'xrank': None, 'box': box_id(dev_index), 'sustained': sustained,
-        'path_gbs_algorithmic': value / world * BYTES_PATH / 1e9,
-        'path_frac_hbm_peak': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
-        'path_note': '12 B/elem is SURVEY 8(d3)\'s accounting (statistics read + Q/DQ read + write); layers that run '
-                     'the resident single launch move 8 B/elem, so this fraction can exceed what a 12 B path could reach',
+        'path_gbs': value / world * bytes_moved / 1e9,
+        'path_frac_hbm_peak': value / world * bytes_moved / 1e9 / HBM_PEAK_GBS,
+        'path_bytes_moved_per_element': bytes_moved,
+        'path_equiv_12B': value / world * BYTES_PATH / 1e9 / HBM_PEAK_GBS,
+        'path_note': 'path_frac_hbm_peak prices every element of the step at the bytes this route reads + writes (8: one read, one '
+                     'write - the single launch, also through the in-launch exchange; 12 through the collective, whose two passes '
+                     'read x twice): achieved bandwidth per GPU over the whole step, launch gaps included.  path_equiv_12B is SURVEY '
+                     '8(d3)\'s accounting (statistics read + Q/DQ read + write), an equivalence kept for comparison with rounds 1-5, '
+                     'where it was printed as path_frac_hbm_peak: it can exceed what a 12-byte path could reach',
         'roofline': objs[dominant],
         'roofline_other_kernels': {k: v for k, v in objs.items() if k != dominant},
     }
     out['xrank'] = xrank_info       # None: the collective from the start (1 GPU, ranks sharing a GPU, CNNQ_XRANK=0, not verified)
+    shard = None
+    if (world > 1 or args.force_exchange) and not args.no_other_configs:
+        # BASELINE configs 3 / 4 / 5 at the shard (round 6): collective - every rank takes part, rank 0 prints.  The legs run
+        # through the exchange the headline ended on (in-launch: the ranks' sums meet inside the single launch; else the chain
+        # around the collective) and recover like the product does (distributed.xrank_checkpoint per leg)
+        import bench_other
+        shard = bench_other.shard_configs(ops, device, per_rank, group, world, rank, exchange_name)
     if rank == 0:
+        if shard is not None:
+            out['other_configs'] = shard
         if world == 1 and not args.force_exchange:
             if not args.no_other_configs:
                 out['other_configs'] = other_configs(ops, device, args.batch)

@@ -2,10 +2,47 @@
 its optional outputs) on one GPU, each timed like the headline and checked after its timed region.  Imported by bench.py
 only when the default single-GPU run asks for it (`--no-other-configs` skips it)."""
 import math
+import time
 
 import torch
 
+import json
+import os
+
 from bench import HBM_PEAK_GBS, RESNET50_CONV_OUTPUTS, VGG16_CONV_OUTPUTS, laplace_activation, timed_best
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of a configuration's kernels from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, collected in
+    separate rocprofv3 --pmc passes and committed under profiles/; never measured inside a timed run): the newest round's file."""
+    for rnd in ('r06', 'r05'):
+        f = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, name))
+        if os.path.exists(f):
+            try:
+                with open(f) as fh:
+                    rec = json.load(fh)
+                return {'bytes_per_launch': rec.get('bytes_per_launch'), 'box': rec.get('box'), 'source': 'profiles/' + os.path.basename(f)}
+            except (OSError, ValueError):
+                return None
+    return None
+
+
+def leg_object(elems, t, bpe, what, verified=None, moved=None, pmc=None):
+    """One entry of `other_configs`.  roofline.achieved / frac price every element at the bytes the launches of THIS round read
+    and write (`bytes_moved_per_element`: the single-launch forms keep their tile in registers between the statistics and the
+    quantization, one read of x fewer than SURVEY 8(d3) counts) - achieved bandwidth, never above what HBM delivered.
+    SURVEY 8(d3)'s accounting (12 / 16 / 8 bytes per element: statistics read(s) + Q/DQ read + write), the figure earlier rounds
+    called `frac`, is kept next to it as an EQUIVALENCE - the rate a chain of separate passes would need for the same time -
+    under `frac_survey_accounting`."""
+    m = bpe if moved is None else moved
+    gbs = elems * m / t / 1e9
+    r = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+         'bytes_moved_per_element': m, 'traffic': pmc,
+         'survey_bytes_per_element': bpe, 'achieved_survey_accounting': elems * bpe / t / 1e9,
+         'frac_survey_accounting': elems * bpe / t / 1e9 / HBM_PEAK_GBS}
+    return {'workload': what, 'ms': t * 1e3, 'value': elems / t, 'unit': 'elements/s', 'verified': verified, 'roofline': r}
 
 
 def other_configs(ops, device, batch):
@@ -15,18 +52,8 @@ def other_configs(ops, device, batch):
     largest tensor of the set."""
     from cnn_quantization_amd import _lib as Lb
 
-    def obj(elems, t, bpe, what, verified=None, moved=None):
-        """bpe: SURVEY 8(d3)'s algorithmic bytes per element (what `frac` is priced on, comparable across rounds); moved: what
-        the launches of this round actually read + write per element where that is less (the single-launch forms keep their
-        tile in registers between the statistics and the quantization: one read of x fewer)."""
-        gbs = elems * bpe / t / 1e9
-        r = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-             'algorithmic_bytes_per_element': bpe, 'traffic': None}
-        if moved is not None:
-            r['bytes_moved_per_element'] = moved
-            r['achieved_moved'] = elems * moved / t / 1e9
-            r['frac_moved'] = elems * moved / t / 1e9 / HBM_PEAK_GBS
-        return {'workload': what, 'ms': t * 1e3, 'value': elems / t, 'unit': 'elements/s', 'verified': verified, 'roofline': r}
+    def obj(elems, t, bpe, what, verified=None, moved=None, pmc=None):
+        return leg_object(elems, t, bpe, what, verified, moved, pmc if batch == 512 else None)
 
     def codes_consistent(y, codes, qp, C):
         sc, zp, qm = (qp[r].view(1, C, 1, 1) for r in (Lb.QP_SCALE, Lb.QP_ZP, Lb.QP_QMAX))
@@ -93,7 +120,7 @@ def other_configs(ops, device, batch):
            and float(bits3.max()) <= 8 and abs(float(bits3.mean()) - 4.) <= 0.011 + 1. / Cb)      # iq.py:403, in steps of 1/C
     out['config3'] = obj(elems, t, 16, 'ResNet-50 b%d, per-channel int4 + ACIQ laplace + bit allocation, dynamic statistics '
                          '(-c laplace -baa): pass A, merge, bit allocation, then ONE launch for pass B + parameters + Q/DQ '
-                         '(cnnq_pc_aciq_qdq_single)' % batch, bool(ok3), moved=12)
+                         '(cnnq_pc_aciq_qdq_single)' % batch, bool(ok3), moved=12, pmc=pmc_traffic('config3'))
     del ys, c3
     # the same configuration with the bit-allocated integer codes as the STORED result
     # (sum(bits)/8 bytes per position instead of 4 B/elem of dequantized floats); the packing pass alone is timed: its
@@ -143,7 +170,7 @@ def other_configs(ops, device, batch):
                    if lib.cnnq_pc_group_describe(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], d8) == 0 and d8[2] == 3 and d8[5] <= 128)
     out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics; %.0f %% of the elements in one '
                          'launch and one read of x (cnnq_pc_stats_single), the rest in the three-launch chain' % (batch, 100. * one_read / elems),
-                         bool(ok4), moved=8 - 4. * one_read / elems)
+                         bool(ok4), moved=8 - 4. * one_read / elems, pmc=pmc_traffic('config4'))
     del layers, xb, sub
     torch.cuda.empty_cache()
     # ---- config 5
@@ -169,7 +196,134 @@ def other_configs(ops, device, batch):
     out['config5'] = obj(elems, t, 16, 'VGG-16 b%d, mid-tread per-channel W4A4 + ACIQ + bin allocation + entropy (-mtq -me): pass A, '
                          'merge, bin allocation, then ONE launch for pass B + step sizes + quantization + code histogram '
                          '(cnnq_pc_midtread_qdq_single; the two 224x224 layers on 160 KB tiles, one channel on the chip at a time)'
-                         % batch, bool(ok5), moved=12)
+                         % batch, bool(ok5), moved=12, pmc=pmc_traffic('config5'))
+    del vl, y5, c5
+    torch.cuda.empty_cache()
+    return out
+
+
+def shard_configs(ops, device, per_rank, group, world, rank, exchange_name):
+    """BASELINE configs 3 / 4 / 5 at the SHARD of a batch-sharded run (round 6): every rank quantizes / reduces its per_rank
+    samples of each tensor, the statistics are the GLOBAL batch's.  COLLECTIVE: every rank of the job calls it (also a forced
+    1-rank exchange).  With the in-launch exchange in force the ranks' sums meet inside the single launch
+    (cnnq_pc_aciq_fused_xrank / _midtread_fused_xrank / _stats_xrank: 12 / 12 / 4 bytes per element moved); otherwise the chain runs
+    around the collective (16 / 16 / 8).  Each leg is timed like the headline (barrier + synchronise on both sides, max over the
+    ranks, best of 3) and followed by distributed.xrank_checkpoint: a leg during which a wait for a peer expired is timed again
+    through the collective, on every rank.  Returns the entries, keyed config3 / config4 / config5."""
+    import torch.distributed as dist
+    from cnn_quantization_amd import _lib as Lb, distributed as D
+
+    def barrier():
+        if world > 1:
+            dist.barrier(group=group)
+        torch.cuda.synchronize()
+
+    def timed(fn, reps=3):
+        fn()
+        best = None
+        for _ in range(reps):
+            barrier()
+            t0 = time.perf_counter()
+            fn()
+            barrier()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        if world > 1:
+            on_dev = dist.get_backend(group) == 'nccl'
+            tt = torch.tensor([best], dtype=torch.float64, device=device if on_dev else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+            best = float(tt[0].item())
+        return best
+
+    def leg(fn, reps=3):
+        """(seconds, in_launch): the leg through whatever exchange is in force; again through the collective if a wait expired"""
+        in_launch = D.xrank_exchange(group) is not None
+        t = timed(fn, reps)
+        if in_launch and not D.xrank_checkpoint(group):
+            in_launch = False
+            t = timed(fn, reps)
+        return t, in_launch
+
+    out = {}
+    layers, seed = [], 100 + 1000 * rank
+    for (C, hw, half, count) in RESNET50_CONV_OUTPUTS:
+        for _ in range(count):
+            layers.append((laplace_activation((per_rank, C, hw, hw), seed, device), half))
+            seed += 1
+    elems = sum(x.numel() for x, _ in layers) * world        # the job's elements (shards are equal up to one sample)
+    ys = [torch.empty_like(x) for x, _ in layers]
+    big = max(range(len(layers)), key=lambda i: layers[i][0].numel())
+    xb, hb = layers[big]
+    Cb = xb.shape[1]
+    # ---- config 3
+    t, inl = leg(lambda: [ops.act_qdq_per_channel(x, 4, positive=half, clip='laplace', bit_alloc=True, group=group, out=y)
+                          for (x, half), y in zip(layers, ys)])
+    y3, p3 = ops.act_qdq_per_channel(xb, 4, positive=hb, clip='laplace', bit_alloc=True, group=group, want_parts=True)
+    bits3 = p3['diag'][Lb.DIAG_BITS]
+    sc, zp, qm = (p3['qp'][r].view(1, Cb, 1, 1) for r in (Lb.QP_SCALE, Lb.QP_ZP, Lb.QP_QMAX))
+    codes = torch.round(y3 / sc + zp)
+    ok3 = (bool(torch.equal(y3, ys[big])) and float(codes.min()) >= 0 and bool((codes <= qm).all()) and bool(torch.equal((codes - zp) * sc, y3))
+           and abs(float(bits3.mean()) - 4.) <= 0.011 + 1. / Cb and bool(torch.isfinite(p3['stats'][Lb.STAT_B]).all()))
+    del codes
+    out['config3'] = leg_object(elems, t, 16, 'ResNet-50 b%d sharded %d ways (%d samples per GPU), per-channel int4 + ACIQ laplace + bit '
+                                'allocation (-c laplace -baa): pass A, all_gather of the moment records, merge, bit allocation, %s'
+                                % (per_rank * world, world, per_rank, 'ONE launch for pass B + the ranks\' sums through the windows + '
+                                   'parameters + Q/DQ (cnnq_pc_aciq_fused_xrank)' if inl else 'pass B, all_gather, merge, parameters, Q/DQ (the chain)'),
+                                bool(ok3), moved=12 if inl else 16)
+    out['config3']['exchange'] = 'in-launch (hipIpc windows) for the sums of |x - mean|, collective for the moment records' if inl else exchange_name
+    del ys, y3
+    # ---- config 4
+    t, inl = leg(lambda: [ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True,
+                                       need_relu=True, group=group) for x, _ in layers])
+    st4, mom4 = ops.pc_stats(xb, xb.shape[0], Cb, xb.shape[2] * xb.shape[3], need_b=True, need_kurt=True, need_relu=True, group=group)
+    mx, mn = xb.amax(dim=(0, 2, 3)), xb.amin(dim=(0, 2, 3))
+    if world > 1:
+        on_dev = dist.get_backend(group) == 'nccl'
+        mxr, mnr = (mx, mn) if on_dev else (mx.cpu(), mn.cpu())
+        dist.all_reduce(mxr, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(mnr, op=dist.ReduceOp.MIN, group=group)
+        mx, mn = mxr.to(device), mnr.to(device)
+    ok4 = (bool(torch.equal(st4[Lb.STAT_MAX], mx)) and bool(torch.equal(st4[Lb.STAT_MIN], mn)) and bool(torch.isfinite(st4).all())
+           and float(mom4[Lb.MOM_COUNT][0]) == float(xb.shape[0] * world * xb.shape[2] * xb.shape[3]))
+    import ctypes
+    lib, d8 = Lb.load(), (ctypes.c_int32 * 8)()
+    one_read = sum(x.numel() for x, _ in layers
+                   if lib.cnnq_pc_group_describe(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], d8) == 0 and d8[2] == 3 and d8[5] <= 128)
+    frac1 = one_read * world / elems if inl else 0.
+    out['config4'] = leg_object(elems, t, 8, 'ResNet-50 b%d sharded %d ways, -sm collect: the seven per-channel statistics of the GLOBAL '
+                                'batch on every rank; %s' % (per_rank * world, world, ('%.0f %% of the elements in one launch and one read of '
+                                                             'x with both phases\' folds exchanged inside it (cnnq_pc_stats_xrank), the rest in the '
+                                                             'chain\'s passes around the same window slots' % (100. * frac1)) if inl
+                                                             else 'two passes around two all_gathers of the fp64 records'),
+                                bool(ok4), moved=8 - 4. * frac1)
+    out['config4']['exchange'] = 'in-launch (hipIpc windows)' if inl else exchange_name
+    del layers, xb
+    torch.cuda.empty_cache()
+    # ---- config 5
+    vl, seed = [], 500 + 1000 * rank
+    for (C, hw, count) in VGG16_CONV_OUTPUTS:
+        for _ in range(count):
+            vl.append(laplace_activation((per_rank, C, hw, hw), seed, device))
+            seed += 1
+    elems = sum(x.numel() for x in vl) * world
+    t, inl = leg(lambda: [ops.mid_tread_qdq(x, 4, clip=True, sym=False, group=group, want_entropy=True) for x in vl], reps=2)
+    xv = vl[2]
+    y5, e5, p5 = ops.mid_tread_qdq(xv, 4, clip=True, sym=False, group=group, want_entropy=True, want_parts=True)
+    Cv = xv.shape[1]
+    d5, lo5, hi5 = (p5['mt'][r].view(1, Cv, 1, 1) for r in (Lb.MT_DELTA, Lb.MT_CMIN, Lb.MT_CMAX))
+    # y = code * delta with the code an integer or exactly a clamp bound (iq.py:202-224): every y inside [c_min, c_max] * delta,
+    # every count accounted for (the all-reduced table holds the GLOBAL batch's codes), a finite entropy
+    c5 = y5 / d5
+    ok5 = (bool((c5 >= lo5 - 1e-3).all()) and bool((c5 <= hi5 + 1e-3).all()) and math.isfinite(float(e5))
+           and bool(((c5 - torch.round(c5)).abs() < 1e-3).float().mean() > 0.9)
+           and int(p5['hist'][:-1].sum()) == xv.numel() * world)
+    out['config5'] = leg_object(elems, t, 16, 'VGG-16 b%d sharded %d ways, mid-tread per-channel + ACIQ + bin allocation + entropy of the '
+                                'GLOBAL batch\'s codes (-mtq -me): pass A, all_gather, merge, bin allocation, %s, all-reduce of the code '
+                                'counts' % (per_rank * world, world, 'ONE launch for pass B + the ranks\' sums through the windows + step sizes + '
+                                            'quantization + code histogram (cnnq_pc_midtread_fused_xrank)' if inl
+                                            else 'pass B, all_gather, merge, parameters, quantization (the chain)'),
+                                bool(ok5), moved=12 if inl else 16)
+    out['config5']['exchange'] = 'in-launch (hipIpc windows) for the sums of |x - mean|, collective for the moment records and the code counts' if inl else exchange_name
     del vl, y5, c5
     torch.cuda.empty_cache()
     return out

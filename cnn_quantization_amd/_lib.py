@@ -101,10 +101,10 @@ SIGNATURES = {
     'cnnq_pc_aciq_qdq_single': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P,
                                      ctypes.c_uint32, _P]),
     'cnnq_pc_aciq_qdq_auto': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P]),
-    'cnnq_pc_aciq_fused_xrank': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P, ctypes.c_size_t, _P, _P,
+    'cnnq_pc_aciq_fused_xrank': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P, _P,
                                       ctypes.POINTER(XRankCtx), ctypes.c_uint32, _P]),
-    'cnnq_pc_midtread_fused_xrank': (_I, [_P, _P, _L, _L, _L, ctypes.c_double, _I, _P, _I, _P, _P, _P, _P, ctypes.c_size_t, _P,
-                                          _P, ctypes.POINTER(XRankCtx), ctypes.c_uint32, _P]),
+    'cnnq_pc_midtread_fused_xrank': (_I, [_P, _P, _L, _L, _L, ctypes.c_double, _I, _P, _I, _P, _P, ctypes.c_size_t, _P, _P, _P, _P,
+                                          ctypes.POINTER(XRankCtx), ctypes.c_uint32, _P]),
     'cnnq_pc_stats_xrank': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, ctypes.c_size_t, _P, _P, ctypes.POINTER(XRankCtx), ctypes.c_uint32,
                                  _P]),
     'cnnq_pc_weight_correct': (_I, [_P, _L, _L, _P, _P, _I, _I, _P]),
@@ -118,6 +118,7 @@ SIGNATURES = {
     'cnnq_pc_midtread_qdq_single': (_I, [_P, _P, _L, _L, _L, ctypes.c_double, _I, _P, _I, _P, _P, ctypes.c_size_t, _P, _P, _P,
                                          ctypes.c_uint32, _P]),
     'cnnq_midtread_entropy': (_I, [_P, _P, _L, _L, _P, _P]),
+    'cnnq_midtread_entropy_count': (_I, [_P, _P, _L, _P, _P, _P]),
     'cnnq_entropy': (_I, [_P, _I, _P, _P]),
     'cnnq_pt_setup': (_I, [ctypes.POINTER(_F), _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'cnnq_pt_qdq': (_I, [_P, _P, _L, _P, _P, _P]),

@@ -236,7 +236,7 @@ __device__ __forceinline__ void mt_count(float t, float lo, float hi, bool lo_ni
     const unsigned kk = (unsigned)(k - wstart);
     const bool inwin = ((float)k == t) && kk < (unsigned)MT_W;
     const bool at_hi = hi_ni && t == hi;
-    const bool at_lo = lo_ni && t == lo;
+    const bool at_lo = lo_ni && t == lo && !at_hi;      // (c_min == c_max, a constant channel: ONE value, counted once)
     nhi += at_hi ? 1u : 0u;
     nlo += at_lo ? 1u : 0u;
     if (inwin) {
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         for (int m = 32; m >= 1; m >>= 1) tsum += shfl_xor_d(tsum, m);
         if (tid == 0) {
             // the batch is sharded: the ranks' sums, added in rank order (cnnq_xrank.hip.h); NaN when a peer never came
-            if constexpr (XR) (void)xr_merge_sum(xr, c, member == 0, tsum);
+            if constexpr (XR) (void)xr_merge_sum(xr, xr.slot0 + c, member == 0, tsum);
             sh_tot = tsum;
         }
     }
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(TPB, (fused_group_waves<K, OUT, MODE, XR>())) 
         // sh_sum[tid] back below: no barrier.)
         for (int ch = tid; ch < nch; ch += TPB) {
             double csum = sh_sum[ch];
-            (void)xr_merge_sum(xr, b.c0 + ch, rb.member == 0, csum);
+            (void)xr_merge_sum(xr, xr.slot0 + b.c0 + ch, rb.member == 0, csum);
             sh_sum[ch] = csum;
         }
     }

@@ -782,6 +782,8 @@ static int xrank_launch(const float* x, float* y, int64_t N, int64_t C, int64_t 
     xr.zero_c = zero_c;
     xr.cdev = seq_dev ? seq_dev + 4 : nullptr;            // round 6: the launches keep the slot counts themselves
     xr.nslots = (int)C;
+    xr.slot0 = 0;
+    xr.no_prologue = 0;
     xr.cmax = cmax;
     xr.status = status;
     xr.timeout = timeout_ticks;
@@ -980,11 +982,12 @@ int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_
     return cnnq_pc_aciq_qdq(x, y, N, C, HW, cfg, ws, qp, diag, stream);
 }
 
-// ---- round 6: configs 3 / 5 / 4 of a batch shard with the cross-rank exchange INSIDE the single launch --------------------------
-// (cnnq_xrank.hip.h; the same windows, numbering and status word as config 2's cnnq_pc_minmax_qdq_xrank_seq / _dev)
-static int xr_from_ctx(const cnnq_xrank_ctx* xc, int64_t nslots, XRank* xr) {
+// ---- round 6: configs 3 / 5 / 4 of a batch shard with the cross-rank exchange INSIDE the launches --------------------------------
+// (cnnq_xrank.hip.h; the same windows, numbering and status word as config 2's cnnq_pc_minmax_qdq_xrank_seq / _dev).  One host
+// call per tensor, ONE launch number, no collective: every statistic of the global batch travels through the windows.
+static int xr_from_ctx(const cnnq_xrank_ctx* xc, int64_t C, XRank* xr) {
     if (!xc || !xc->windows || !xc->status || !xc->seq_dev || ((uintptr_t)xc->seq_dev & 3)) return CNNQ_EINVAL;
-    if (xc->world <= 0 || xc->rank < 0 || xc->rank >= xc->world || xc->timeout_ticks <= 0 || nslots <= 0 || nslots > xc->cmax) return CNNQ_EINVAL;
+    if (xc->world <= 0 || xc->rank < 0 || xc->rank >= xc->world || xc->timeout_ticks <= 0 || C <= 0 || C * ST_XW > xc->cmax) return CNNQ_EINVAL;
     xr->windows = xc->windows;
     xr->rank = xc->rank;
     xr->world = xc->world;
@@ -993,58 +996,52 @@ static int xr_from_ctx(const cnnq_xrank_ctx* xc, int64_t nslots, XRank* xr) {
     xr->seq_mirror = xc->seq ? xc->seq_dev : nullptr;
     xr->zero_c = 0;
     xr->cdev = xc->seq_dev + 4;
-    xr->nslots = (int)nslots;
+    xr->nslots = (int)(C * ST_XW);                       // the sums layout: eight words per channel
+    xr->slot0 = (int)(C * (ST_XW_COUNT + 1));            // word 6: sum |x - mean|
+    xr->no_prologue = 0;
     xr->cmax = xc->cmax;
     xr->status = xc->status;
     xr->timeout = xc->timeout_ticks;
     return 0;
 }
 // device numbering: the slots of the launch zeroed and the number advanced behind it (host numbering: the launch after next cleans up)
-static int xr_finish_ctx(const cnnq_xrank_ctx* xc, int64_t nslots, hipStream_t st) {
+static int xr_finish_ctx(const cnnq_xrank_ctx* xc, int64_t C, hipStream_t st) {
     if (xc->seq) return 0;
-    hipLaunchKernelGGL(k_xr_finish, dim3(1), dim3(1024), 0, st, xc->windows, xc->rank, xc->world, xc->cmax, (int)nslots, 0u, xc->seq_dev,
+    hipLaunchKernelGGL(k_xr_finish, dim3(1), dim3(1024), 0, st, xc->windows, xc->rank, xc->world, xc->cmax, (int)(C * ST_XW), 0u, xc->seq_dev,
                        xc->seq_dev + 4);
     return launch_status();
 }
-static int xr_exchange_sums(double* vals, int64_t C, int nw, int w0, int pair0, int prologue, const XRank& xr, hipStream_t st) {
-    hipLaunchKernelGGL(k_xr_exchange_sums, dim3((unsigned)((nw * C + TPB - 1) / TPB)), dim3(TPB), 0, st, vals, (int)C, nw, w0, pair0, prologue, xr);
+// pass A of a shard made global: k_moments -> k_xr_moments (the first kernel of the launch number: it runs the prologue)
+static int xr_pass_a(const float* x, int64_t N, int64_t C, int64_t HW, int need_relu, double* part, int G, const XRank& xr, double* mom,
+                     float* stats, void* stream) {
+    int rc = cnnq_pc_moments(x, N, C, HW, need_relu, part, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_xr_moments, dim3((unsigned)((C + XS_CPB - 1) / XS_CPB)), dim3(TPB), 0, (hipStream_t)stream, part, G, (int)C, need_relu, xr, mom, stats);
     return launch_status();
 }
-// stats[B][c] = sum / count (the fallback of the sharded fused kernels: the row their last launch writes)
-__global__ void __launch_bounds__(TPB) k_b_row(const double* __restrict__ sums, const double* __restrict__ count, float* __restrict__ stats, const int C) {
-    const int c = (int)blockIdx.x * TPB + (int)threadIdx.x;
-    if (c < C) stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sums[c] / count[c]);
-}
-// the rank's merged moment record -> the exchange words of k_stats_flat<XR> (pair, sum, sumsq, relu sums, count) and back
-__global__ void __launch_bounds__(TPB) k_mom_words(double* __restrict__ mom, double* __restrict__ words, const int C, const int back) {
-    const int c = (int)blockIdx.x * TPB + (int)threadIdx.x;
-    if (c >= C) return;
-    const int rows[5] = {CNNQ_MOM_SUM, CNNQ_MOM_SUMSQ, CNNQ_MOM_SUM_RELU, CNNQ_MOM_SUMSQ_RELU, CNNQ_MOM_COUNT};
-    unsigned long long* w0 = reinterpret_cast<unsigned long long*>(words);
-    if (!back) {
-        float a = (float)mom[(size_t)CNNQ_MOM_MIN * C + c], b = (float)mom[(size_t)CNNQ_MOM_MAX * C + c];
-        if (a != a || b != b) { a = NAN; b = NAN; }
-        w0[c] = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-        for (int i = 0; i < 5; ++i) words[(size_t)(i + 1) * C + c] = mom[(size_t)rows[i] * C + c];
-    } else {
-        mom[(size_t)CNNQ_MOM_MIN * C + c] = (double)__uint_as_float((unsigned)(w0[c] & 0xffffffffull));
-        mom[(size_t)CNNQ_MOM_MAX * C + c] = (double)__uint_as_float((unsigned)(w0[c] >> 32));
-        for (int i = 0; i < 5; ++i) mom[(size_t)rows[i] * C + c] = words[(size_t)(i + 1) * C + c];
-    }
+// pass B of a shard through the chain's kernel, its sums made global: k_absdev -> k_xr_devsums (rows B / KURT of stats)
+static int xr_pass_b(const float* x, int64_t N, int64_t C, int64_t HW, int nw, int want_kurt, double* part2, int G, const double* mom,
+                     XRank xr, float* stats, void* stream) {
+    int rc = cnnq_pc_absdev(x, N, C, HW, stats, want_kurt, part2, stream);
+    if (rc) return rc;
+    xr.no_prologue = 1;
+    hipLaunchKernelGGL(k_xr_devsums, dim3((unsigned)((C + 31) / 32)), dim3(TPB), 0, (hipStream_t)stream, part2, G, (int)C, nw, want_kurt,
+                       mom + (size_t)CNNQ_MOM_COUNT * C, xr, stats);
+    return launch_status();
 }
 
-// Config 3 of a batch shard: x is this rank's shard; stats holds rows MIN, MAX, MEAN, STD of the GLOBAL batch (pass A's records
-// merged over the ranks by the caller: cnnq_pc_moments -> cnnq_pc_combine -> all_gather -> cnnq_pc_combine), count [C] the global
-// batch's elements per channel (row COUNT of that merged record, in device memory).  (bit allocation) -> ONE launch: the tile's sum |x - mean|, the local slot meeting, the ranks'
-// sums exchanged through the windows and added in rank order, parameters, Q/DQ out of the registers.  Row B of stats, qp and
-// diag are written (the same on every rank).  A shard without a single-launch plan runs pass B -> exchange -> parameters ->
-// Q/DQ around the same slots (ws: cnnq_pc_aciq_workspace bytes), so the ranks need not agree on their plans; either way the
-// call consumes ONE launch number.  CNNQ_ENOTSUP (nothing enqueued, no number consumed) only for configurations
-// cnnq_pc_aciq_qdq_single refuses too.
-int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, float* stats,
-                             const double* count, void* ws, void* gws, size_t gws_bytes, float* qp, float* diag, const cnnq_xrank_ctx* xc,
-                             unsigned flags, void* stream) {
-    if (!x || !y || !cfg || !ws || !stats || !qp || ((uintptr_t)ws & 7) || !count || ((uintptr_t)count & 7)) return CNNQ_EINVAL;
+// Config 3 of a batch shard (Laplace clipping, optional bit allocation on the 'gaus' prior), the whole pipeline: k_moments ->
+// k_xr_moments (the six words of the pass-A record through the windows: the table of the GLOBAL batch on every rank) ->
+// (k_bitalloc) -> ONE launch for the tile's sum |x - mean|, the local slot meeting, the ranks' sums through the windows, added in
+// rank order, the parameters and the Q/DQ out of the registers - the four launches of one GPU, x read twice (12 bytes per
+// element), no collective.  stats [CNNQ_NSTAT][C], mom [CNNQ_NMOM][C] (fp64), qp, diag: outputs, the same on every rank.  A
+// shard without a single-launch plan runs k_absdev -> k_xr_devsums -> k_params -> k_qdq around the same slots, so the ranks need
+// not agree on their plans; either way the call consumes ONE launch number.  ws: cnnq_pc_aciq_workspace bytes.  CNNQ_ENOTSUP
+// (nothing enqueued, no number consumed) only for configurations cnnq_pc_aciq_qdq_single refuses too.
+int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws, void* gws,
+                             size_t gws_bytes, float* stats, double* mom, float* qp, float* diag, const cnnq_xrank_ctx* xc, unsigned flags,
+                             void* stream) {
+    if (!x || !y || !cfg || !ws || !stats || !mom || !qp || ((uintptr_t)ws & 7) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
     if (cfg->num_bits < 1 || cfg->num_bits > 8 || (gws && ((uintptr_t)gws & 127))) return CNNQ_EINVAL;
     const bool use_ba = cfg->bit_alloc && cfg->num_bits <= 4;
     if (use_ba && !diag) return CNNQ_EINVAL;
@@ -1055,6 +1052,9 @@ int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(ws);
+    rc = xr_pass_a(x, N, C, HW, 0, part, G, xr, mom, stats, stream);
+    if (rc) return rc;
     GPlan gp;
     const bool single = gws && plan_sums(N, C, HW, al16(x) && al16(y), &gp, 1) == 0 && gp.ws_bytes <= gws_bytes &&
                         (size_t)gp.ngroups * gp.gstride * 8 <= GRP_WS_SLOT_BYTES && !(gp.KL && !(gp.flat && gp.K == 32 && gp.KL == 8));
@@ -1073,19 +1073,12 @@ int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int
         aa.qp = qp;
         aa.diag = diag;
         aa.cfg = *cfg;
-        aa.count_dev = count;
-        rc = launch_fused(0, x, y, gp, aa, gws, flags & 3u, st, 0, XOut{}, &xr);
+        aa.count_dev = mom + (size_t)CNNQ_MOM_COUNT * C;
+        XRank xb = xr;
+        xb.no_prologue = 1;
+        rc = launch_fused(0, x, y, gp, aa, gws, flags & 3u, st, 0, XOut{}, &xb);
     } else {
-        // pass B of this shard -> its sums -> the ranks' sums through the windows -> b -> the chain's parameters and Q/DQ
-        double* part2 = reinterpret_cast<double*>(ws);
-        double* sums = part2 + (size_t)G * CNNQ_NDEV * C;
-        rc = cnnq_pc_absdev(x, N, C, HW, stats, 0, part2, stream);
-        if (!rc) rc = cnnq_pc_combine_dev(part2, G, C, nullptr, 0, sums, nullptr, stream);
-        if (!rc) rc = xr_exchange_sums(sums, C, 1, 0, 0, 1, xr, st);
-        if (!rc) {
-            hipLaunchKernelGGL(k_b_row, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, st, sums, count, stats, (int)C);
-            rc = launch_status();
-        }
+        rc = xr_pass_b(x, N, C, HW, 1, 0, part, G, mom, xr, stats, stream);
         if (!rc) rc = cnnq_pc_params(stats, C, cfg, qp, diag, stream);
         if (!rc) rc = cnnq_pc_qdq(x, y, N, C, HW, qp, nullptr, nullptr, 0, stream);
     }
@@ -1094,12 +1087,12 @@ int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int
 }
 
 // Config 5 of a batch shard (mid-tread, clip = 1): as above with the bin allocation (k_mt_params<GUESS> on the global std) in
-// front and MODE 1 of the fused kernels; mt rows DELTA / CMIN / CMAX and stats row B are written; hist (optional,
-// CNNQ_MT_HIST_WORDS(C), zeroed here) counts THIS rank's codes - sum it over the ranks before cnnq_midtread_entropy.
+// place of the bit allocation and MODE 1 of the fused kernels; mt [CNNQ_NMT][C] out; hist (optional, CNNQ_MT_HIST_WORDS(C),
+// zeroed here) counts THIS rank's codes - sum it over the ranks, then cnnq_midtread_entropy_count with mom's COUNT row.
 int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, double target, int sym, const double* tables,
-                                 int ntab, float* stats, const double* count, void* ws, void* gws, size_t gws_bytes, float* mt, uint64_t* hist,
+                                 int ntab, void* ws, void* gws, size_t gws_bytes, float* stats, double* mom, float* mt, uint64_t* hist,
                                  const cnnq_xrank_ctx* xc, unsigned flags, void* stream) {
-    if (!x || !y || !tables || ntab < 2 || !ws || !stats || !mt || ((uintptr_t)ws & 7) || ((uintptr_t)hist & 7) || !count || ((uintptr_t)count & 7)) return CNNQ_EINVAL;
+    if (!x || !y || !tables || ntab < 2 || !ws || !stats || !mom || !mt || ((uintptr_t)ws & 7) || ((uintptr_t)hist & 7) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
     if (gws && ((uintptr_t)gws & 127)) return CNNQ_EINVAL;
     XRank xr;
     int rc = xr_from_ctx(xc, C, &xr);
@@ -1108,6 +1101,9 @@ int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C,
     if (G <= 0) return G ? G : CNNQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (hist && hipMemsetAsync(hist, 0, (size_t)CNNQ_MT_HIST_WORDS(C) * sizeof(uint64_t), st) != hipSuccess) return launch_status();
+    double* part = reinterpret_cast<double*>(ws);
+    rc = xr_pass_a(x, N, C, HW, 0, part, G, xr, mom, stats, stream);
+    if (rc) return rc;
     GPlan gp;
     const bool single = gws && plan_sums(N, C, HW, al16(x) && al16(y), &gp, 1) == 0 && gp.ws_bytes <= gws_bytes &&
                         (size_t)gp.ngroups * gp.gstride * 8 <= GRP_WS_SLOT_BYTES && (gp.flat || gp.v.A == 1) &&
@@ -1119,21 +1115,15 @@ int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C,
         if (rc) return rc;
         FusedArgs fa = {};
         fa.stats = stats;
-        fa.count_dev = count;
+        fa.count_dev = mom + (size_t)CNNQ_MOM_COUNT * C;
         fa.mt = mt;
         fa.mcfg = mcfg;
         fa.hist = reinterpret_cast<unsigned long long*>(hist);
-        rc = launch_fused(1, x, y, gp, fa, gws, flags & 3u, st, hist ? 1 : 0, XOut{}, &xr);
+        XRank xb = xr;
+        xb.no_prologue = 1;
+        rc = launch_fused(1, x, y, gp, fa, gws, flags & 3u, st, hist ? 1 : 0, XOut{}, &xb);
     } else {
-        double* part2 = reinterpret_cast<double*>(ws);
-        double* sums = part2 + (size_t)G * CNNQ_NDEV * C;
-        rc = cnnq_pc_absdev(x, N, C, HW, stats, 0, part2, stream);
-        if (!rc) rc = cnnq_pc_combine_dev(part2, G, C, nullptr, 0, sums, nullptr, stream);
-        if (!rc) rc = xr_exchange_sums(sums, C, 1, 0, 0, 1, xr, st);
-        if (!rc) {
-            hipLaunchKernelGGL(k_b_row, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), 0, st, sums, count, stats, (int)C);
-            rc = launch_status();
-        }
+        rc = xr_pass_b(x, N, C, HW, 1, 0, part, G, mom, xr, stats, stream);
         if (!rc) rc = cnnq_pc_midtread_params(stats, C, target, 1, sym, tables, ntab, mt, stream);
         if (!rc) rc = cnnq_pc_midtread_qdq(x, y, N, C, HW, mt, 1, nullptr, hist, stream);
     }
@@ -1142,15 +1132,15 @@ int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C,
 }
 
 // Config 4 of a batch shard: the seven statistics of the GLOBAL batch from ONE read of this rank's shard (k_stats_flat with the
-// cross-rank stage: both phases' folds exchanged inside the launch; 8 slots per channel, C * 8 <= cmax).  stats [CNNQ_NSTAT][C]
-// and mom [CNNQ_NMOM][C] (may be NULL) are the global batch's on every rank.  A shard without a flat-tile plan (or with more
-// than 128 tiles per channel) runs the chain's passes around the same slots (ws: cnnq_pc_stats_workspace + 16 C doubles).  ONE
-// launch number per call.
+// cross-rank stage: both phases' folds exchanged inside the launch; eight slots per channel, 8 C <= cmax).  stats [CNNQ_NSTAT][C]
+// and mom [CNNQ_NMOM][C] are the global batch's on every rank.  A shard without a flat-tile plan (or with more than 128 tiles per
+// channel) runs the chain's two passes with their records made global by k_xr_moments / k_xr_devsums around the same slots -
+// four launches, no collective (ws: cnnq_pc_stats_workspace bytes).  ONE launch number per call.
 int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
                         size_t gws_bytes, double* mom, float* stats, const cnnq_xrank_ctx* xc, unsigned flags, void* stream) {
-    if (!x || !stats || !ws || ((uintptr_t)ws & 7) || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
+    if (!x || !stats || !mom || !ws || ((uintptr_t)ws & 7) || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
     XRank xr;
-    int rc = xr_from_ctx(xc, C * ST_XW, &xr);
+    int rc = xr_from_ctx(xc, C, &xr);
     if (rc) return rc;
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
@@ -1171,30 +1161,11 @@ int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int ne
     } else {
         double* part = reinterpret_cast<double*>(ws);
         double* part2 = part + (size_t)G * CNNQ_NMOM * C;
-        double* gmom = part2 + (size_t)G * CNNQ_NDEV * C;      // [NMOM][C], then the exchange words [8][C] (6 of phase 1, 2 of phase 2)
-        double* words = gmom + (size_t)CNNQ_NMOM * C;
-        const dim3 cg((unsigned)((C + TPB - 1) / TPB)), cb(TPB);
-        rc = cnnq_pc_moments(x, N, C, HW, need_relu, part, stream);
-        if (!rc) rc = cnnq_pc_combine(part, G, C, need_relu, gmom, nullptr, stream);
-        if (!rc) { hipLaunchKernelGGL(k_mom_words, cg, cb, 0, st, gmom, words, (int)C, 0); rc = launch_status(); }
-        // (without the relu sums words 3, 4 are skipped on every rank: k_stats_flat<RELU = false> does not exchange them either)
-        if (!rc && need_relu) rc = xr_exchange_sums(words, C, 6, 0, 1, 1, xr, st);
-        if (!rc && !need_relu) {
-            rc = xr_exchange_sums(words, C, 3, 0, 1, 1, xr, st);
-            if (!rc) rc = xr_exchange_sums(words + (size_t)ST_XW_COUNT * C, C, 1, ST_XW_COUNT, 0, 0, xr, st);
-        }
-        if (!rc) { hipLaunchKernelGGL(k_mom_words, cg, cb, 0, st, gmom, words, (int)C, 1); rc = launch_status(); }
-        if (!rc) rc = cnnq_pc_combine(gmom, 1, C, need_relu, mom, stats, stream);
-        if (!rc && need_dev) {
-            double* dev = words + (size_t)(ST_XW_COUNT + 1) * C;
-            rc = cnnq_pc_absdev(x, N, C, HW, stats, need_kurt, part2, stream);
-            if (!rc) rc = cnnq_pc_combine_dev(part2, G, C, nullptr, need_kurt, dev, nullptr, stream);
-            if (!rc) rc = xr_exchange_sums(dev, C, 2, ST_XW_COUNT + 1, 0, 0, xr, st);
-            if (!rc) rc = cnnq_pc_combine_dev(dev, 1, C, gmom, need_kurt, nullptr, stats, stream);
-        }
+        rc = xr_pass_a(x, N, C, HW, need_relu ? 1 : 0, part, G, xr, mom, stats, stream);
+        if (!rc && need_dev) rc = xr_pass_b(x, N, C, HW, 2, need_kurt ? 1 : 0, part2, G, mom, xr, stats, stream);
     }
     if (rc) return rc;
-    return xr_finish_ctx(xc, C * ST_XW, st);
+    return xr_finish_ctx(xc, C, st);
 }
 
 int cnnq_pc_weight_correct(float* wq, int64_t C, int64_t HW, const float* stats_w, const float* stats_q, int vcorr,
@@ -1365,6 +1336,15 @@ int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int6
     if (!hist || !mt || !out || C <= 0 || total <= 0) return CNNQ_EINVAL;
     hipLaunchKernelGGL(k_mt_entropy, dim3(1), dim3(PTPB), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned long long*>(hist), mt, (int)C, (double)total, out);
+    return launch_status();
+}
+
+// the same with the element count taken from device memory: count[0] elements per channel (row CNNQ_MOM_COUNT of the merged
+// moment record of a batch-sharded run, whose global batch size only the device knows exactly - shards may differ by a sample)
+int cnnq_midtread_entropy_count(const uint64_t* hist, const float* mt, int64_t C, const double* count, float* out, void* stream) {
+    if (!hist || !mt || !out || !count || ((uintptr_t)count & 7) || C <= 0) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_mt_entropy, dim3(1), dim3(PTPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(hist), mt, (int)C, 0., out, count);
     return launch_status();
 }
 

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
                             // SALU instructions of the kernel without histogram.
                             const bool z = (t == 0.f);
                             const bool at_hi = CLIP && hi_ni[j][a] && t == hi[j][a];
-                            const bool at_lo = CLIP && lo_ni[j][a] && t == lo[j][a];
+                            const bool at_lo = CLIP && lo_ni[j][a] && t == lo[j][a] && !at_hi;   // (c_min == c_max, a constant channel: ONE value, counted once - round 6)
                             nzero += z ? 1u : 0u;
                             if constexpr (CLIP) { nhi[j][a] += at_hi ? 1u : 0u; nlo[j][a] += at_lo ? 1u : 0u; }
                             const int k = (int)t;                       // saturating; NaN -> 0
@@ -295,13 +295,15 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
 
 // entropy over integer bins + the per-channel non-integer clamp values (equal values merged,
 // as torch.unique would, utils/entropy.py:10)
+// count_dev (may be null): the elements per CHANNEL of the tensor the codes were counted over, in device memory (row COUNT of a
+// merged moment record: a batch-sharded run knows the global batch's size on the device, not on the host) - total = count * C
 __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* __restrict__ hist,
                                                      const float* __restrict__ mt, int C, double total,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const double* __restrict__ count_dev = nullptr) {
     __shared__ double sh[PTPB / 64];
     __shared__ unsigned long long lrep[MT_W];
     const int tid = threadIdx.x;
-    const float ftotal = (float)total;
+    const float ftotal = (float)(count_dev ? count_dev[0] * (double)C : total);
     double e = 0.;
     // the window bins live in MT_GR replica tables: fold them (bin i of the window is code wstart + i)
     const unsigned long long* rep = hist + MT_NB + 2 + 2 * (size_t)C;

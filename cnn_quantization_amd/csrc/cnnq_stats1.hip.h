@@ -872,4 +872,99 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         for (int m = tid; m < Gs * NPK; m += TPB) __hip_atomic_store(lines + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- round 6: the chain's partial records made GLOBAL through the windows, no collective -----------------------------------------
+// k_xr_moments behind k_moments: merges the G pass-A records of this shard per channel, exchanges the six words of the sums
+// layout (cnnq_xrank.hip.h) with the other ranks - every rank pushes its own and adds the W ranks' words in rank order - and
+// writes the table rows and the merged moment record of the GLOBAL batch (k_combine's formulas).  The first kernel of its launch
+// number: its workgroups share the prologue (xr_prologue_all).
+constexpr int XS_CPB = 2;      // channels per workgroup
+__global__ void __launch_bounds__(TPB) k_xr_moments(const double* __restrict__ part, const int G, const int C, const int has_relu,
+                                                    const XRank xr, double* __restrict__ mom, float* __restrict__ stats) {
+    xr_prologue_all(xr);
+    __shared__ unsigned long long sh_w[XS_CPB][8];
+    // 2 channels x 8 words x 16 lanes: lane j merges records j, j + 16, ... (at most four of them), the sixteen lanes fold by a
+    // fixed xor tree
+    const int tid = threadIdx.x, j = tid & 15, w = (tid >> 4) & 7, cl = tid >> 7;
+    const int c = (int)blockIdx.x * XS_CPB + cl;
+    const bool live = c < C && (w <= 2 || w == ST_XW_COUNT || ((w == 3 || w == 4) && has_relu));
+    double acc = 0., mn = INFINITY, mx = -INFINITY;
+    if (live) {
+        const int row = w == 1 ? CNNQ_MOM_SUM : w == 2 ? CNNQ_MOM_SUMSQ : w == 3 ? CNNQ_MOM_SUM_RELU : w == 4 ? CNNQ_MOM_SUMSQ_RELU : CNNQ_MOM_COUNT;
+        for (int gi = j; gi < G; gi += 16) {
+            const double* p = part + (size_t)gi * CNNQ_NMOM * C + c;
+            if (w == 0) {
+                mn = pmind(mn, p[(size_t)CNNQ_MOM_MIN * C]);
+                mx = pmaxd(mx, p[(size_t)CNNQ_MOM_MAX * C]);
+            } else {
+                acc += p[(size_t)row * C];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) {
+        acc += shfl_xor_d(acc, m);
+        mn = pmind(mn, shfl_xor_d(mn, m));
+        mx = pmaxd(mx, shfl_xor_d(mx, m));
+    }
+    if (j == 0) {
+        unsigned long long bits = 0ull;
+        if (live) {
+            bits = w == 0 ? ((unsigned long long)__float_as_uint((float)mn) | ((unsigned long long)__float_as_uint((float)mx) << 32))
+                          : (unsigned long long)__double_as_longlong(acc);
+            (void)xr_merge_word(xr, w * C + c, true, w == 0, bits);
+        }
+        sh_w[cl][w] = bits;            // (skipped words: zero = +0.0)
+    }
+    __syncthreads();
+    if (c < C && w == 0 && j == 0) {
+        const unsigned long long pr = sh_w[cl][0];
+        auto dw = [&](int i) { return __longlong_as_double((long long)sh_w[cl][i]); };
+        const MomSum r{(double)__uint_as_float((unsigned)(pr & 0xffffffffull)), (double)__uint_as_float((unsigned)(pr >> 32)), dw(1), dw(2),
+                       dw(ST_XW_COUNT), dw(3), dw(4)};
+        if (mom) {
+            mom[(size_t)CNNQ_MOM_MIN * C + c] = r.mn;
+            mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
+            mom[(size_t)CNNQ_MOM_SUM * C + c] = r.s;
+            mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = r.ss;
+            mom[(size_t)CNNQ_MOM_COUNT * C + c] = r.cnt;
+            mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = r.rs;
+            mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = r.rss;
+        }
+        stats[(size_t)CNNQ_STAT_MIN * C + c] = (float)r.mn;
+        stats[(size_t)CNNQ_STAT_MAX * C + c] = (float)r.mx;
+        stats[(size_t)CNNQ_STAT_MEAN * C + c] = mean_of(r);
+        stats[(size_t)CNNQ_STAT_STD * C + c] = std_of(r);
+        float std_pos = 0.f;
+        if (has_relu) {
+            double rv = (r.rss - r.rs * (r.rs / r.cnt)) / (r.cnt - 1.);
+            if (rv < 0.) rv = 0.;
+            std_pos = (float)sqrt(rv);
+        }
+        stats[(size_t)CNNQ_STAT_STD_POS * C + c] = std_pos;      // the table is written completely
+        stats[(size_t)CNNQ_STAT_B * C + c] = 0.f;
+        stats[(size_t)CNNQ_STAT_KURT * C + c] = 0.f;
+    }
+}
+
+// k_xr_devsums behind k_absdev: the same for pass B's records - nw = 1: word 6 (sum |x - mean|: what k_fused_* exchange), nw = 2:
+// words 6 and 7 (k_stats_flat's second meeting) - and rows B / KURT of the table from the global sums and the global count.  Never
+// the first kernel of its launch number.  32 channels x 2 words x 4 lanes per workgroup.
+__global__ void __launch_bounds__(TPB) k_xr_devsums(const double* __restrict__ part2, const int G, const int C, const int nw, const int want_kurt,
+                                                    const double* __restrict__ count, const XRank xr, float* __restrict__ stats) {
+    const int tid = threadIdx.x, j = tid & 3, w = (tid >> 2) & 1, cl = tid >> 3;
+    const int c = (int)blockIdx.x * 32 + cl;
+    const bool live = c < C && w < nw;
+    double acc = 0.;
+    if (live)
+        for (int gi = j; gi < G; gi += 4) acc += part2[((size_t)gi * CNNQ_NDEV + (w ? CNNQ_DEV_Z4 : CNNQ_DEV_ABS)) * C + c];
+    acc += shfl_xor_d(acc, 1);
+    acc += shfl_xor_d(acc, 2);
+    if (live && j == 0) {
+        (void)xr_merge_sum(xr, (ST_XW_COUNT + 1 + w) * C + c, true, acc);
+        const double cnt = count[c];
+        if (w == 0) stats[(size_t)CNNQ_STAT_B * C + c] = (float)(acc / cnt);
+        else stats[(size_t)CNNQ_STAT_KURT * C + c] = want_kurt ? (float)(acc / cnt - 3.) : 0.f;
+    }
+}
+
 }  // namespace

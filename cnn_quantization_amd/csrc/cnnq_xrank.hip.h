@@ -39,6 +39,12 @@
 // on what the host remembers: workgroup 0 of a launch records the number of slots the launch uses in the device array
 // cdev[parity] and zeroes the slots cdev[(parity + 2) & 3] recorded two launches back - eager and captured launches, replays in
 // any order and a switch from host to device numbering all leave the same trail.
+// The sums layout (one launch NUMBER may span several kernels - the first one runs the prologue, the others carry no_prologue):
+//   word 0 {min, max} pair   1 sum   2 sum of squares   3 / 4 the sums of relu(x)   5 the rank's element count
+//   word 6 sum |x - mean|    7 sum ((x - mean) / std)^4
+// Words 0-5 make the pass-A record global (k_stats_flat's first meeting on a flat-tile shard; k_xr_moments behind k_moments
+// otherwise and for configs 3 / 5, whose pass A is a launch of its own), words 6-7 pass B's (k_fused_* take word 6 only).  No
+// collective is left on these paths: a sharded config 3 is k_moments, k_xr_moments, k_bitalloc, k_fused - the launches of one GPU.
 #pragma once
 #include "cnnq_common.hip.h"
 
@@ -53,7 +59,9 @@ struct XRank {
     unsigned* seq_mirror;      // host-side numbering: workgroup 0 stores seq here (the device word a later capture continues from)
     int zero_c;                // slots of the launch two back: workgroup 0 zeroes them (0: nothing to clean); only without cdev
     unsigned* cdev;            // [4] slots in use per parity, kept by the launches themselves (round 6; null: zero_c from the host)
-    int nslots;                // slots this launch uses per rank (C for the extrema; words * C for the sums)
+    int nslots;                // slots this launch uses per rank (C for the extrema; 8 C for the launches that carry sums)
+    int slot0;                 // first slot of the fused kernels' sum (cnnq_aciq.hip.h: word 6 of the sums layout, 6 C)
+    int no_prologue;           // this kernel is not the first of its launch number: an earlier kernel of the sequence cleaned up
     int cmax;                  // channels a window holds per (parity, rank)
     unsigned* status;          // |= XR_STATUS_PEER_TIMEOUT
     long long timeout;         // ticks of the 100 MHz clock
@@ -162,7 +170,7 @@ __device__ __forceinline__ bool xr_merge_sum(const XRank& xr, int s, bool push, 
 // the launches keep the books themselves: cdev[parity] = slots in use; this launch zeroes what cdev[(parity + 2) & 3] says, clears
 // that entry and records its own count - whatever the host captured, replayed or ran eagerly in between.
 __device__ __forceinline__ void xr_prologue(const XRank& xr) {
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || xr.no_prologue) return;
     const unsigned seq = xr_seq(xr);
     const unsigned par = (seq + 2u) & (XR_PARITIES - 1u);
     const int zc = xr.cdev ? (int)__hip_atomic_load(xr.cdev + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xr.zero_c;
@@ -181,6 +189,31 @@ __device__ __forceinline__ void xr_prologue(const XRank& xr) {
         }
     }
     if (xr.seq_mirror && threadIdx.x == 0) *xr.seq_mirror = xr.seq;      // nobody reads the word under host numbering
+}
+
+// The same for a kernel whose EVERY workgroup can lend a hand (k_xr_moments: the launches that carry sums use eight slots per
+// channel, and 16 K uncached stores from one workgroup were 5-10 us of a 14 us kernel): each workgroup zeroes its slice of the
+// slots of the launch two back.  All of them read the same count - nobody writes that entry during this launch (its next writer
+// is workgroup 0 of the launch after next, recording its own slots) - so it is not cleared here.
+__device__ __forceinline__ void xr_prologue_all(const XRank& xr) {
+    if (xr.no_prologue) return;
+    const unsigned seq = xr_seq(xr);
+    const unsigned par = (seq + 2u) & (XR_PARITIES - 1u);
+    const int zc = xr.cdev ? (int)__hip_atomic_load(xr.cdev + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xr.zero_c;
+    const int total = xr.world * zc;
+    if (total > 0) {
+        void* own = xr.windows[xr.rank];
+        const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int i0 = (int)blockIdx.x * per, i1 = min(total, i0 + per);
+        for (int i = i0 + (int)threadIdx.x; i < i1; i += (int)blockDim.x) {
+            const int r = i / zc, c = i - r * zc;
+            __hip_atomic_store(xr_slot(own, par, xr.world, xr.cmax, r, c), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (xr.cdev) xr.cdev[seq & (XR_PARITIES - 1u)] = (unsigned)xr.nslots;
+        if (xr.seq_mirror) *xr.seq_mirror = xr.seq;
+    }
 }
 
 // device numbering: enqueued behind every exchanging launch (ONE workgroup): every reader of this rank is done, so the slots of
@@ -209,22 +242,6 @@ __global__ void __launch_bounds__(TPB) k_xr_exchange(float* __restrict__ mm, con
     (void)xr_merge(xr, c, true, mn, mx);
     mm[c] = mn;
     mm[C + c] = mx;
-}
-
-// ... and for sums (round 6): vals[nw][C] this rank's partial sums in, the W ranks' sums added in rank order out; word w of
-// channel c travels in slot (w0 + w) * C + c - the layout of the single-launch kernels, so a rank whose shard has no single-launch
-// plan speaks the same protocol around the chain's passes.  pair0: word 0 is a {min, max} pair stored as two floats in vals[0][c]
-// (the statistics kernel's phase 1) and folds like the extrema.
-__global__ void __launch_bounds__(TPB) k_xr_exchange_sums(double* __restrict__ vals, const int C, const int nw, const int w0, const int pair0,
-                                                          const int prologue, const XRank xr) {
-    if (prologue) xr_prologue(xr);
-    const int i = (int)blockIdx.x * TPB + (int)threadIdx.x;
-    if (i >= nw * C) return;
-    const int w = i / C, c = i - w * C;
-    unsigned long long* words = reinterpret_cast<unsigned long long*>(vals);
-    unsigned long long bits = words[i];
-    (void)xr_merge_word(xr, (w0 + w) * C + c, true, pair0 && w == 0, bits);
-    words[i] = bits;
 }
 
 }  // namespace

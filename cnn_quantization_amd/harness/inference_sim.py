@@ -73,6 +73,12 @@ def build_parser():
     p.add_argument('--rho_weight', '-rw', default=None, type=float)
     p.add_argument('--no-bn-folding', action='store_true')
     p.add_argument('--verbose', action='store_true')
+    p.add_argument('--sharded', action='store_true',
+                   help='one process per GPU (start under torchrun / torch.distributed.run): every rank takes its shard of each '
+                        'batch (inference_sim.py:196-200 splits the batch over DataParallel replicas; here the statistics are '
+                        'those of the GLOBAL batch, DESIGN.md section 6) and the ranks check the in-launch exchange together '
+                        'after every forward (distributed.xrank_checkpoint), redoing the batch through the collective if a '
+                        'wait for a peer expired')
     p.add_argument('--graph', action='store_true',
                    help='also capture the quantized forward into a HIP graph and time its replay (small batches: '
                         'removes the per-launch host overhead; the library only enqueues kernels, so it is capturable)')
@@ -135,8 +141,29 @@ class QuantTimer:
         return [(i, t, s, n, e0.elapsed_time(e1) * 1e-3, h) for (i, t, s, n, e0, e1, h) in self.rows]
 
 
+def _init_ranks():
+    """The default process group of a --sharded run, from torchrun's environment: RCCL (backend nccl) with one GPU per rank,
+    gloo when the ranks share a GPU (test rigs)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    one_each = torch.cuda.device_count() >= int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    torch.cuda.set_device(local if one_each else 0)
+    dist.init_process_group('nccl' if one_each else 'gloo', rank=rank, world_size=world)
+
+
 def run(args, quiet=False):
     """Returns a dict with the per-call timing rows and totals."""
+    from cnn_quantization_amd import distributed as D
+    sharded = bool(getattr(args, 'sharded', False))
+    redone = 0
+    if sharded:
+        _init_ranks()
+        D.set_xrank_recovery('checkpoint')           # nothing raises between checkpoints: the ranks stay in lock-step
     torch.manual_seed(args.seed)
     Singleton.reset()
     reset_layer_counters()
@@ -159,12 +186,22 @@ def run(args, quiet=False):
         with torch.no_grad():
             for _ in range(args.batches + 1):        # first batch is warm-up (MIOpen find, allocator)
                 x = torch.randn(args.batch_size, 3, args.image_size, args.image_size, generator=g, device=dev)
-                timer.rows.clear()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                out = model(x)
-                torch.cuda.synchronize()
-                t_fwd.append(time.perf_counter() - t0)
+                if sharded:                          # the same batch on every rank (same seed); this rank's samples of it
+                    n0, n1 = D.shard_batch(args.batch_size, D.rank(qm.group), D.world_size(qm.group))
+                    x = x[n0:n1].contiguous()
+                for attempt in range(2):
+                    timer.rows.clear()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    out = model(x)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    # the synchronisation point of the forward: did a wait of the in-launch exchange expire on ANY rank?  Then
+                    # the group is on the collective from here on and this batch is run again (its outputs were NaN somewhere)
+                    if not sharded or D.xrank_checkpoint(qm.group):
+                        break
+                    redone += 1
+                t_fwd.append(dt)
         rows = timer.summary()
         t_graph = None
         if args.graph and qm.stats_mode.name != 'collect_stats' and not args.measure_entropy:
@@ -194,7 +231,7 @@ def run(args, quiet=False):
     tot_t = sum(r[4] for r in rows)
     res = dict(rows=rows, quant_seconds=tot_t, forward_seconds=t_fwd[-1], conv_elements=sum(r[3] for r in act),
                conv_quant_seconds=sum(r[4] for r in act), entropy=logger.averages(), graph_seconds=t_graph, graph_max_abs_diff=graph_diff if t_graph is not None else None,
-               output_finite=bool(torch.isfinite(out).all()))
+               output_finite=bool(torch.isfinite(out).all()), batches_redone=redone, logits=out)
     if not quiet:
         print('%-22s %-22s %-22s %10s %10s %9s' % ('id', 'tag', 'shape', 'Melem', 'us', 'Gelem/s'))
         for (i, t, s, n, dt, _h) in rows:

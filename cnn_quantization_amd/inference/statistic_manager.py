@@ -61,6 +61,9 @@ class StatisticManager(metaclass=Singleton):
         # holds the statistics of the GLOBAL batch
         world = D.world_size(self.group)
         table, mom = ops.pc_stats(x, 1, 1, n, need_b=True, need_kurt=True, need_relu=True, group=self.group)
+        if world > 1 and not D.xrank_checkpoint(self.group):
+            # a wait of the in-launch exchange expired on some rank: the group is on the collective now - the table again
+            table, mom = ops.pc_stats(x, 1, 1, n, need_b=True, need_kurt=True, need_relu=True, group=self.group)
         host = table.cpu().numpy()[:, 0]
         m = mom.cpu().numpy()[:, 0]
         total = m[L.MOM_COUNT]      # elements of the global batch (== n on one rank)

@@ -62,6 +62,11 @@ class StatisticManagerPerChannel(metaclass=Singleton):
         table, _ = ops.pc_stats(x, N, C, HW, need_b='b' in self.stats_names,
                                 need_kurt='kurtosis' in self.stats_names,
                                 need_relu='std_pos' in self.stats_names, group=self.group)
+        if D.world_size(self.group) > 1 and not D.xrank_checkpoint(self.group):
+            # sharded: a wait of the in-launch exchange expired on some rank (the table is NaN there); the group is on the
+            # collective now - this layer's table again, before anything of it is recorded
+            table, _ = ops.pc_stats(x, N, C, HW, need_b='b' in self.stats_names, need_kurt='kurtosis' in self.stats_names,
+                                    need_relu='std_pos' in self.stats_names, group=self.group)
         if self.batch_avg and not force_global_min_max:
             # mean over the batch of the per-sample extrema (smpc.py:72,78): rows = (n, c) pairs; with several ranks
             # the sums and the sample counts travel, so every rank holds the mean over the GLOBAL batch

@@ -218,109 +218,125 @@ def _xrank_for(group, C, words=1):
     return xr if (xr is not None and xr.fits(C, words)) else None
 
 
+def _xrank_plan(kind, x, N, C, HW, group, st, ws_bytes):
+    """What the sharded single-call routes need per (group, stream, geometry), looked up once: the exchange, the scratch
+    workspace and the group workspace.  None: the group has no in-launch exchange.  (Under a stream capture nothing is cached:
+    a capture-time scratch buffer belongs to the graph's pool.)"""
+    key = (kind, id(group), x.device.index, st, N, C, HW, x.data_ptr() % 16 == 0)
+    plan = _XPLAN.get(key)
+    if plan is None:
+        xr = _xrank_for(group, C, 8)
+        if xr is None:
+            plan = False
+        else:
+            plan = (xr, group, _scratch(x, kind, ws_bytes(), st), _group_workspace(x, st))
+        if not torch.cuda.is_current_stream_capturing():
+            _XPLAN[key] = plan
+    return plan or None
+
+
 def _pc_stats_xrank(x, N, C, HW, need_b, need_kurt, need_relu, group, flags=0):
-    """Config 4 of a batch shard in ONE launch and one read of x (k_stats_flat with the cross-rank stage; a shard without a
-    flat-tile plan runs the chain's passes around the same window slots inside the call).  Returns (stats, mom) of the GLOBAL
-    batch, or None when the group has no in-launch exchange."""
-    xr = _xrank_for(group, C, 8)
-    if xr is None:
-        return None
+    """Config 4 of a batch shard in ONE host call and - where the shard has a flat-tile plan - one launch and one read of x
+    (cnnq_pc_stats_xrank: k_stats_flat with the cross-rank stage; otherwise the chain's two passes with their records made global
+    through the same window slots).  No collective.  Returns (stats, mom) of the GLOBAL batch, or None when the group has no
+    in-launch exchange."""
     lib = L.load()
     st = _raw_stream(x.device.index)
-    al = int(x.data_ptr() % 16 == 0)
-    nbytes = lib.cnnq_pc_stats_workspace(N, C, HW, al)
-    if nbytes == 0:
-        L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
-    gws = _group_workspace(x, st)
+
+    def nbytes():
+        n = lib.cnnq_pc_stats_workspace(N, C, HW, int(x.data_ptr() % 16 == 0))
+        if n == 0:
+            L.check(min(lib.cnnq_pc_groups(N, C, HW, 1), -1), 'cnnq_pc_groups(%d,%d,%d)' % (N, C, HW))
+        return n
+    plan = _xrank_plan('stats', x, N, C, HW, group, st, nbytes)
+    if plan is None:
+        return None
+    xr, _, ws, gws = plan
     stats = torch.empty((L.NSTAT, C), dtype=torch.float32, device=x.device)
     mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
-    ws = _scratch(x, 'stats', nbytes + 16 * C * 8, st)
     ctx = xr.ctx(st)
-    L.check(lib.cnnq_pc_stats_xrank(x.data_ptr(), N, C, HW, int(bool(need_b)), int(bool(need_kurt)), int(bool(need_relu)), ws.data_ptr(),
-                                    gws, GROUP_WS_BYTES if gws is not None else 0, mom.data_ptr(), stats.data_ptr(), ctypes.byref(ctx),
-                                    int(flags), st), 'cnnq_pc_stats_xrank')
+    rc = lib.cnnq_pc_stats_xrank(x.data_ptr(), N, C, HW, 1 if need_b else 0, 1 if need_kurt else 0, 1 if need_relu else 0, ws.data_ptr(),
+                                 gws, GROUP_WS_BYTES if gws is not None else 0, mom.data_ptr(), stats.data_ptr(), ctypes.byref(ctx),
+                                 int(flags), st)
+    if rc:
+        L.check(rc, 'cnnq_pc_stats_xrank')
     return stats, mom
 
 
-def _global_pass_a(x, N, C, HW, group, st):
-    """Pass A of a batch shard made global: this shard's moment records, merged, all-gathered (one collective of 7 C doubles per
-    rank) and merged in rank order.  Returns (stats [NSTAT + NQP + NDIAG, C] fp32 with rows MIN, MAX, MEAN, STD filled, mom
-    [NMOM, C] fp64 of the global batch)."""
-    lib = L.load()
-    part = pc_moments(x, N, C, HW)
-    mom_local = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
-    L.check(lib.cnnq_pc_combine(part.data_ptr(), part.shape[0], C, 0, mom_local.data_ptr(), None, st), 'cnnq_pc_combine')
-    gathered = D.all_gather_records(mom_local, group)
-    tabs = torch.empty((L.NSTAT + L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
-    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
-    L.check(lib.cnnq_pc_combine(gathered.data_ptr(), gathered.shape[0], C, 0, mom.data_ptr(), tabs.data_ptr(), st), 'cnnq_pc_combine')
-    return tabs, mom
-
-
-def _aciq_workspace(x, N, C, HW, st):
+def _aciq_ws_bytes(x, N, C, HW):
     lib = L.load()
     al = int(x.data_ptr() % 16 == 0)
     key = ('aciq', N, C, HW, al)
     nbytes = _WS_BYTES.get(key)
     if nbytes is None:
         nbytes = _WS_BYTES[key] = (lib.cnnq_pc_aciq_workspace(N, C, HW, al) + 15) // 16 * 16
-    return _scratch(x, 'aciq', nbytes + (L.NQP + L.NDIAG) * C * 4, st)
+    return nbytes
 
 
 def _aciq_qdq_xrank(x, N, C, HW, cfg, group, want_parts, out, flags=0):
-    """Config 3 of a batch shard (Laplace clipping, optional bit allocation on the 'gaus' prior): pass A -> all_gather of the
-    moment records -> merge -> (bit allocation) -> ONE launch that reads x once and exchanges the ranks' sums of |x - mean| through
-    the windows (cnnq_pc_aciq_fused_xrank; round 6): 12 bytes per element and one collective where the chain moves 16 around two.
-    Returns y [, parts], or None when the group has no in-launch exchange (the caller takes the chain)."""
-    xr = _xrank_for(group, C)
-    if xr is None:
-        return None
+    """Config 3 of a batch shard (Laplace clipping, optional bit allocation on the 'gaus' prior) in ONE host call
+    (cnnq_pc_aciq_fused_xrank; round 6): pass A, its record made global through the exchange windows, (bit allocation), ONE launch
+    for pass B + the ranks' sums of |x - mean| + parameters + Q/DQ - the four launches of one GPU, 12 bytes per element, no
+    collective, where the chain moves 16 around two.  Returns y [, parts], or None when the group has no in-launch exchange (the
+    caller takes the chain)."""
     lib = L.load()
     st = _raw_stream(x.device.index)
+    plan = _xrank_plan('aciq', x, N, C, HW, group, st,
+                       lambda: _aciq_ws_bytes(x, N, C, HW) + (L.NSTAT + L.NQP + L.NDIAG) * C * 4 + L.NMOM * C * 8)
+    if plan is None:
+        return None
+    xr, _, ws, gws = plan
     y = _out_like(x, out)
-    tabs, mom = _global_pass_a(x, N, C, HW, group, st)
-    stats, qp, diag = tabs[:L.NSTAT], tabs[L.NSTAT:L.NSTAT + L.NQP], tabs[L.NSTAT + L.NQP:]
-    gws = _group_workspace(x, st)
-    ws = _aciq_workspace(x, N, C, HW, st)
-    ctx = xr.ctx(st)
-    L.check(lib.cnnq_pc_aciq_fused_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), stats.data_ptr(),
-                                         mom[L.MOM_COUNT].data_ptr(), ws.data_ptr(), gws, GROUP_WS_BYTES if gws is not None else 0,
-                                         qp.data_ptr(), diag.data_ptr(), ctypes.byref(ctx), int(flags), st), 'cnnq_pc_aciq_fused_xrank')
     if want_parts:
-        return y, dict(stats=stats, qp=qp, diag=diag)
+        tabs = torch.empty((L.NSTAT + L.NQP + L.NDIAG, C), dtype=torch.float32, device=x.device)
+        mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
+        tp, mp = tabs.data_ptr(), mom.data_ptr()
+    else:                       # nobody outside the call reads the tables: they live behind the workspace
+        mp = ws.data_ptr() + _aciq_ws_bytes(x, N, C, HW)
+        tp = mp + L.NMOM * C * 8
+    sp, qp, dp = tp, tp + L.NSTAT * C * 4, tp + (L.NSTAT + L.NQP) * C * 4
+    ctx = xr.ctx(st)
+    rc = lib.cnnq_pc_aciq_fused_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, ctypes.byref(cfg), ws.data_ptr(), gws,
+                                      GROUP_WS_BYTES if gws is not None else 0, sp, mp, qp, dp, ctypes.byref(ctx), int(flags), st)
+    if rc:
+        L.check(rc, 'cnnq_pc_aciq_fused_xrank')
+    if want_parts:
+        return y, dict(stats=tabs[:L.NSTAT], qp=tabs[L.NSTAT:L.NSTAT + L.NQP], diag=tabs[L.NSTAT + L.NQP:], mom=mom)
     return y
 
 
 def _mid_tread_qdq_xrank(x, N, C, HW, target, sym, tabs_mt, group, want_entropy, want_parts, flags=0):
     """Config 5 of a batch shard: as _aciq_qdq_xrank with the bin allocation and MODE 1 of the fused kernels
-    (cnnq_pc_midtread_fused_xrank); the ranks' code counts are summed before the entropy.  Returns what mid_tread_qdq returns, or
-    None when the group has no in-launch exchange."""
-    xr = _xrank_for(group, C)
-    if xr is None:
-        return None
+    (cnnq_pc_midtread_fused_xrank); the ranks' code counts are summed before the entropy (the one collective left: an integer
+    all-reduce of the count table).  Returns what mid_tread_qdq returns, or None when the group has no in-launch exchange."""
     lib = L.load()
     st = _raw_stream(x.device.index)
+    plan = _xrank_plan('aciq', x, N, C, HW, group, st,
+                       lambda: _aciq_ws_bytes(x, N, C, HW) + (L.NSTAT + L.NQP + L.NDIAG) * C * 4 + L.NMOM * C * 8)
+    if plan is None:
+        return None
+    xr, _, ws, gws = plan
     y = torch.empty_like(x)
-    tabs, mom = _global_pass_a(x, N, C, HW, group, st)
-    stats = tabs[:L.NSTAT]
-    mt = torch.empty((L.NMT, C), dtype=torch.float32, device=x.device)
+    tabs = torch.empty((L.NSTAT + L.NMT, C), dtype=torch.float32, device=x.device)
+    stats, mt = tabs[:L.NSTAT], tabs[L.NSTAT:]
+    mom = torch.empty((L.NMOM, C), dtype=torch.float64, device=x.device)
     hist = torch.empty(L.mt_hist_words(C), dtype=torch.int64, device=x.device) if want_entropy else None     # zeroed by the call
-    gws = _group_workspace(x, st)
-    ws = _aciq_workspace(x, N, C, HW, st)
     ctx = xr.ctx(st)
-    L.check(lib.cnnq_pc_midtread_fused_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, float(target), int(bool(sym)), tabs_mt.data_ptr(),
-                                             tabs_mt.shape[1], stats.data_ptr(), mom[L.MOM_COUNT].data_ptr(), ws.data_ptr(), gws,
-                                             GROUP_WS_BYTES if gws is not None else 0, mt.data_ptr(), _ptr(hist), ctypes.byref(ctx),
-                                             int(flags), st), 'cnnq_pc_midtread_fused_xrank')
+    rc = lib.cnnq_pc_midtread_fused_xrank(x.data_ptr(), y.data_ptr(), N, C, HW, float(target), int(bool(sym)), tabs_mt.data_ptr(),
+                                          tabs_mt.shape[1], ws.data_ptr(), gws, GROUP_WS_BYTES if gws is not None else 0, stats.data_ptr(),
+                                          mom.data_ptr(), mt.data_ptr(), _ptr(hist), ctypes.byref(ctx), int(flags), st)
+    if rc:
+        L.check(rc, 'cnnq_pc_midtread_fused_xrank')
     entropy = None
     if want_entropy:
         D.all_reduce_sum_(hist, group)
         ent = torch.empty(1, dtype=torch.float32, device=x.device)
-        L.check(lib.cnnq_midtread_entropy(_ptr(hist), _ptr(mt), C, x.numel() * D.world_size(group), _ptr(ent), st), 'cnnq_midtread_entropy')
+        # (the global batch's element count from the merged moment record: shards may differ by a sample)
+        L.check(lib.cnnq_midtread_entropy_count(_ptr(hist), _ptr(mt), C, mom[L.MOM_COUNT].data_ptr(), _ptr(ent), st), 'cnnq_midtread_entropy')
         entropy = ent[0]
     res = [y, entropy]
     if want_parts:
-        res.append(dict(stats=stats, mt=mt, hist=hist))
+        res.append(dict(stats=stats, mt=mt, hist=hist, mom=mom))
     return tuple(res)
 
 
@@ -690,11 +706,15 @@ def minmax_qdq_fused(x, N, C, HW, num_bits, positive=False, want_codes=False, wa
       (_minmax_qdq_xrank).  Extrema are exact, so every rank gets the bits of one GPU holding the whole batch.
 
     chain=True forces the three-launch chain where a single-launch kernel would otherwise run: the reference form the
-    single-launch kernels are tested against.  _xrank: an XRankExchange to use (its verify()), False: never."""
+    single-launch kernels are tested against.  _xrank: an XRankExchange to use (its verify()), False: never.  group=False:
+    replicated data, the one-GPU route."""
     if not _checked:
         x = _dev_f32(x, 'x')
-    world = D.world_size(group)
-    if not (world > 1 or D.forced_exchange()):
+    # group=False: replicated data (weights) - never exchanged, whatever process group the job runs in.  (Until round 6 this
+    # arrived here as None = the default group: every rank's identical weights went through the exchange - the same bits, one
+    # needless collective per layer, and a wait that expired there left NaN WEIGHTS behind, outside any forward a checkpoint redoes.)
+    world = 1 if group is False else D.world_size(group)
+    if group is False or not (world > 1 or D.forced_exchange()):
         return _minmax_qdq_local(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out, want_parts, chain)
     resident = _RESIDENT and not chain
     if _xrank is not False and (_xrank is not None or _XRANK_ON) and not ((want_codes or want_entropy) and num_bits > 8):
@@ -1088,7 +1108,7 @@ def act_qdq_per_channel(x, num_bits, positive=False, clip='no', bit_alloc=False,
         raise L.CnnqError('bcorr combines only with the plain per-channel activation Q/DQ')
     if stats is None and clip == 'no' and not use_ba and not whole_tensor:
         res = minmax_qdq_fused(x, N, C, HW, num_bits, positive, want_codes, want_entropy, out=out,
-                               want_parts=want_parts, group=None if world == 1 else group, _checked=True)
+                               want_parts=want_parts, group=group, _checked=True)
         if bcorr is not None:
             res = act_bias_correction_(x, res, bool(bcorr), group=None if group is False else group)
         return res
@@ -1253,7 +1273,7 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
         res = mid_tread_qdq_single(x, N, C, HW, target, sym, tabs, want_entropy, want_parts)
         if res is not None:
             return res
-    stats, _ = pc_stats(x, N, C, HW, need_b=bool(clip), group=grp, local_only=local)
+    stats, mom = pc_stats(x, N, C, HW, need_b=bool(clip), group=grp, local_only=local)
     mt = torch.empty((L.NMT, C), dtype=torch.float32, device=x.device)
     L.check(lib.cnnq_pc_midtread_params(_ptr(stats), C, float(target), int(bool(clip)), int(bool(sym)), _ptr(tabs),
                                         tabs.shape[1], _ptr(mt), _stream(x)), 'cnnq_pc_midtread_params')
@@ -1268,8 +1288,11 @@ def mid_tread_qdq(x, target, clip, sym, per_channel_dim=1, whole_tensor=False, g
         if world > 1:
             D.all_reduce_sum_(hist, grp)
         ent = torch.empty(1, dtype=torch.float32, device=x.device)
-        L.check(lib.cnnq_midtread_entropy(_ptr(hist), _ptr(mt), C, x.numel() * world, _ptr(ent), _stream(x)),
-                'cnnq_midtread_entropy')
+        if world > 1:       # the global batch's element count from the merged moment record (shards may differ by a sample)
+            L.check(lib.cnnq_midtread_entropy_count(_ptr(hist), _ptr(mt), C, mom[L.MOM_COUNT].data_ptr(), _ptr(ent), _stream(x)),
+                    'cnnq_midtread_entropy')
+        else:
+            L.check(lib.cnnq_midtread_entropy(_ptr(hist), _ptr(mt), C, x.numel(), _ptr(ent), _stream(x)), 'cnnq_midtread_entropy')
         entropy = ent[0]
     res = [y, entropy]
     if want_codes:

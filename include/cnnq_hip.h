@@ -444,22 +444,24 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
 int cnnq_pc_aciq_qdq_auto(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws,
                           void* gws, size_t gws_bytes, float* qp, float* diag, void* stream);
 
-/* Round 6 - configs 3 / 5 / 4 of a BATCH SHARD with the cross-rank exchange inside the single launch (csrc/cnnq_xrank.hip.h,
+/* Round 6 - configs 3 / 5 / 4 of a BATCH SHARD with the cross-rank exchange inside the launches (csrc/cnnq_xrank.hip.h,
  * csrc/cnnq_aciq.hip.h, csrc/cnnq_stats1.hip.h): the sharded forms of cnnq_pc_aciq_qdq_single, cnnq_pc_midtread_qdq_single and
- * cnnq_pc_stats_single.  The reference has no counterpart (its DataParallel replicas quantize with their own sub-batch's
- * statistics, inference_sim.py:196-200); these reproduce int_quantizer.py:327-359 / 185-225 and
- * statistic_manager_perchannel.py:45-79 on the GLOBAL batch from one read of each rank's shard.
+ * cnnq_pc_stats_single - one host call per tensor, the launches of one GPU, NO collective.  The reference has no counterpart (its
+ * DataParallel replicas quantize with their own sub-batch's statistics, inference_sim.py:196-200); these reproduce
+ * int_quantizer.py:327-359 / 185-225 and statistic_manager_perchannel.py:45-79 on the GLOBAL batch from each rank's shard.
  *   cnnq_xrank_ctx   the exchange of config 2 (same windows, same launch numbering, same status word - the launches of all
  *                    four entry points share ONE sequence per stream):
- *       windows / rank / world / cmax   as cnnq_pc_minmax_qdq_xrank; a launch needs C slots per rank (the statistics kernel 8 C)
+ *       windows / rank / world / cmax   as cnnq_pc_minmax_qdq_xrank; these launches use eight slots per channel: 8 C <= cmax
  *       seq       the host's launch number (1, 2, 3, ...); 0: device numbering (captured launches), see _xrank_dev
  *       seq_dev   EIGHT device words, zeroed once (one block per rank and stream): [0] the launch number, [4..7] the slots in
  *                 use per parity - the launches record and clean them themselves (no host bookkeeping; also used by
  *                 cnnq_pc_minmax_qdq_xrank_seq / _dev since round 6, which therefore need the eight words too)
  *       status / timeout_ticks   as cnnq_pc_minmax_qdq_xrank: bit 2 when a wait for a peer expired (outputs NaN)
- * Sums travel as the complement of their fp64 bits and every reader adds the W ranks' words in RANK order: all ranks derive
- * the same b / mean / std, hence the same parameters, bit for bit.  A shard without a single-launch plan runs the chain's
- * passes around the same slots, so the ranks need not agree on their plans; every call consumes exactly one launch number. */
+ * What travels (slot = word * C + channel): word 0 the {min, max} pair, 1 sum, 2 sum of squares, 3 / 4 the sums of relu(x), 5
+ * the rank's element count, 6 sum |x - mean|, 7 sum ((x - mean) / std)^4 - sums as the complement of their fp64 bits, and every
+ * reader adds the W ranks' words in RANK order: all ranks derive the same mean / std / b, hence the same parameters, bit for
+ * bit.  A shard without a single-launch plan runs the chain's passes around the same slots, so the ranks need not agree on their
+ * plans; every call consumes exactly one launch number. */
 typedef struct cnnq_xrank_ctx {
     void* const* windows;
     int32_t rank, world, cmax;
@@ -468,20 +470,22 @@ typedef struct cnnq_xrank_ctx {
     uint32_t* status;
     int64_t timeout_ticks;
 } cnnq_xrank_ctx;
-/* stats: rows MIN, MAX, MEAN, STD of the GLOBAL batch in (pass A merged over the ranks by the caller), row B out; count: [C] device
- * doubles, the global batch's elements per channel (row CNNQ_MOM_COUNT of the merged moment record); ws: cnnq_pc_aciq_workspace bytes; qp / diag out as cnnq_pc_params (the same on every
- * rank).  Laplace clipping, bit allocation on the 'gaus' prior, num_bits <= 8 (else CNNQ_ENOTSUP: nothing enqueued). */
-int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, float* stats,
-                             const double* count, void* ws, void* gws, size_t gws_bytes, float* qp, float* diag, const cnnq_xrank_ctx* xc,
-                             unsigned flags, void* stream);
-/* mid-tread with clipping; mt[CNNQ_NMT][C] out; hist (optional, CNNQ_MT_HIST_WORDS(C), zeroed here) counts THIS rank's codes:
- * sum the ranks' tables before cnnq_midtread_entropy (total = the global element count). */
+/* Config 3: k_moments -> k_xr_moments -> (k_bitalloc) -> k_fused_* <XR>: x read twice (12 bytes per element).  ws:
+ * cnnq_pc_aciq_workspace bytes; stats [CNNQ_NSTAT][C], mom [CNNQ_NMOM][C] (fp64), qp, diag (as cnnq_pc_params): outputs, the
+ * global batch's, the same on every rank.  Laplace clipping, bit allocation on the 'gaus' prior, num_bits <= 8 (else
+ * CNNQ_ENOTSUP: nothing enqueued, no number consumed).  flags as cnnq_pc_aciq_qdq_single. */
+int cnnq_pc_aciq_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, const cnnq_params_cfg* cfg, void* ws, void* gws,
+                             size_t gws_bytes, float* stats, double* mom, float* qp, float* diag, const cnnq_xrank_ctx* xc, unsigned flags,
+                             void* stream);
+/* Config 5 (mid-tread with clipping); mt [CNNQ_NMT][C] out; hist (optional, CNNQ_MT_HIST_WORDS(C), zeroed here) counts THIS
+ * rank's codes: sum the ranks' tables, then cnnq_midtread_entropy_count with mom's COUNT row. */
 int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C, int64_t HW, double target, int sym, const double* tables,
-                                 int ntab, float* stats, const double* count, void* ws, void* gws, size_t gws_bytes, float* mt, uint64_t* hist,
+                                 int ntab, void* ws, void* gws, size_t gws_bytes, float* stats, double* mom, float* mt, uint64_t* hist,
                                  const cnnq_xrank_ctx* xc, unsigned flags, void* stream);
-/* the seven statistics (and the merged moment record, mom may be NULL) of the GLOBAL batch on every rank; 8 C <= cmax;
- * ws: cnnq_pc_stats_workspace + 16 C doubles; flags as cnnq_pc_stats_single (bit 0: recompute path, bit 3: also channels
- * of more than 128 tiles). */
+/* Config 4: the seven statistics and the merged moment record of the GLOBAL batch on every rank, from ONE read of the shard
+ * where it has a flat-tile plan (k_stats_flat<XR>), else k_moments -> k_xr_moments -> k_absdev -> k_xr_devsums.  ws:
+ * cnnq_pc_stats_workspace bytes; flags as cnnq_pc_stats_single (bit 0: recompute path, bit 3: also channels of more than 128
+ * tiles). */
 int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
                         size_t gws_bytes, double* mom, float* stats, const cnnq_xrank_ctx* xc, unsigned flags, void* stream);
 
@@ -537,6 +541,10 @@ int cnnq_pc_midtread_qdq_single(const float* x, float* y, int64_t N, int64_t C, 
                                 const double* tables, int ntab, void* ws, void* gws, size_t gws_bytes, float* stats, float* mt,
                                 uint64_t* hist, unsigned flags, void* stream);
 int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int64_t total, float* out, void* stream);
+/* ... with the element count in device memory: count[0] = elements per channel of the tensor the codes were counted over (row
+ * CNNQ_MOM_COUNT of the merged moment record; total = count[0] * C).  For batch-sharded runs, whose shards may differ by a
+ * sample: the global batch's size is known exactly on the device. */
+int cnnq_midtread_entropy_count(const uint64_t* hist, const float* mt, int64_t C, const double* count, float* out, void* stream);
 
 /* Shannon entropy in bits, -sum p*log2(p) over the non-empty bins -> out[0] (utils/entropy.py:12-15). */
 int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream);

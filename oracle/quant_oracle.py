@@ -435,15 +435,16 @@ def alpha_mult_from_tables(omega, sym, omega_table, alpha_table):
 
 
 def mid_tread_core(t, target, clip, sym, omega_table=None, alpha_table=None, want_entropy=False,
-                   return_parts=False):
-    """Row a14, iq.py:185-225 on a [R, M] matrix."""
-    std = t.std(-1)
+                   return_parts=False, stats=None):
+    """Row a14, iq.py:185-225 on a [R, M] matrix.  stats (tests only): dict of per-row `std`, `mean`, `b` to use INSTEAD of
+    the row statistics of t - the arithmetic downstream of the statistics on a table somebody else reduced (the device's)."""
+    std = t.std(-1) if stats is None else stats['std']
     omega = omega_alloc(std, target_bins=(2 ** target)).round()
     mu = None
     if clip:
         am = t.new_tensor(alpha_mult_from_tables(omega, sym, omega_table, alpha_table))
-        mu = t.mean(dim=-1)
-        b = torch.mean(torch.abs(t - mu.unsqueeze(-1)), dim=-1)
+        mu = t.mean(dim=-1) if stats is None else stats['mean']
+        b = torch.mean(torch.abs(t - mu.unsqueeze(-1)), dim=-1) if stats is None else stats['b']
         rng = (2 * am * b) if sym else (torch.max(mu, mu.new_tensor([0.])) + am * b)
     else:
         rng = (t.max(-1)[0] - t.min(-1)[0]) if sym else t.max(-1)[0]
@@ -460,7 +461,8 @@ def mid_tread_core(t, target, clip, sym, omega_table=None, alpha_table=None, wan
     codes = q.clone()
     y = q * Delta.unsqueeze(-1)
     if return_parts:
-        return y, entropy, dict(codes=codes, omega=omega, Delta=Delta, c_min=c_min, c_max=c_max, std=std)
+        return y, entropy, dict(codes=codes, omega=omega, Delta=Delta, c_min=c_min, c_max=c_max, std=std,
+                                alpha_mult=am if clip else None)
     return y, entropy
 
 

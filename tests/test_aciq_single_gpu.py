@@ -53,25 +53,7 @@ def acts(shape, seed, relu=False):
     return x.contiguous()
 
 
-def oracle_from_device_stats(x_cpu, st, bits_dev, num_bits, half, ba):
-    """alpha, delta / offset, parameters and the element-wise result the oracle derives from the DEVICE's statistics."""
-    from cnn_quantization_amd import _lib as L
-    C = x_cpu.shape[1]
-    st = st.cpu()
-    bits = O.bits_alloc_fixed_target(st[L.STAT_STD], num_bits, True) if ba else None
-    if ba:
-        assert torch.equal(bits_dev.cpu(), bits)
-    alpha = O.alpha_laplace(st[L.STAT_B], num_bits, half, bits)
-    delta, offset = O.alpha_to_delta_offset(alpha, st[L.STAT_MAX], st[L.STAT_MIN], st[L.STAT_MEAN], half)
-    delta, offset = torch.as_tensor(delta, dtype=torch.float32), torch.as_tensor(offset, dtype=torch.float32) * torch.ones(C)
-    max_ = offset + delta                                    # iq.py:351 then :443 (two fp32 roundings)
-    t = O._channel_rows(x_cpu)
-    y, codes, scale, zp, qmax = O.qdq_core(t, max_ - offset, offset, num_bits=num_bits, bit_alloc=bits, return_parts=True)
-    N, _, H, W = x_cpu.shape
-    y = y.view(C, N, H, W).transpose(0, 1).contiguous()
-    codes = codes.view(C, N, H, W).transpose(0, 1).contiguous()
-    return dict(alpha=torch.as_tensor(alpha, dtype=torch.float32), delta=max_ - offset, offset=offset, scale=scale, zp=zp,
-                qmax=qmax * torch.ones(C), y=y, codes=codes)
+from _direct import aciq_on_table as oracle_from_device_stats      # noqa: E402  (shared with the sharded tests since round 6)
 
 
 # flat tiles (56x56, 28x28: one channel per group), row pieces (32x32: cpc = 256), whole channels per workgroup with the

@@ -53,11 +53,44 @@ def test_json_line_contract():
     for k in ('config1', 'config2_entropy', 'config2_packed_single_launch', 'config3', 'config3_packed_storage',
               'config3_packed_load', 'config4', 'config5'):
         assert oc[k]['verified'] is True, k
-        assert oc[k]['roofline']['bound'] == 'hbm' and oc[k]['value'] > 0
+        ro = oc[k]['roofline']
+        assert ro['bound'] == 'hbm' and oc[k]['value'] > 0
+        # round 6: `frac` is ACHIEVED bandwidth - the bytes the launches move - and never above the peak; the
+        # SURVEY accounting of earlier rounds sits beside it under its own name
+        assert 0 < ro['frac'] <= 1 and abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-12, k
+        assert abs(ro['achieved'] - oc[k]['value'] * ro['bytes_moved_per_element'] / 1e9) / ro['achieved'] < 1e-9, k
+        assert ro['bytes_moved_per_element'] <= ro['survey_bytes_per_element'] and ro['frac'] <= ro['frac_survey_accounting'] + 1e-12, k
+    assert oc['config3']['roofline']['bytes_moved_per_element'] == 12 and oc['config5']['roofline']['bytes_moved_per_element'] == 12
+    assert 0 < d['path_frac_hbm_peak'] <= 1 and d['path_bytes_moved_per_element'] == 8
+    assert abs(d['path_frac_hbm_peak'] - d['value'] * 8 / 1e9 / 8000.) < 1e-9 and d['path_equiv_12B'] > d['path_frac_hbm_peak']
+
+
+def test_shard_legs_of_configs_3_4_5():
+    """Round 6: `bench.py --batch 64 --force-exchange` (and --gpus N) carries BASELINE configs 3 / 4 / 5 at the shard in
+    other_configs, with the bytes they move; with the in-launch exchange in force (CNNQ_XRANK=1 on the forced 1-rank group) they
+    run the sharded single-launch kernels, with the collective the chain."""
+    d = run_bench('--gpus', '1', '--batch', '16', '--steps', '2', '--warmup', '1', '--force-exchange', '--no-cpu-baseline',
+                  env={'CNNQ_XRANK': '1'})
+    oc = d['other_configs']
+    assert d['verified'] is True and 'in-launch exchange' in d['config']['exchange']
+    for k, moved in (('config3', 12), ('config5', 12)):
+        assert oc[k]['verified'] is True and oc[k]['roofline']['bytes_moved_per_element'] == moved and 'in-launch' in oc[k]['exchange'], k
+    assert oc['config4']['verified'] is True and 4 <= oc['config4']['roofline']['bytes_moved_per_element'] <= 8
+    assert d['path_bytes_moved_per_element'] == 8
+    d = run_bench('--gpus', '1', '--batch', '16', '--steps', '2', '--warmup', '1', '--force-exchange', '--no-cpu-baseline',
+                  env={'CNNQ_XRANK': '0'})
+    oc = d['other_configs']
+    for k, moved in (('config3', 16), ('config4', 8), ('config5', 16)):
+        assert oc[k]['verified'] is True and oc[k]['roofline']['bytes_moved_per_element'] == moved and 'all_gather' in oc[k]['exchange'], k
+    assert d['path_bytes_moved_per_element'] == 12
+    # two ranks sharing the GPU over gloo (the collective route): every rank takes part in the legs, rank 0 prints them
+    d = run_bench('--gpus', '2', '--batch', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', env={'CNNQ_BENCH_BACKEND': 'gloo'})
+    oc = d['other_configs']
+    assert all(oc[k]['verified'] is True for k in ('config3', 'config4', 'config5'))
 
 
 def test_plain_process_starts_its_own_ranks():
-    d = run_bench('--gpus', '2', '--batch', '64', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+    d = run_bench('--gpus', '2', '--batch', '64', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-other-configs',
                   env={'CNNQ_BENCH_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['verified'] is True
     assert d['config']['per_gpu_batch'] == 32 and d['config']['global_batch'] == 64
@@ -70,7 +103,7 @@ def test_plain_process_starts_its_own_ranks():
 def test_eight_ranks_on_one_gpu():
     """The driver's N = 8 form (one batch of 64 sharded eight ways), all ranks on the one GPU over gloo: exit 0, one line,
     eight per-rank times, the job's elements over the slowest rank's time, outputs verified on every rank."""
-    d = run_bench('--gpus', '8', '--batch', '64', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+    d = run_bench('--gpus', '8', '--batch', '64', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-other-configs',
                   env={'CNNQ_BENCH_BACKEND': 'gloo'})
     assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and d['verified'] is True
     assert d['config']['per_gpu_batch'] == 8 and d['config']['global_batch'] == 64
@@ -87,6 +120,7 @@ def test_in_launch_exchange_falls_back_to_the_collective():
     is verified.  The default (auto) never starts the in-launch exchange between ranks that share a GPU."""
     env = {'CNNQ_BENCH_BACKEND': 'gloo', 'CNNQ_XRANK': '1', 'CNNQ_XRANK_TIMEOUT_MS': '1000'}
     d = run_bench('--gpus', '2', '--batch', '16', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', env=env)
+    assert all(d['other_configs'][k]['verified'] is True for k in ('config3', 'config4', 'config5'))     # whichever exchange they ended on
     assert d['verified'] is True and d['xrank'] is not None and d['xrank']['used'] == (not d['xrank']['fell_back'])
     assert ('in-launch exchange' in d['config']['exchange']) == d['xrank']['used']
     d = run_bench('--gpus', '2', '--batch', '16', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',

@@ -52,9 +52,10 @@ def ref64(x):
 SHAPES = [(40, 6, 56, 56), (33, 5, 28, 28), (8, 4, 112, 112), (300, 3, 56, 56), (64, 7, 56, 56), (16, 3, 28, 28), (300, 2, 112, 112)]
 # row-piece tiles: whole channels per workgroup (14x14), channels straddling the loads (7x7: one channel per element), a row
 # that is a whole multiple of the workgroup (64x64: column blocks of one channel), ragged sample splits, and the tile heights
-# the planner picks at full size (K = 16: [512,160,14,14]; K = 32 with eight rows in LDS: [512,320,14,14], [512,1320,7,7])
+# the planner picks at full size (K = 16: [512,160,14,14] and - straddling rows take at most K = 16 since round 6, their K = 32
+# instances spilled - [512,640,7,7]; K = 32 with eight rows in LDS: [512,320,14,14])
 GROUP_SHAPES = [(12, 24, 14, 14), (70, 12, 14, 14), (64, 37, 14, 14), (40, 44, 7, 7), (33, 12, 7, 7), (6, 3, 64, 64), (300, 8, 7, 7), (130, 20, 14, 14)]
-BIG_GROUP_SHAPES = [(512, 160, 14, 14), (512, 320, 14, 14), (512, 1320, 7, 7)]
+BIG_GROUP_SHAPES = [(512, 160, 14, 14), (512, 320, 14, 14), (512, 640, 7, 7)]
 
 
 @pytest.mark.parametrize('shape', SHAPES + GROUP_SHAPES)

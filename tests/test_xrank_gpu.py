@@ -64,24 +64,8 @@ def _worker(rank, world, port, tmp):
                 out['o_%d_%d' % (i, half)] = (y.cpu(), codes.cpu(), float(ent), parts['qp'].cpu(), parts['stats'].cpu(), float(ent2),
                                               bool(torch.equal(y, y2)))
         out['launches_out'] = ex.seq - seq0 - out['launches']
-        # configs 3 / 5 and the seven statistics of a sharded run move their moment records through the collective whatever
-        # CNNQ_XRANK says (two routes, and the in-launch one is config 2's): same calls, switch on and off, bit for bit
-        x = _batch(3, (38, 24, 14, 14))
-        n0, n1 = D.shard_batch(38, rank, world)
-        xs = x[n0:n1].contiguous().cuda()
-        def stats_paths():
-            r = [ops.act_qdq_per_channel(xs, 4, clip='laplace', bit_alloc=True),
-                 ops.mid_tread_qdq(xs, 4, clip=True, sym=False)[0],
-                 ops.pc_stats(xs, xs.shape[0], 24, 196, need_b=True, need_kurt=True, need_relu=True)[0]]
-            torch.cuda.synchronize()
-            return [t.cpu() for t in r]
-        a = stats_paths()
-        os.environ['CNNQ_XRANK'] = '0'
-        ops.reload_switches()
-        b = stats_paths()
-        os.environ['CNNQ_XRANK'] = '1'
-        ops.reload_switches()
-        out['stats_same'] = all(bool(torch.equal(u, v)) for u, v in zip(a, b))
+        # (configs 3 / 5 and the seven statistics of a sharded run: since round 6 their sums meet inside the single launch too -
+        #  tests/test_sharded_single_gpu.py)
         torch.cuda.synchronize()
         out['healthy'] = ex.healthy()
         out['group_status'] = ops.group_status(xs)
@@ -119,7 +103,6 @@ def test_two_ranks_on_one_gpu_equal_the_whole_batch(tmp_path):
                 assert torch.equal(o[3][0], rp['scale'].flatten()) and torch.equal(o[3][1], rp['zero_point'].flatten()), (shape, half)
                 assert torch.equal(o[4][1], torch.as_tensor(rp['max']).flatten()) and o[6]
     assert all(p['launches_out'] == 2 * len(SHAPES) * 2 for p in parts)    # they too went through the in-launch exchange
-    assert all(p['stats_same'] for p in parts)
 
 
 def _single(rank, world, port, tmp):
@@ -183,7 +166,7 @@ def _graph(rank, world, port, tmp):
         with torch.cuda.stream(side):
             for x, y in zip(xs, ys):                     # eagerly once on this stream: workspaces and the sequence word exist
                 ops.act_qdq_per_channel(x, 4, out=y)
-            seq_before = int(ex.seq_dev.item())
+            seq_before = int(ex.seq_dev[0].item())
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 for x, y in zip(xs, ys):
@@ -195,13 +178,84 @@ def _graph(rank, world, port, tmp):
                 side.synchronize()
                 replays += 1
                 same = same and all(bool(torch.equal(y, r)) for y, r in zip(ys, refs))
-            same = same and int(ex.seq_dev.item()) == seq_before + 3 * len(xs)     # the device word advanced once per replayed launch
+            same = same and int(ex.seq_dev[0].item()) == seq_before + 3 * len(xs)     # the device word advanced once per replayed launch
             same = same and ex.healthy()
         torch.cuda.current_stream().wait_stream(side)
     torch.save({'ok': ok, 'same': same, 'replays': replays}, os.path.join(tmp, 'graph.pt'))
     if ex is not None:
         ex.close()
     dist.destroy_process_group()
+
+
+def _graph_after_larger(rank, world, port, tmp):
+    """a graph that holds a SINGLE exchange launch, captured after eager launches with MORE channels, replayed
+    five times, with an eager launch between capture and first replay and another between two replays.  With the host's
+    bookkeeping of round 5 the slots [zero_c, C) of the eager launches' parities stayed dirty and a later launch folded stale
+    extrema; the launches now record and clean their slot counts on the device (cdev)."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['CNNQ_XRANK'] = '1'
+    os.environ['CNNQ_XRANK_TIMEOUT_MS'] = '3000'
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cnn_quantization_amd import ops, distributed as D
+    ops.reload_switches()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ex = D.xrank_exchange(None)
+    ok, same, rest = ex is not None, True, -1
+    if ok:
+        # two ranks sharing the GPU, each with its half of every batch: a stale slot of the PEER is what a dirty parity shows
+        def shard(x):
+            n0, n1 = D.shard_batch(x.shape[0], rank, world)
+            return x[n0:n1].contiguous().cuda()
+        big = [shard(_batch(20 + i, (12, 96, 14, 14)) * (1 + i)) for i in range(3)]       # 96 channels, different ranges
+        small = shard(_batch(31, (40, 6, 56, 56)))                                          # 6 channels
+        small2 = shard(_batch(32, (40, 6, 56, 56)) * 7.)                                    # the same slots, other extrema
+        ref = lambda x: ops.minmax_qdq_fused(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], 4, False, _xrank=False)
+        refs_big, ref_small, ref_small2 = [ref(x) for x in big], ref(small), ref(small2)
+        ys = torch.empty_like(small)
+        with torch.cuda.stream(side):
+            for x in big:
+                ops.act_qdq_per_channel(x, 4)                                               # eager, C = 96
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                ops.act_qdq_per_channel(small, 4, out=ys)                                   # ONE captured launch, C = 6
+            same = same and bool(torch.equal(ops.act_qdq_per_channel(big[1], 4), refs_big[1]))   # eager between capture and replay
+            for rep in range(5):
+                ys.zero_()
+                g.replay()
+                side.synchronize()
+                same = same and bool(torch.equal(ys, ref_small))
+                if rep == 2:
+                    same = same and bool(torch.equal(ops.act_qdq_per_channel(big[2], 4), refs_big[2]))   # eager between replays
+                    same = same and bool(torch.equal(ops.act_qdq_per_channel(small2, 4), ref_small2))
+            for x, r in zip(big, refs_big):                                                 # and eager again afterwards
+                same = same and bool(torch.equal(ops.act_qdq_per_channel(x, 4), r))
+            side.synchronize()
+            same = same and ex.healthy()
+            # every parity's slots are zero again once two more launches have passed (the trail the launches keep themselves)
+            for _ in range(2):
+                ops.act_qdq_per_channel(small, 4)
+            side.synchronize()
+            cdev = ex.seq_dev[4:8].tolist()
+            rest = sum(1 for v in cdev if v != 0)
+        torch.cuda.current_stream().wait_stream(side)
+    torch.save({'ok': ok, 'same': same, 'rest': rest}, os.path.join(tmp, 'graph2_%d.pt' % rank))
+    dist.barrier()
+    if ex is not None:
+        ex.close()
+    dist.destroy_process_group()
+
+
+def test_single_captured_launch_after_eager_launches_with_more_channels(tmp_path):
+    port = 37700 + os.getpid() % 1500
+    mp.spawn(_graph_after_larger, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rk in range(2):
+        r = torch.load(os.path.join(str(tmp_path), 'graph2_%d.pt' % rk))
+        assert r['ok'] and r['same'], rk
+        assert 0 <= r['rest'] <= 2      # at most the two launches still ahead of their clean-up hold slots
 
 
 def test_exchange_launches_replay_from_a_graph(tmp_path):
