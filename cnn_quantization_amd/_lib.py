@@ -96,6 +96,8 @@ SIGNATURES = {
     'cnnq_hist_replica_bytes': (ctypes.c_size_t, []),
     'cnnq_pc_minmax_qdq_single': (_I, [_P, _P, _L, _L, _L, _I, _I, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P]),
     'cnnq_entropy_replicas': (_I, [_P, _P, _P]),
+    'cnnq_entropy_replicas_batch': (_I, [_P, _I, _P, _P]),
+    'cnnq_midtread_entropy_batch': (_I, [_I, _P, _P, _P, _P, _P, _P]),
     'cnnq_pc_aciq_workspace': (ctypes.c_size_t, [_L, _L, _L, _I]),
     'cnnq_pc_aciq_qdq': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P, _P]),
     'cnnq_pc_aciq_qdq_single': (_I, [_P, _P, _L, _L, _L, ctypes.POINTER(ParamsCfg), _P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P,

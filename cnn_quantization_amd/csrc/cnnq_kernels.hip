@@ -868,6 +868,14 @@ int cnnq_hist_replicas_fold(uint64_t* hist_rep, uint64_t* hist, void* stream) {
 }
 
 // entropy (bits) of the replica histogram the call above filled; the tables are zero again afterwards
+// n sets of replica tables, back to back (cnnq_hist_replica_bytes each), in ONE launch: out[i] = the entropy of set i; all left zero
+int cnnq_entropy_replicas_batch(uint64_t* hist_rep, int n, float* out, void* stream) {
+    if (!hist_rep || !out || n <= 0) return CNNQ_EINVAL;
+    hipLaunchKernelGGL(k_entropy_replicas, dim3((unsigned)n), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned long long*>(hist_rep), out);
+    return launch_status();
+}
+
 int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream) {
     if (!hist_rep || !out) return CNNQ_EINVAL;
     hipLaunchKernelGGL(k_entropy_replicas, dim3(1), dim3(TPB), 0, (hipStream_t)stream,
@@ -1345,6 +1353,22 @@ int cnnq_midtread_entropy_count(const uint64_t* hist, const float* mt, int64_t C
     if (!hist || !mt || !out || !count || ((uintptr_t)count & 7) || C <= 0) return CNNQ_EINVAL;
     hipLaunchKernelGGL(k_mt_entropy, dim3(1), dim3(PTPB), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned long long*>(hist), mt, (int)C, 0., out, count);
+    return launch_status();
+}
+
+// the entropies of n histograms of the mid-tread path in ONE launch (n <= 16; the arrays are host arrays of n entries)
+int cnnq_midtread_entropy_batch(int n, const uint64_t* const* hist, const float* const* mt, const int64_t* C, const int64_t* total,
+                                float* out, void* stream) {
+    if (n <= 0 || n > MT_ENT_BATCH || !hist || !mt || !C || !total || !out) return CNNQ_EINVAL;
+    MtEntBatch b = {};
+    for (int i = 0; i < n; ++i) {
+        if (!hist[i] || !mt[i] || C[i] <= 0 || total[i] <= 0) return CNNQ_EINVAL;
+        b.hist[i] = reinterpret_cast<const unsigned long long*>(hist[i]);
+        b.mt[i] = mt[i];
+        b.C[i] = (int)C[i];
+        b.total[i] = (double)total[i];
+    }
+    hipLaunchKernelGGL(k_mt_entropy_batch, dim3((unsigned)n), dim3(PTPB), 0, (hipStream_t)stream, b, out);
     return launch_status();
 }
 

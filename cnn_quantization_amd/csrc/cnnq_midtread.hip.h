@@ -297,9 +297,27 @@ __global__ void __launch_bounds__(TPB) k_mt_qdq(const float* __restrict__ x, flo
 // as torch.unique would, utils/entropy.py:10)
 // count_dev (may be null): the elements per CHANNEL of the tensor the codes were counted over, in device memory (row COUNT of a
 // merged moment record: a batch-sharded run knows the global batch's size on the device, not on the host) - total = count * C
+// up to MT_ENT_BATCH histograms in one launch (round 6: the tensors of a forward at its end), one workgroup each
+constexpr int MT_ENT_BATCH = 16;
+struct MtEntBatch {
+    const unsigned long long* hist[MT_ENT_BATCH];
+    const float* mt[MT_ENT_BATCH];
+    double total[MT_ENT_BATCH];
+    int C[MT_ENT_BATCH];
+};
+__device__ __forceinline__ void mt_entropy_one(const unsigned long long* __restrict__ hist, const float* __restrict__ mt, int C, double total,
+                                               float* __restrict__ out, const double* __restrict__ count_dev);
 __global__ void __launch_bounds__(PTPB) k_mt_entropy(const unsigned long long* __restrict__ hist,
                                                      const float* __restrict__ mt, int C, double total,
                                                      float* __restrict__ out, const double* __restrict__ count_dev = nullptr) {
+    mt_entropy_one(hist, mt, C, total, out, count_dev);
+}
+__global__ void __launch_bounds__(PTPB) k_mt_entropy_batch(const MtEntBatch b, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    mt_entropy_one(b.hist[i], b.mt[i], b.C[i], b.total[i], out + i, nullptr);
+}
+__device__ __forceinline__ void mt_entropy_one(const unsigned long long* __restrict__ hist, const float* __restrict__ mt, int C, double total,
+                                               float* __restrict__ out, const double* __restrict__ count_dev) {
     __shared__ double sh[PTPB / 64];
     __shared__ unsigned long long lrep[MT_W];
     const int tid = threadIdx.x;

@@ -516,7 +516,12 @@ __global__ void __launch_bounds__(TPB) k_entropy(const unsigned long long* __res
 
 // entropy of XHIST_REPLICAS replica tables (the histogram output of the single-launch kernels): fold them, hand the
 // folded table to the same arithmetic as k_entropy, and leave the tables zero for the next launch
+// One workgroup per histogram (round 6: the tables of a whole forward's tensors in ONE launch at its end - nothing consumes an
+// entropy mid-forward, iq.py:445 logs it - instead of a dependent 8-25 us launch behind every tensor): workgroup b takes the
+// tables at rep + b * XHIST_REPLICAS * 256 and writes out[b].
 __global__ void __launch_bounds__(TPB) k_entropy_replicas(unsigned long long* __restrict__ rep, float* __restrict__ out) {
+    rep += (size_t)blockIdx.x * XHIST_REPLICAS * 256;
+    out += blockIdx.x;
     __shared__ unsigned long long bins[256];
     __shared__ double sh[TPB / 64];
     __shared__ double sh_total;

@@ -159,6 +159,7 @@ def _init_ranks():
 def run(args, quiet=False):
     """Returns a dict with the per-call timing rows and totals."""
     from cnn_quantization_amd import distributed as D
+    from cnn_quantization_amd import ops as ops_mod
     sharded = bool(getattr(args, 'sharded', False))
     redone = 0
     if sharded:
@@ -193,7 +194,12 @@ def run(args, quiet=False):
                     timer.rows.clear()
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    out = model(x)
+                    if args.measure_entropy:
+                        # -me: the entropies of all layers' codes in ONE launch at the end of the forward (ops.entropy_batch)
+                        with ops_mod.entropy_batch():
+                            out = model(x)
+                    else:
+                        out = model(x)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                     # the synchronisation point of the forward: did a wait of the in-launch exchange expire on ANY rank?  Then

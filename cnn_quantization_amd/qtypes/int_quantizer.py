@@ -133,7 +133,15 @@ class IntQuantizer:
 
     def _log_entropy(self, id, entropy, meter, weight):
         if entropy is not None and self.logger is not None:
-            self.logger.log_metric(id + '.entropy', float(entropy), step='auto', meterId=meter, weight=weight)
+            def log(e=entropy):
+                self.logger.log_metric(id + '.entropy', float(e), step='auto', meterId=meter, weight=weight)
+            eb = ops._ENT_BATCH
+            if eb is not None:
+                # inside an ops.entropy_batch block (the harness wraps a forward in one): the value exists when the block's one
+                # entropy launch has run - the logger is called then, in the order of the layers, as int_quantizer.py:153,179,445
+                eb.after(log)
+            else:
+                log()
 
     # ------------------------------------------------------------------ per-channel activations
     def gemmlowpQuantizeActivationPerChannel(self, tensor, id, tag="", stat_id=None, min_=None, max_=None):

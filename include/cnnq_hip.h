@@ -360,6 +360,10 @@ int cnnq_pc_minmax_qdq_single(const float* x, float* y, int64_t N, int64_t C, in
                               void* gws, size_t gws_bytes, float* qp, float* mm, uint8_t* codes, uint64_t* hist_rep,
                               uint8_t* packed, void* stream);
 int cnnq_entropy_replicas(uint64_t* hist_rep, float* out, void* stream);
+/* Round 6: the entropies of a whole forward's tensors in ONE launch at its end (the reference logs the value, nothing consumes
+ * it mid-forward: int_quantizer.py:445,179,217): n sets of replica tables back to back (cnnq_hist_replica_bytes() each, every
+ * tensor's launch counting into its own set) -> out[n]; all tables are zero afterwards. */
+int cnnq_entropy_replicas_batch(uint64_t* hist_rep, int n, float* out, void* stream);
 
 /* Config 2 in ONE launch and ONE read of x when the batch is sharded over `world` GPUs of one node
  * (csrc/cnnq_xrank.hip.h; opt-in in the Python host - CNNQ_XRANK=1 / auto - and only after it reproduced the collective
@@ -545,6 +549,10 @@ int cnnq_midtread_entropy(const uint64_t* hist, const float* mt, int64_t C, int6
  * CNNQ_MOM_COUNT of the merged moment record; total = count[0] * C).  For batch-sharded runs, whose shards may differ by a
  * sample: the global batch's size is known exactly on the device. */
 int cnnq_midtread_entropy_count(const uint64_t* hist, const float* mt, int64_t C, const double* count, float* out, void* stream);
+/* ... and of n <= 16 tensors in one launch (host arrays of n entries each: the histograms, their mt tables, channel counts and
+ * element totals) -> out[n]. */
+int cnnq_midtread_entropy_batch(int n, const uint64_t* const* hist, const float* const* mt, const int64_t* C, const int64_t* total,
+                                float* out, void* stream);
 
 /* Shannon entropy in bits, -sum p*log2(p) over the non-empty bins -> out[0] (utils/entropy.py:12-15). */
 int cnnq_entropy(const uint64_t* hist, int nbins, float* out, void* stream);

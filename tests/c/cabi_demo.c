@@ -35,10 +35,12 @@ static int routes_agree(void) {
     }
     float *dx, *y0, *y1, *y2, *pmm, *qp, *ws, *local;
     void* gws = NULL;
-    const size_t gws_bytes = (size_t)16 << 20;
+    /* the exchange workspace of the single-launch routes is sized by the library for the shape at hand (include/cnnq_hip.h:
+     * cnnq_pc_group_workspace; the Python host allocates one 18 MB block that covers every layer of the BASELINE configs) */
+    const size_t gws_bytes = cnnq_pc_group_workspace(N, C, HW);
     const int G = cnnq_pc_groups(N, C, HW, 1);
     const size_t wsb = cnnq_pc_minmax_qdq_workspace(N, C, HW);
-    if (G <= 0 || wsb == 0) { fprintf(stderr, "plan failed\n"); return 2; }
+    if (G <= 0 || wsb == 0 || gws_bytes == 0) { fprintf(stderr, "plan failed\n"); return 2; }
     CHECK(hipMalloc((void**)&dx, n * sizeof(float)));
     CHECK(hipMalloc((void**)&y0, n * sizeof(float)));
     CHECK(hipMalloc((void**)&y1, n * sizeof(float)));

@@ -30,6 +30,33 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b'gfx950' in lib.cnnq_version()
 
 
+def test_no_kernel_instance_uses_scratch():
+    """Round 6: three instances of the shipped library carried 20 bytes of scratch - a spilled tile row at
+    the 168-register edge of the K = 32 tiles.  None may: the gfx950 code object inside libcnnq_hip.so is unbundled and every
+    kernel's .private_segment_fixed_size read from its notes (llvm tools of the ROCm image; runs on the CPU)."""
+    import subprocess
+    import tempfile
+    from cnn_quantization_amd import _build
+    llvm = '/opt/rocm/lib/llvm/bin'
+    if not os.path.exists(os.path.join(llvm, 'llvm-readelf')):
+        pytest.skip('llvm tools not found')
+    lib = _build.build()
+    with tempfile.TemporaryDirectory() as d:
+        co, fat = os.path.join(d, 'dev.co'), os.path.join(d, 'fat.bin')
+        subprocess.run([llvm + '/llvm-objcopy', '-O', 'binary', '--only-section=.hip_fatbin', lib, fat], check=True)
+        subprocess.run([llvm + '/clang-offload-bundler', '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--input=' + fat,
+                        '--output=' + co, '--unbundle'], check=True, capture_output=True)
+        notes = subprocess.run([llvm + '/llvm-readelf', '--notes', co], check=True, capture_output=True, text=True).stdout
+    kernels = notes.split('  - .agpr_count:')[1:]
+    assert len(kernels) > 300, len(kernels)
+    spilling = []
+    for b in kernels:
+        name = re.search(r'\.name:\s+(\S+)', b).group(1)
+        if int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', b).group(1)) > 0:
+            spilling.append(name)
+    assert not spilling, spilling
+
+
 def test_enums_match_header():
     from cnn_quantization_amd import _lib as L
     text = open(os.path.join(ROOT, 'include', 'cnnq_hip.h')).read()

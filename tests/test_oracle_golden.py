@@ -123,6 +123,17 @@ def test_collect_stats(golden):
     assert O.collect_stats_perchannel(torch.zeros(4, 6, 1, 1)) is None
 
 
+def test_collect_stats_at_a_single_launch_shape(golden):
+    """round 6: the reference's collection on [16,3,28,28] (tests/golden/make_golden_collect_flat.py), a shape whose statistics
+    take ONE launch on the device (k_stats_flat) - the oracle restates it bit for bit here too."""
+    g = golden('collect_flat')
+    for bi, batch_avg in enumerate((False, True)):
+        for k in range(2):
+            st = O.collect_stats_perchannel(g.t('x%d' % k), batch_avg=batch_avg)
+            for s in O.COLLECT_STATS:
+                assert bits_equal(st[s], g.np('b%d_%s' % (bi, s))[k]), (bi, k, s)
+
+
 def test_weights(golden):
     g = golden('weights')
     for k in range(int(g.np('n_cases'))):

@@ -70,6 +70,51 @@ def test_single_launch_statistics_full_tile_heights(ops, shape, need):
     check_statistics(ops, shape, need)
 
 
+def test_reference_generated_collection_through_the_single_launch(ops, golden, tmp_path, monkeypatch):
+    """k_stats_flat against vectors of the REFERENCE (statistic_manager_perchannel.py:45-79 run on [16,3,28,28],
+    tests/golden/make_golden_collect_flat.py), through the route that takes the single launch: ops.pc_stats_single itself and the
+    product's StatisticManagerPerChannel.save_tensor_stats (which must end up in it: cnnq_pc_stats_auto).  Extrema bit for bit;
+    mean / std / b / std_pos within the fp64-sum tier of test_hip_parity.test_stats_collect_set_vs_oracle; kurtosis as there."""
+    from cnn_quantization_amd import _lib as L
+    from cnn_quantization_amd.inference import statistic_manager_perchannel as smpc
+    g = golden('collect_flat')
+    rows = (('max', L.STAT_MAX), ('min', L.STAT_MIN), ('std', L.STAT_STD), ('mean', L.STAT_MEAN), ('kurtosis', L.STAT_KURT),
+            ('b', L.STAT_B), ('std_pos', L.STAT_STD_POS))
+
+    def close(name, got, want, exact=True):
+        if name in ('max', 'min') and exact:
+            assert bits_equal(got, want), name
+        elif name in ('max', 'min'):        # batch_avg: the mean over the batch of the per-sample extrema (fp64 here, fp32 there)
+            np.testing.assert_allclose(got, want, rtol=2e-6, err_msg=name)
+        elif name == 'kurtosis':
+            np.testing.assert_allclose(got, want, rtol=1e-3, atol=5e-4, err_msg=name)
+        else:
+            np.testing.assert_allclose(got, want, rtol=5e-6, atol=2e-6, err_msg=name)
+    for k in range(2):
+        xd = g.t('x%d' % k).cuda()
+        N, C, H, W = xd.shape
+        res = ops.pc_stats_single(xd, N, C, H * W, True, True, True, flags=0)        # flags 0: the product's own routing
+        assert res is not None, 'no single-launch plan for the golden shape'
+        st = res[0].cpu()
+        for name, row in rows:
+            close(name, st[row].numpy(), g.np('b0_%s' % name)[k])
+    assert ops.group_status(xd) == 0
+    # ... and through the manager (same pickle rows as the reference's manager holds), batch_avg off and on
+    monkeypatch.setenv('HOME', str(tmp_path))
+    for bi, batch_avg in enumerate((False, True)):
+        smpc.Singleton._instances.pop(smpc.StatisticManagerPerChannel, None)
+        sm = smpc.StatisticManagerPerChannel('flat_%d' % bi, load_stats=False, batch_avg=batch_avg,
+                                             stats=['max', 'min', 'std', 'mean', 'kurtosis', 'b', 'std_pos'])
+        for k in range(2):
+            sm.save_tensor_stats(g.t('x%d' % k).cuda(), 'activation', 'conv0_activation')
+        for name, _ in rows:
+            got = sm.stats['conv0_activation'][name]
+            assert got.shape == (2, 3)
+            for k in range(2):
+                close(name, got[k], g.np('b%d_%s' % (bi, name))[k], exact=not batch_avg)
+    smpc.Singleton._instances.pop(smpc.StatisticManagerPerChannel, None)
+
+
 def check_statistics(ops, shape, need):
     from cnn_quantization_amd import _lib as L
     need_b, need_kurt, need_relu = need
