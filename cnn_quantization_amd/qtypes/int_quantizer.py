@@ -135,7 +135,7 @@ class IntQuantizer:
         if entropy is not None and self.logger is not None:
             def log(e=entropy):
                 self.logger.log_metric(id + '.entropy', float(e), step='auto', meterId=meter, weight=weight)
-            eb = ops._ENT_BATCH
+            eb = getattr(ops, '_ENT_BATCH', None)
             if eb is not None:
                 # inside an ops.entropy_batch block (the harness wraps a forward in one): the value exists when the block's one
                 # entropy launch has run - the logger is called then, in the order of the layers, as int_quantizer.py:153,179,445
