@@ -122,11 +122,7 @@ def roofline_objects(layers, batch, world, single_launch=True):
     # HBM bytes from the PMC counters: collected in separate rocprofv3 --pmc passes of this very command and
     # committed under profiles/ (never measured inside a timed run); attached only to the configuration they
     # were measured on
-    pmc = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+    pmc = next((f for f in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_traffic.json' % r) for r in (6, 5, 4, 3)) if os.path.exists(f)), '')
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
@@ -140,10 +136,8 @@ def roofline_objects(layers, batch, world, single_launch=True):
         except (OSError, ValueError):
             pass
     # the same kernel's average duration under `rocprofv3 --kernel-trace --stats` of this command, committed with the box
-    # it was measured on (profiles/r04_rocprof_headline.json): next to the live figure so the two can be paired
-    rp = os.path.join(ROOT, 'profiles', 'r05_rocprof_headline.json')
-    if not os.path.exists(rp):
-        rp = os.path.join(ROOT, 'profiles', 'r04_rocprof_headline.json')
+    # it was measured on (profiles/rNN_rocprof_headline.json, the newest round's): next to the live figure so the two can be paired
+    rp = next((f for f in (os.path.join(ROOT, 'profiles', 'r%02d_rocprof_headline.json' % r) for r in (6, 5, 4)) if os.path.exists(f)), '')
     if os.path.exists(rp) and world == 1:
         try:
             with open(rp) as f:

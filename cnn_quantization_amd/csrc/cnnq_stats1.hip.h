@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
     __shared__ double l_d[4][TPB / 64];
     __shared__ double sh_out[8], sh_out2[2];      // the folded words of phase 1 (kept for the final row) and of phase 2
     __shared__ float sh_mm[2];
-    __shared__ int sh_code;
+    __shared__ int sh_code, sh_last;
     const unsigned st0 = threadIdx.x == 0 ? __hip_atomic_load(ws.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     int c, member;
@@ -354,6 +354,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         }
     }
     float vb = 0.f, kurt = 0.f;
+    bool writer = member == 0;                  // who writes the channel's row: member 0, or - with phase 2 - its last arriver
     if (sa.need_dev) {
         // ---- phase 2 (k_absdev's arithmetic: fp32 difference, reciprocal of the std, fp64 sums)
         const float isd = sa.need_kurt ? 1.f / sd : 0.f;
@@ -367,7 +368,12 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 k4 += (double)(z2 * z2);
             }
         };
-        bool published = false;
+        // Round 6: nobody WAITS for the second meeting any more.  A member publishes its two words and counts its arrival; whoever
+        // arrives LAST - every other member's words are out by then - folds them (member order), exchanges them with the other
+        // ranks (XR), writes the channel's row and re-arms the group's lines; everybody else leaves at once and its slot on the
+        // CU goes to the next workgroup's loads.  (Round 5 had every member poll the second meeting too: a quarter of a
+        // workgroup's life with its 128 KB of registers neither loading nor needed - the memory system idled through it.)
+        bool have_fold = false;
         if (!cold) {
             // out of the registers.  (On the cold path the tile is NOT used again - this member's words come out of the loop
             // below like everybody's - so its registers are free there: the recompute code next to a live tile spilled it.)
@@ -389,14 +395,9 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             reduce2(da, dk, sw);
             encode(sw, ST_W2, false);
             st_publish(lines + (size_t)member * ST_LINE, sw.w, ST_W1, ST_W2);
-            published = true;
-            fold.init();
-            if (st_fold_poll(fold, lines, g.Gs, ST_W1, ST_W2, false, tmo, &sh_code)) st_fold_finish(fold, ST_W2, false, sh_out2, sh_mm);
-            __syncthreads();
-            cold = (sh_code & 3) != 0;
-            if (cold && tid == 0) atomicOr(ws.status, (unsigned)(sh_code & 3));
-        }
-        if (cold) {
+        } else {
+            // a member whose first meeting failed (or the test hook): every member's words from x with that member's own lane
+            // mapping, folded in member order - the same bits whoever ends up writing the row
             fold.init();
             for (int m = 0; m < g.Gs; ++m) {
                 double a2 = 0., k2 = 0., la2 = 0., lk2 = 0.;
@@ -416,27 +417,39 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 StWords s2;
                 reduce2(a2, k2, s2);
                 st_fold_add(fold, m, s2.w, ST_W2, false);
-                if (m == member && !published) {       // the others wait for this member's words whatever happened to it
+                if (m == member) {                      // its own words go out like everybody's: the last arriver may be somebody else
                     encode(s2, ST_W2, false);
                     st_publish(lines + (size_t)member * ST_LINE, s2.w, ST_W1, ST_W2);
                 }
             }
-            __syncthreads();                           // a hot attempt's partial sh_out2 writes are behind us
+            __syncthreads();
             st_fold_finish(fold, ST_W2, false, sh_out2, sh_mm);
-            __syncthreads();
+            have_fold = true;
         }
-        if constexpr (XR) {
-            if (tid < ST_W2) {
-                double s2 = sh_out2[tid];
-                (void)xr_merge_sum(xr, (ST_XW_COUNT + 1 + tid) * g.C + c, member == 0, s2);
-                sh_out2[tid] = s2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the words have left the CU before the arrival is counted
+        __syncthreads();
+        if (tid == 0) sh_last = grp_arrive_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
+        __syncthreads();
+        writer = sh_last != 0;
+        if (writer) {
+            if (!have_fold) {
+                fold.init();
+                if (st_fold_poll(fold, lines, g.Gs, ST_W1, ST_W2, false, tmo, &sh_code)) st_fold_finish(fold, ST_W2, false, sh_out2, sh_mm);
+                __syncthreads();
             }
-            __syncthreads();
+            if constexpr (XR) {
+                if (tid < ST_W2) {
+                    double s2 = sh_out2[tid];
+                    (void)xr_merge_sum(xr, (ST_XW_COUNT + 1 + tid) * g.C + c, true, s2);     // this rank's one push per word
+                    sh_out2[tid] = s2;
+                }
+                __syncthreads();
+            }
+            vb = (float)(sh_out2[0] / count_of());
+            kurt = sa.need_kurt ? (float)(sh_out2[1] / count_of() - 3.) : 0.f;
         }
-        vb = (float)(sh_out2[0] / count_of());
-        kurt = sa.need_kurt ? (float)(sh_out2[1] / count_of() - 3.) : 0.f;
     }
-    if (member == 0 && tid == 0) {
+    if (writer && tid == 0) {
         const size_t C = (size_t)g.C;
         sa.stats[(size_t)CNNQ_STAT_MIN * C + c] = sh_mm[0];
         sa.stats[(size_t)CNNQ_STAT_MAX * C + c] = sh_mm[1];
@@ -455,11 +468,14 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             sa.mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = RELU ? sh_out[4] : 0.;
         }
     }
-    // ---- leave the group; the last member out re-arms the group's lines
+    // ---- leave the group.  With phase 2 the last ARRIVER above is also the last to need the lines: it re-arms them; without it
+    //      the departures are counted and the last member out does
     __syncthreads();
-    if (tid == 0) sh_code = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
-    __syncthreads();
-    if (sh_code)
+    if (!sa.need_dev) {
+        if (tid == 0) sh_last = grp_depart_last(grp_lines(ws.cnt, c, g.Gs, 0, 1), member, g.Gs) ? 1 : 0;
+        __syncthreads();
+    }
+    if (sh_last)
         for (int m = tid; m < g.Gs * ST_LINE; m += TPB) __hip_atomic_store(lines + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

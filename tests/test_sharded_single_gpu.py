@@ -218,3 +218,58 @@ def test_one_rank_forced_through_the_exchange_equals_the_one_gpu_launch(tmp_path
     r = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
     assert r['ok'], r['why']
     assert r['healthy'] and r['same_as_one_gpu']
+
+
+def _graph_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CNNQ_XRANK='1', CNNQ_FORCE_EXCHANGE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    from cnn_quantization_amd import ops, distributed as D
+    ops.reload_switches()
+    side = torch.cuda.Stream()                           # the exchange binds to ONE stream: a capturable one from the start
+    with torch.cuda.stream(side):
+        ex = D.xrank_exchange(None)
+    ok, same = ex is not None, True
+    if ok:
+        shapes = [(40, 6, 56, 56), (70, 12, 14, 14), (130, 24, 7, 7), (7, 16, 5, 9)]
+        xs = [acts(sh, 400 + i).cuda() for i, sh in enumerate(shapes)]
+        ys = [torch.empty_like(x) for x in xs]
+        with torch.cuda.stream(side):
+            refs, rstats = [], []
+            for x, y in zip(xs, ys):                     # eagerly once: workspaces and the sequence words exist
+                refs.append(ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True).clone())
+                rstats.append(ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True, need_relu=True)[0].clone())
+            side.synchronize()
+            seq_before = int(ex.seq_dev[0].item())
+            g = torch.cuda.CUDAGraph()
+            sts = []
+            with torch.cuda.graph(g, stream=side):
+                for x, y in zip(xs, ys):
+                    ops.act_qdq_per_channel(x, 4, clip='laplace', bit_alloc=True, out=y)
+                    sts.append(ops.pc_stats(x, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], need_b=True, need_kurt=True, need_relu=True)[0])
+            for rep in range(3):
+                for y in ys:
+                    y.zero_()
+                g.replay()
+                side.synchronize()
+                same = same and all(bool(torch.equal(y, r)) for y, r in zip(ys, refs))
+                same = same and all(_same(a, b) for a, b in zip(sts, rstats))
+            same = same and int(ex.seq_dev[0].item()) == seq_before + 3 * 2 * len(xs)      # one launch number per call and replay
+            same = same and int(ex.seq_dev[4:8].abs().sum()) == 0                          # every launch cleaned up behind itself
+            same = same and ex.healthy()
+        torch.cuda.current_stream().wait_stream(side)
+    torch.save({'ok': ok, 'same': same}, os.path.join(tmp, 'graph.pt'))
+    if ex is not None:
+        ex.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_configs_3_and_4_replay_from_a_graph(tmp_path):
+    """The sharded single-call routes are capturable (device-side launch numbers, the slot bookkeeping on the device): config 3
+    and the seven statistics of four shard shapes (flat tiles, row pieces, straddling rows, no plan) captured once, replayed
+    three times through the window of one forced rank - the eager bits every time."""
+    port = 33600 + os.getpid() % 1500
+    mp.spawn(_graph_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(str(tmp_path), 'graph.pt'))
+    assert r['ok'] and r['same']
