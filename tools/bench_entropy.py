@@ -19,22 +19,39 @@ for (C, hw, half, count) in bench.RESNET50_CONV_OUTPUTS:
         seed += 1
 ys = [torch.empty_like(x) for x, _ in layers]
 elems = sum(x.numel() for x, _ in layers)
-for ent in (False, True, False, True):
-    t = bench.timed_best(lambda: [ops.act_qdq_per_channel(x, 4, positive=half, want_entropy=ent, out=y) for (x, half), y in zip(layers, ys)])
-    print('config 2 b%d %-14s %.3f ms per forward (%.1f G elem/s)' % (batch, 'with entropy' if ent else 'plain', t * 1e3, elems / t / 1e9), flush=True)
+def fwd(ent, batched):
+    if ent and batched:
+        with ops.entropy_batch():          # round 6: ONE entropy launch for the 53 tensors, at the end of the forward
+            for (x, half), y in zip(layers, ys):
+                ops.act_qdq_per_channel(x, 4, positive=half, want_entropy=True, out=y)
+    else:
+        for (x, half), y in zip(layers, ys):
+            ops.act_qdq_per_channel(x, 4, positive=half, want_entropy=ent, out=y)
+
+
+for ent, batched in ((False, False), (True, False), (True, True), (False, False), (True, False), (True, True)):
+    t = bench.timed_best(lambda: fwd(ent, batched))
+    print('config 2 b%d %-28s %.3f ms per forward (%.1f G elem/s)' % (batch, ('with entropy, one launch at the end' if batched else 'with entropy, per tensor') if ent else 'plain',
+                                                                     t * 1e3, elems / t / 1e9), flush=True)
 seen = set()
 for (x, half), y in zip(layers, ys):
     if tuple(x.shape) in seen:
         continue
     seen.add(tuple(x.shape))
     ts = {}
-    for ent in (False, True):
-        f = lambda: ops.act_qdq_per_channel(x, 4, positive=half, want_entropy=ent, out=y)
+    for ent in (False, True, 'batched'):
+        f = lambda: ops.act_qdq_per_channel(x, 4, positive=half, want_entropy=bool(ent), out=y)
         f(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(6):
-            f()
+        if ent == 'batched':
+            with ops.entropy_batch():
+                for _ in range(6):
+                    f()
+        else:
+            for _ in range(6):
+                f()
         e1.record(); torch.cuda.synchronize()
         ts[ent] = e0.elapsed_time(e1) * 1e3 / 6
-    print('%-22s plain %8.1f us  entropy %8.1f us  x%.3f' % (list(x.shape), ts[False], ts[True], ts[True] / ts[False]), flush=True)
+    print('%-22s plain %8.1f us  entropy %8.1f us  x%.3f   batched %8.1f us  x%.3f' % (list(x.shape), ts[False], ts[True], ts[True] / ts[False],
+                                                                                       ts['batched'], ts['batched'] / ts[False]), flush=True)
