@@ -173,7 +173,8 @@ int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, 
 // The same table from ONE launch that reads x once (cnnq_stats1.hip.h: the tile stays in registers across pass A and pass B,
 // the partial sums meet through the slot region of the group workspace): 4 instead of 8 bytes per element, one launch instead
 // of three.  Flat-tile plans only; CNNQ_ENOTSUP - nothing enqueued - otherwise (and for a gws that is NULL or too small): the
-// caller takes cnnq_pc_stats.  flags: 0 (tests: 1 = skip the waits and recompute).
+// caller takes cnnq_pc_stats.  flags: bit 0 - skip the waits and recompute (tests); bit 3 - also channels of more than 128 tiles and
+// the row-piece routing that the default (0: what cnnq_pc_stats_auto passes) leaves to the chain because it loses there.
 int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,
                          size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream) {
     if (!x || !stats || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
@@ -945,8 +946,11 @@ int cnnq_pc_aciq_qdq_single(const float* x, float* y, int64_t N, int64_t C, int6
     if (use_ba && !diag) return CNNQ_EINVAL;                     // the bit table lives in diag
     if (cfg->clip != 1 || cfg->direct_range || (use_ba && cfg->prior_is_b) || !gws) return CNNQ_ENOTSUP;
     GPlan gp;
-    if (plan_sums(N, C, HW, al16(x) && al16(y), &gp, 1) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    // (with the codes / the histogram wanted the 160 KB tiles of a big channel have no instance - 32 KB of LDS rows next to the 32 KB
+    //  code table: planned without them, so that CNNQ_ENOTSUP comes BEFORE anything is enqueued: ADVICE r5)
+    if (plan_sums(N, C, HW, al16(x) && al16(y), &gp, (codes || hist_rep) ? 0 : 1) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
     if ((size_t)gp.ngroups * gp.gstride * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
+    if (gp.KL && !(gp.flat && gp.K == 32 && gp.KL == 8)) return CNNQ_ENOTSUP;
     const int G = cnnq_pc_groups(N, C, HW, al16(x) ? 1 : 0);
     if (G <= 0) return G ? G : CNNQ_EINVAL;
     double* part = reinterpret_cast<double*>(ws);

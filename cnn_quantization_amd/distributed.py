@@ -251,6 +251,23 @@ class XRankExchange:
             ref = ops.minmax_qdq_fused(x, n, c, h * w, 4, half, group=self.group, _xrank=False)
             got = ops.minmax_qdq_fused(x, n, c, h * w, 4, half, group=self.group, _xrank=self)
             ok = ok and bool(torch.equal(ref, got))
+        # ... and the SUMS (round 6): the seven statistics of the global batch through the windows (eight words per channel; a
+        # flat-tile shard and one without a plan) against the chain around the collective - extrema and count exact, the sums
+        # within the tier of two orders of fp64 additions
+        from . import _lib as L
+        for (n, c, h, w) in ((40, 6, 56, 56), (37, 24, 14, 14)):
+            x = torch.randn((n, c, h, w), generator=g, device=self.device) * (1 + self.rank) - 0.3
+            plan = (self, self.group, ops._scratch(x, 'stats', L.load().cnnq_pc_stats_workspace(n, c, h * w, 1), ops._raw_stream(self.device.index)),
+                    ops._group_workspace(x))
+            ops._XPLAN[('stats', id(self.group), x.device.index, ops._raw_stream(self.device.index), n, c, h * w, x.data_ptr() % 16 == 0)] = plan
+            st, mom = ops._pc_stats_xrank(x, n, c, h * w, True, True, True, self.group)
+            ops.release_plans()
+            part = ops.pc_moments(x, n, c, h * w, True)
+            mom_local, _ = ops.pc_combine(part, True)
+            mom_ref, st_ref = ops.pc_combine(all_gather_records(mom_local, self.group), True)
+            ok = ok and bool(torch.equal(st[:2], st_ref[:2])) and bool(torch.equal(mom[L.MOM_COUNT], mom_ref[L.MOM_COUNT]))
+            ok = ok and bool(torch.allclose(st[2:4], st_ref[2:4], rtol=1e-5, atol=1e-6)) and bool(torch.allclose(mom[2:4], mom_ref[2:4], rtol=1e-9, atol=1e-6))
+            ok = ok and bool(torch.isfinite(st[L.STAT_B]).all()) and bool((st[L.STAT_B] > 0).all())
         return self._all_agree(ok and self.healthy())
 
     def _unmap(self):

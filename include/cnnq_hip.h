@@ -132,7 +132,8 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
  * tile of x in registers (and LDS) across pass A and pass B, and the workgroups of a channel exchange their partial sums twice
  * through the slot region of the exchange workspace (cnnq_group_ws_alloc) - 4 instead of 8 bytes per element, one launch
  * instead of three; the same per-element arithmetic and final formulas as the chain, a different (fixed) order of the fp64
- * additions.  Flat-tile geometries (H*W % 4 == 0, H*W / 4 >= 128 and not a multiple of 256, 2 .. 512 tiles per channel), and
+ * additions (round 6: nobody waits for the second exchange - the workgroup that arrives LAST folds it, writes the channel's row
+ * and re-arms the slots; the others leave after publishing their words).  Flat-tile geometries (H*W % 4 == 0, H*W / 4 >= 128 and not a multiple of 256, 2 .. 512 tiles per channel), and
  * the row-piece tiles of cnnq_pc_minmax_qdq_group for shorter rows (k_stats_group).  CNNQ_ENOTSUP where the chain is faster:
  * more than 128 tiles per channel, row-piece geometries below 256 MB or with channels straddling the 16-byte loads (flags
  * bit 3 lifts these three rules: tests), and where there is no 16-byte tiling at all.
