@@ -192,11 +192,9 @@ int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int n
     sa.need_dev = (need_b || need_kurt) ? 1 : 0;
     sa.need_kurt = need_kurt ? 1 : 0;
     if (!gp.flat) {
-        // short rows: row-piece tiles (k_stats_group).  A single-round grid of register tiles loads, reduces and meets in lockstep:
-        // the memory system idles through two meetings, and the two streaming passes of the chain win wherever a workgroup owns
-        // many channels (measured b512: [512,1024,14,14] 134 us against the chain's 155, [512,512,14,14] 76 / 77,
-        // [512,2048,7,7] 114 / 88, [512,512,7,7] 91 / 46) - by default only the large layers of one channel per lane
-        if (!(flags & 8u) && (gp.v.A != 1 || N * C * HW * 4 < ((int64_t)256 << 20))) return CNNQ_ENOTSUP;
+        // short rows: row-piece tiles (k_stats_group), where they beat the chain (stats_group_pays: every one-channel-per-lane
+        // shape, straddling rows only while the tensor is small)
+        if (!(flags & 8u) && !stats_group_pays(gp, N, C, HW)) return CNNQ_ENOTSUP;
         return launch_stats_group(x, gp, sa, gws, gws_bytes, flags & 1u, (hipStream_t)stream);
     }
     return launch_stats_flat(x, gp, sa, gws, flags & 1u, N * C * HW * 4 > NT_BYTES, (hipStream_t)stream);
@@ -1159,18 +1157,23 @@ int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int ne
     hipStream_t st = (hipStream_t)stream;
     const int need_dev = (need_b || need_kurt) ? 1 : 0;
     GPlan gp;
-    const bool single = gws && plan_sums(N, C, HW, al16(x), &gp, 0) == 0 && gp.ws_bytes <= gws_bytes && gp.flat && !gp.KL &&
-                        (gp.Gs <= 128 || (flags & 8u)) && (size_t)gp.ngroups * gp.gstride * ST_LINE * 8 <= GRP_WS_SLOT_BYTES;
+    const bool planned = gws && plan_sums(N, C, HW, al16(x), &gp, 0) == 0 && gp.ws_bytes <= gws_bytes;
+    const bool single = planned && gp.flat && !gp.KL && (gp.Gs <= 128 || (flags & 8u)) &&
+                        (size_t)gp.ngroups * gp.gstride * ST_LINE * 8 <= GRP_WS_SLOT_BYTES;
+    St1Args sa;
+    sa.stats = stats;
+    sa.mom = mom;
+    sa.count = (double)N * (double)HW;                     // this rank's; the launch exchanges it with the sums
+    sa.need_relu = need_relu ? 1 : 0;
+    sa.need_dev = need_dev;
+    sa.need_kurt = need_kurt ? 1 : 0;
+    rc = CNNQ_ENOTSUP;
     if (single) {
-        St1Args sa;
-        sa.stats = stats;
-        sa.mom = mom;
-        sa.count = (double)N * (double)HW;                 // this rank's; the launch exchanges it with the sums
-        sa.need_relu = need_relu ? 1 : 0;
-        sa.need_dev = need_dev;
-        sa.need_kurt = need_kurt ? 1 : 0;
         rc = launch_stats_flat(x, gp, sa, gws, flags & 1u, false, st, &xr);
-    } else {
+    } else if (planned && !gp.flat && ((flags & 8u) || stats_group_pays(gp, N, C, HW))) {
+        rc = launch_stats_group(x, gp, sa, gws, gws_bytes, flags & 1u, st, &xr);       // CNNQ_ENOTSUP (nothing enqueued): the slots do not fit
+    }
+    if (rc == CNNQ_ENOTSUP) {
         double* part = reinterpret_cast<double*>(ws);
         double* part2 = part + (size_t)G * CNNQ_NMOM * C;
         rc = xr_pass_a(x, N, C, HW, need_relu ? 1 : 0, part, G, xr, mom, stats, stream);

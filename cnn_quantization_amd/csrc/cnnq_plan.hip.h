@@ -618,7 +618,19 @@ int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* w
 }
 
 // the single-read statistics kernel on a row-piece plan (k_stats_group): SG_NP words per member and owned channel
-int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* ws, size_t ws_bytes, unsigned flags, hipStream_t st) {
+// Where the row-piece single launch beats the three-launch chain (measured: tools/bench_stats_small.py at batch 64 and 512, round 6 -
+// after its second meeting stopped being waited for): every one-channel-per-lane shape (14x14: 19.6 against 30.5 us at
+// [64,256,14,14], 47.1 / 49.4 at [512,256,14,14], 134 / 156 at [512,1024,14,14]); straddling rows (7x7) only while the tensor is
+// small ([64,512,7,7] 28.6 against 37.9 us; [64,2048,7,7] 60.7 / 35.7 and [512,512,7,7] 90 / 47 lose: many channels per workgroup
+// reduce, publish and fold seven words each in lockstep).
+inline bool stats_group_pays(const GPlan& p, int64_t N, int64_t C, int64_t HW) {
+    return p.v.A == 1 || N * C * HW * 4 <= ((int64_t)8 << 20);
+}
+
+int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* ws, size_t ws_bytes, unsigned flags, hipStream_t st,
+                       const XRank* xrp = nullptr) {
+    const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: both phases' folds exchanged inside the launch
+    const XRank xr = xrank ? *xrp : XRank{};
     if (p.flat) return CNNQ_ENOTSUP;
     const int kk = (p.g.mode == 1) ? 1 : p.g.k;
     const int64_t words = (((int64_t)p.Gs * SG_NP * kk + 15) / 16) * 16;
@@ -634,7 +646,9 @@ int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* 
     const dim3 grid((unsigned)((int64_t)p.g.S * p.g.ncb)), block(TPB);
 #define LAUNCH_SG(A, KR, KL)                                                                                             \
     do {                                                                                                                 \
-        if (sa.need_relu) hipLaunchKernelGGL((k_stats_group<A, KR, KL, true>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags);  \
+        if (xrank && sa.need_relu) hipLaunchKernelGGL((k_stats_group<A, KR, KL, true, true>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags, xr);  \
+        else if (xrank) hipLaunchKernelGGL((k_stats_group<A, KR, KL, false, true>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags, xr);            \
+        else if (sa.need_relu) hipLaunchKernelGGL((k_stats_group<A, KR, KL, true>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags);  \
         else hipLaunchKernelGGL((k_stats_group<A, KR, KL, false>), grid, block, 0, st, x, p.g, p.Gs, w, sa, flags);              \
     } while (0)
     if (p.v.A == 4) {

@@ -20,7 +20,7 @@
 // rounding, and are bit-identical run after run and between the meeting and the recompute path (the cold path recomputes
 // EVERY member's words with that member's own lane mapping and folds them in the same order).
 //
-// Round 6 - XR = true (k_stats_flat): the batch is sharded over W GPUs (cnnq_xrank.hip.h).  After each phase's LOCAL meeting the
+// Round 6 - XR = true (k_stats_flat, k_stats_group): the batch is sharded over W GPUs (cnnq_xrank.hip.h).  After each phase's LOCAL meeting the
 // folded words of the rank - phase 1: the pair, the sums, and the rank's element count; phase 2: the two sums - are exchanged with
 // the other ranks inside the launch (lane w of wave 0 takes word w: one polling loop for all of them; member 0 pushes, every
 // member reads its own rank's window) and folded in rank order, so every rank writes the row of the GLOBAL batch from one read
@@ -640,12 +640,16 @@ __device__ __forceinline__ void sg_fold(const unsigned long long* src, int Gs, i
     }
 }
 
-template <int A, int KR, int KL, bool RELU>
+template <int A, int KR, int KL, bool RELU, bool XR = false>
 __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_stats_group(const float* __restrict__ x, const Geo g, const int Gs,
-                                                                                        const GWs ws, const St1Args sa, const unsigned flags) {
+                                                                                        const GWs ws, const St1Args sa, const unsigned flags,
+                                                                                        const XRank xr = XRank{}) {
     constexpr int K = KR + KL;
     constexpr int NP1 = RELU ? 5 : 3;
     static_assert(MAXCH <= TPB, "one lane per channel");
+    if constexpr (XR) xr_prologue(xr);                 // workgroup 0: the slots of the launch two back
+    __shared__ double sh_cnt[XR ? MAXCH : 1];          // XR: the global batch's elements per channel
+    __shared__ int sh_last;
     __shared__ __attribute__((aligned(16))) float sh_x[KL ? KL * TPB * 4 : 4];
     __shared__ double l_a[TPB * A];
     __shared__ double sh_q[4 * MAXCH];            // phase 1: sum, sum of squares, relu sums; phase 2: sum |x - mean|, sum z^4
@@ -748,10 +752,33 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         sg_fold<4, false>(tab, Gs, kk, nch, 0, NP1, 0, sh_q, sh_mn, sh_mx, &sh_code);
         __syncthreads();
     }
+    if constexpr (XR) {
+        // the batch is sharded (round 6): the owned channels' folded words - the pair, the sums, the rank's element count -
+        // exchanged with the other ranks, rank order (cnnq_xrank.hip.h: slot = word * C + channel); member 0 pushes
+        for (int i = tid; i < nch * (ST_XW_COUNT + 1); i += TPB) {
+            const int w = i / nch, ch = i - w * nch;
+            if (w < NP1 || w == ST_XW_COUNT) {
+                unsigned long long bits;
+                if (w == 0) bits = (unsigned long long)__float_as_uint(sh_mn[ch]) | ((unsigned long long)__float_as_uint(sh_mx[ch]) << 32);
+                else bits = (unsigned long long)__double_as_longlong(w == ST_XW_COUNT ? sa.count : sh_q[(size_t)(w - 1) * MAXCH + ch]);
+                (void)xr_merge_word(xr, w * g.C + b.c0 + ch, rb.member == 0, w == 0, bits);
+                if (w == 0) {
+                    sh_mn[ch] = __uint_as_float((unsigned)(bits & 0xffffffffull));
+                    sh_mx[ch] = __uint_as_float((unsigned)(bits >> 32));
+                } else if (w == ST_XW_COUNT) {
+                    sh_cnt[ch] = __longlong_as_double((long long)bits);
+                } else {
+                    sh_q[(size_t)(w - 1) * MAXCH + ch] = __longlong_as_double((long long)bits);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    auto count_of = [&](int ch) -> double { if constexpr (XR) return sh_cnt[ch]; else return sa.count; };
     // ---- mean / std / std_pos of the owned channels: identical in every member (the formulas of k_combine)
     if (tid < nch) {
         const int c = b.c0 + tid;
-        const MomSum r{(double)sh_mn[tid], (double)sh_mx[tid], sh_q[tid], sh_q[MAXCH + tid], sa.count, RELU ? sh_q[2 * MAXCH + tid] : 0.,
+        const MomSum r{(double)sh_mn[tid], (double)sh_mx[tid], sh_q[tid], sh_q[MAXCH + tid], count_of(tid), RELU ? sh_q[2 * MAXCH + tid] : 0.,
                        RELU ? sh_q[3 * MAXCH + tid] : 0.};
         const float mean = mean_of(r), sd = std_of(r);
         sh_mean[tid] = mean;
@@ -778,7 +805,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 sa.mom[(size_t)CNNQ_MOM_MAX * C + c] = r.mx;
                 sa.mom[(size_t)CNNQ_MOM_SUM * C + c] = r.s;
                 sa.mom[(size_t)CNNQ_MOM_SUMSQ * C + c] = r.ss;
-                sa.mom[(size_t)CNNQ_MOM_COUNT * C + c] = sa.count;
+                sa.mom[(size_t)CNNQ_MOM_COUNT * C + c] = r.cnt;
                 sa.mom[(size_t)CNNQ_MOM_SUM_RELU * C + c] = r.rs;
                 sa.mom[(size_t)CNNQ_MOM_SUMSQ_RELU * C + c] = r.rss;
             }
@@ -802,7 +829,9 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             wg_channel_sums<A>(g, bb, bok, da, l_a, sh_q);
             wg_channel_sums<A>(g, bb, bok, dk, l_a, sh_q + MAXCH);
         };
-        bool published = false;
+        // Round 6, as k_stats_flat: nobody waits for the second meeting - the LAST arriver folds it (member order), exchanges it
+        // with the other ranks (XR), writes rows B / KURT and re-arms the group's block
+        bool have_fold = false;
         if (!cold) {
             // out of the registers.  (On the cold path the tile is NOT used again: its registers are free there.)
             int tidq = threadIdx.x;
@@ -833,14 +862,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 if (KL + j < nrows) dev_add(v[j], mean, isd, da, dk);
             reduce2(b, ok, da, dk);
             emit(lines + (size_t)rb.member * NPK, 5, 2);
-            published = true;
-            __syncthreads();
-            sg_fold<4, true>(lines, Gs, kk, nch, 5, 2, tmo, sh_q, sh_mn, sh_mx, &sh_code);
-            __syncthreads();
-            cold = (sh_code & 3) != 0;
-            if (cold && tid == 0) atomicOr(ws.status, (unsigned)(sh_code & 3));
-        }
-        if (cold) {
+        } else {
             for (int m = 0; m < Gs; ++m) {
                 const RBlk mb = rblk_at(g, rb.group, m);
                 const int mcol = mb.b.col0 + tid;
@@ -865,26 +887,49 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 }
                 reduce2(mb.b, mok, da, dk);
                 emit(tab + (size_t)m * NPK, 5, 2);
-                if (m == rb.member && !published) emit(lines + (size_t)rb.member * NPK, 5, 2);    // the others wait for this member's words whatever happened to it
+                if (m == rb.member) emit(lines + (size_t)rb.member * NPK, 5, 2);    // its own words go out like everybody's
                 __syncthreads();
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             sg_fold<4, false>(tab, Gs, kk, nch, 5, 2, 0, sh_q, sh_mn, sh_mx, &sh_code);
             __syncthreads();
+            have_fold = true;
         }
-        if (tid < nch && rb.member == 0) {
-            const size_t C = (size_t)g.C;
-            const int c = b.c0 + tid;
-            sa.stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sh_q[tid] / sa.count);
-            sa.stats[(size_t)CNNQ_STAT_KURT * C + c] = sa.need_kurt ? (float)(sh_q[MAXCH + tid] / sa.count - 3.) : 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the words have left the CU before the arrival is counted
+        __syncthreads();
+        if (tid == 0) sh_last = grp_arrive_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
+        __syncthreads();
+        if (sh_last) {
+            if (!have_fold) {
+                sg_fold<4, true>(lines, Gs, kk, nch, 5, 2, tmo, sh_q, sh_mn, sh_mx, &sh_code);
+                __syncthreads();
+            }
+            if constexpr (XR) {
+                for (int i = tid; i < nch * ST_W2; i += TPB) {
+                    const int w = i / nch, ch = i - w * nch;
+                    double s2 = sh_q[(size_t)w * MAXCH + ch];
+                    (void)xr_merge_sum(xr, (ST_XW_COUNT + 1 + w) * g.C + b.c0 + ch, true, s2);      // this rank's one push per word
+                    sh_q[(size_t)w * MAXCH + ch] = s2;
+                }
+                __syncthreads();
+            }
+            if (tid < nch) {
+                const size_t C = (size_t)g.C;
+                const int c = b.c0 + tid;
+                sa.stats[(size_t)CNNQ_STAT_B * C + c] = (float)(sh_q[tid] / count_of(tid));
+                sa.stats[(size_t)CNNQ_STAT_KURT * C + c] = sa.need_kurt ? (float)(sh_q[MAXCH + tid] / count_of(tid) - 3.) : 0.f;
+            }
         }
     }
-    // ---- leave the group; the last member out re-arms the group's block
+    // ---- leave the group.  With phase 2 the last ARRIVER above is also the last to need the block: it re-arms it; without it the
+    //      departures are counted and the last member out does
     __syncthreads();
-    if (tid == 0) sh_code = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
-    __syncthreads();
-    if (sh_code)
+    if (!sa.need_dev) {
+        if (tid == 0) sh_last = grp_depart_last(grp_lines(ws.cnt, rb.group, Gs, 0, 1), rb.member, Gs) ? 1 : 0;
+        __syncthreads();
+    }
+    if (sh_last)
         for (int m = tid; m < Gs * NPK; m += TPB) __hip_atomic_store(lines + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -180,7 +180,7 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
         res = _pc_stats_xrank(x, N, C, HW, need_b, need_kurt, need_relu, group)
         if res is not None:
             return res
-    if world == 1:
+    if world == 1 and (local_only or not D.forced_exchange()):
         # one C call, one cached workspace (cnnq_pc_stats_auto)
         lib = L.load()
         nbytes = lib.cnnq_pc_stats_workspace(N, C, HW, int(x.data_ptr() % 16 == 0))
@@ -195,14 +195,17 @@ def pc_stats(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, group=
                                        _ptr(_scratch(x, 'stats', nbytes, st)), gws, GROUP_WS_BYTES if gws is not None else 0,
                                        _ptr(mom), _ptr(stats), st), 'cnnq_pc_stats')
         return stats, mom
+    # the collective route (ranks sharing a GPU, CNNQ_XRANK=0, after a recovery; also a 1-rank group under CNNQ_FORCE_EXCHANGE=1,
+    # which times the real collectives on one GPU): the chain's passes with an all_gather of the fp64 records behind each
+    exchanging = world > 1 or D.forced_exchange()
     part = pc_moments(x, N, C, HW, need_relu)
-    if world > 1:
+    if exchanging:
         mom_local, _ = pc_combine(part, need_relu)
         part = D.all_gather_records(mom_local, group)
     mom, stats = pc_combine(part, need_relu)
     if need_b or need_kurt:
         part2 = pc_absdev(x, N, C, HW, stats, need_kurt)
-        if world > 1:
+        if exchanging:
             dev_local = pc_combine_dev(part2, mom, None, need_kurt, want_sums=True)
             part2 = D.all_gather_records(dev_local, group)
         pc_combine_dev(part2, mom, stats, need_kurt)

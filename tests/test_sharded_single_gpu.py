@@ -32,8 +32,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (N, C, H, W): flat tiles / row pieces of one channel / whole channels per workgroup + exchange over the batch splits /
-# straddling float4s (A = 4) / no single-launch plan (H*W = 45) / uneven shards of a flat shape
-SHAPES = [(40, 6, 56, 56), (24, 3, 32, 32), (70, 12, 14, 14), (130, 24, 7, 7), (7, 16, 5, 9), (33, 5, 28, 28)]
+# straddling float4s (A = 4) / no single-launch plan (H*W = 45) / uneven shards of a flat shape / straddling rows too large for
+# the statistics' single launch to pay (> 8 MB: the chain's passes around the window slots)
+SHAPES = [(40, 6, 56, 56), (24, 3, 32, 32), (70, 12, 14, 14), (130, 24, 7, 7), (7, 16, 5, 9), (33, 5, 28, 28), (260, 200, 7, 7)]
 
 
 def acts(shape, seed, relu=False):
