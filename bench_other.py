@@ -167,11 +167,11 @@ def other_configs(ops, device, batch):
     ok4 = (bool(torch.equal(st4[Lb.STAT_MAX], xb.amax(dim=(0, 2, 3)))) and bool(torch.equal(st4[Lb.STAT_MIN], xb.amin(dim=(0, 2, 3))))
            and float(((st4[Lb.STAT_MEAN][:8].double() - m8).abs() / m8.abs().clamp(min=1e-3)).max()) < 1e-5
            and float(((st4[Lb.STAT_STD][:8].double() - s8).abs() / s8).max()) < 1e-5)
-    # layers with a flat-tile plan of at most 128 tiles per channel take ONE launch that reads x once (cnnq_pc_stats_single)
-    import ctypes
-    lib, d8 = Lb.load(), (ctypes.c_int32 * 8)()
+    # the layers the library routes to ONE launch that reads x once (cnnq_pc_stats_route: flat tiles of at most 256 members per
+    # channel, row pieces where they beat the chain)
+    lib = Lb.load()
     one_read = sum(x.numel() for x, _ in layers
-                   if lib.cnnq_pc_group_describe(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], d8) == 0 and d8[2] == 3 and d8[5] <= 128)
+                   if lib.cnnq_pc_stats_route(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], 1, ops.GROUP_WS_BYTES, 0) > 0)
     out['config4'] = obj(elems, t, 8, 'ResNet-50 b%d, -sm collect: the seven per-channel statistics; %.0f %% of the elements in one '
                          'launch and one read of x (cnnq_pc_stats_single), the rest in the three-launch chain' % (batch, 100. * one_read / elems),
                          bool(ok4), moved=8 - 4. * one_read / elems, pmc=pmc_traffic('config4'))
@@ -293,10 +293,9 @@ def shard_configs(ops, device, per_rank, group, world, rank, exchange_name):
         mx, mn = mxr.to(device), mnr.to(device)
     ok4 = (bool(torch.equal(st4[Lb.STAT_MAX], mx)) and bool(torch.equal(st4[Lb.STAT_MIN], mn)) and bool(torch.isfinite(st4).all())
            and float(mom4[Lb.MOM_COUNT][0]) == float(xb.shape[0] * world * xb.shape[2] * xb.shape[3]))
-    import ctypes
-    lib, d8 = Lb.load(), (ctypes.c_int32 * 8)()
+    lib = Lb.load()
     one_read = sum(x.numel() for x, _ in layers
-                   if lib.cnnq_pc_group_describe(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], d8) == 0 and d8[2] == 3 and d8[5] <= 128)
+                   if lib.cnnq_pc_stats_route(x.shape[0], x.shape[1], x.shape[2] * x.shape[3], 1, ops.GROUP_WS_BYTES, 0) > 0)
     frac1 = one_read * world / elems if inl else 0.
     out['config4'] = leg_object(elems, t, 8, 'ResNet-50 b%d sharded %d ways, -sm collect: the seven per-channel statistics of the GLOBAL '
                                 'batch on every rank; %s' % (per_rank * world, world, ('%.0f %% of the elements in one launch and one read of '

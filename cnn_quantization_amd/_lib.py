@@ -53,6 +53,7 @@ SIGNATURES = {
     'cnnq_pc_stats': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _P, _P]),
     'cnnq_pc_stats_single': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, ctypes.c_size_t, _P, _P, ctypes.c_uint32, _P]),
     'cnnq_pc_stats_auto': (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P, ctypes.c_size_t, _P, _P, _P]),
+    'cnnq_pc_stats_route': (_I, [_L, _L, _L, _I, ctypes.c_size_t, ctypes.c_uint32]),
     'cnnq_pc_params': (_I, [_P, _L, ctypes.POINTER(ParamsCfg), _P, _P, _P]),
     'cnnq_pc_qdq': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _I, _P]),
     'cnnq_pc_quantize_pack4': (_I, [_P, _P, _L, _L, _L, _P, _P]),

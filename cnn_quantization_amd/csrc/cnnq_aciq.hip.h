@@ -360,23 +360,24 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
     char* yb = reinterpret_cast<char*>(y) + base;
     uint8_t* cbb = (MODE == 0 && OUT == 1 && xo.codes) ? xo.codes + base / 4 : nullptr;
 
-    // ---- the tile: the first KL steps straight into LDS (LDS-DMA, issued first), then K 16-byte loads per lane, back to back
+    // ---- the tile: K 16-byte loads per lane, back to back, then the last KL steps straight into LDS (LDS-DMA).  Round 6: the
+    //      register steps first and the LDS-DMA behind the compiler's back (lds_dma16_behind, cnnq_common.hip.h) - with the
+    //      builtin in flight it waited for vmcnt(0) before the first use of any register step
     float v[K][4];
     FWalk w = w0;
-    if constexpr (KL > 0) {
-#pragma unroll
-        for (int l = 0; l < KL; ++l) {
-            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
-                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
-            w.step(g);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
         ldv_nt<4>(reinterpret_cast<const float*>(xb + off), v[j]);
         w.step(g);
+    }
+    if constexpr (KL > 0) {
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+            lds_dma16_behind(xb, off, sh_x + (l * TPB + (tid & ~63)) * 4);
+            w.step(g);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     // steps of this lane inside the channel: u + 256 s < total.  Two accumulators, the register steps and the LDS steps, each
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
     const int nvalid = u < g.total ? (int)((g.total - u + 255u) / 256u) : 0;
     double sa = 0.;
 #pragma unroll
-    for (int j = 0; j < K; ++j) absdev_step(v[j], vmean, KL + j < nvalid, sa);
+    for (int j = 0; j < K; ++j) absdev_step(v[j], vmean, j < nvalid, sa);
     if constexpr (KL > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
         double sl = 0.;
@@ -392,9 +393,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         for (int l = 0; l < KL; ++l) {
             const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
             const float t[4] = {q.x, q.y, q.z, q.w};
-            absdev_step(t, vmean, l < nvalid, sl);
+            absdev_step(t, vmean, K + l < nvalid, sl);
         }
-        sa = sl + sa;
+        sa = sa + sl;
     }
     const double msum = wg_sum1(sa, l_s);
 
@@ -424,10 +425,10 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                 const unsigned nn = ee / g.cpc;
                 float t[4];
                 ldv<4>(x + (size_t)nn * (size_t)g.P + (size_t)c * (size_t)g.HW + (size_t)(ee - nn * g.cpc) * 4, t);
-                if (s < KL) absdev_step(t, vmean, in, sl2);
+                if (s >= K) absdev_step(t, vmean, in, sl2);
                 else absdev_step(t, vmean, in, s2);
             }
-            if constexpr (KL > 0) s2 = sl2 + s2;
+            if constexpr (KL > 0) s2 = s2 + sl2;
             const double ms = wg_sum1(s2, l_s);
             if (tid == 0) __hip_atomic_store(tab + m, (unsigned long long)__double_as_longlong(ms), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -473,6 +474,13 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         unsigned nzp[1] = {0u};
         if (__builtin_amdgcn_readfirstlane((int)fast)) {
             const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp), s_qm = uniform_f(qm);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                float o[4], cd[4];
+                qdq4_fast(v[j], s_sc, s_rs, s_zp, s_qm, o, cd);
+                if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                w.step(g);
+            }
             if constexpr (KL > 0) {
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
@@ -484,14 +492,15 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                     w.step(g);
                 }
             }
+        } else {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 float o[4], cd[4];
-                qdq4_fast(v[j], s_sc, s_rs, s_zp, s_qm, o, cd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
                 if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
                 w.step(g);
             }
-        } else {
             if constexpr (KL > 0) {
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
@@ -503,14 +512,6 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                     if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
                     w.step(g);
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                float o[4], cd[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
-                if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, nullptr, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-                w.step(g);
             }
         }
         if constexpr (OUT == 1) {
@@ -558,6 +559,8 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
         };
         if (__builtin_amdgcn_readfirstlane((int)fast)) {
             const float rd = uniform_f(1.0f / d);
+#pragma unroll
+            for (int j = 0; j < K; ++j) emit(v[j], true, rd);
             if constexpr (KL > 0) {
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
@@ -566,9 +569,9 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                     emit(t, true, rd);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < K; ++j) emit(v[j], true, rd);
         } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) emit(v[j], false, 0.f);
             if constexpr (KL > 0) {
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
@@ -577,8 +580,6 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
                     emit(t, false, 0.f);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < K; ++j) emit(v[j], false, 0.f);
         }
         if constexpr (OUT == 1) {
             if (want_hist) {

@@ -183,4 +183,18 @@ __device__ __host__ __forceinline__ float qmax_of(int num_bits) { return (float)
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
+// One LDS-DMA load (16 bytes per lane: lane i of the wave lands at lds + 16 i) issued BEHIND the compiler's back.  With the
+// builtin in flight the compiler waits for vmcnt(0) before the first use of ANY loaded register (it does not count across the
+// two kinds of load), which serialises "the whole tile has landed" before the first addition.  Written as asm, issued AFTER the
+// register loads of the tile: the loads return in order, so the compiler's own counts for the register steps - it believes
+// fewer loads are in flight than there are - only ever wait longer than they must, never shorter; the reader of the LDS steps
+// waits for vmcnt(0) explicitly.  base: wave-uniform; lds: wave-uniform.
+__device__ __forceinline__ void lds_dma16_behind(const char* base, unsigned off, const float* lds) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds);
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    const unsigned long long bs = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(bs), "s"(l) : "memory", "m0");
+}
+
 }  // namespace

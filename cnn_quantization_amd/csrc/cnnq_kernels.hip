@@ -173,17 +173,16 @@ int cnnq_pc_stats(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, 
 // The same table from ONE launch that reads x once (cnnq_stats1.hip.h: the tile stays in registers across pass A and pass B,
 // the partial sums meet through the slot region of the group workspace): 4 instead of 8 bytes per element, one launch instead
 // of three.  Flat-tile plans only; CNNQ_ENOTSUP - nothing enqueued - otherwise (and for a gws that is NULL or too small): the
-// caller takes cnnq_pc_stats.  flags: bit 0 - skip the waits and recompute (tests); bit 3 - also channels of more than 128 tiles and
+// caller takes cnnq_pc_stats.  flags: bit 0 - skip the waits and recompute (tests); bit 3 - also channels of more than 256 tiles and
 // the row-piece routing that the default (0: what cnnq_pc_stats_auto passes) leaves to the chain because it loses there.
-int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,
-                         size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream) {
-    if (!x || !stats || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
-    if (!gws) return CNNQ_ENOTSUP;
+static int stats_single_impl(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,
+                             size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream, bool aligned, bool dry) {
     GPlan gp;
-    if (plan_sums(N, C, HW, al16(x), &gp, 0) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
-    // two meetings with nothing to write behind them: beyond ~128 members per channel they cost more than the second read
-    // ([512,64,112,112], 196 members: 529 us against the chain's 495; tests force it with flag 8)
-    if (gp.Gs > 128 && !(flags & 8u)) return CNNQ_ENOTSUP;
+    if (plan_sums(N, C, HW, aligned, &gp, 0) != 0 || gp.ws_bytes > gws_bytes) return CNNQ_ENOTSUP;
+    // two meetings with nothing to write behind them: with many members per channel they cost more than the second read.  Measured
+    // up to 196 members ([512,64,112,112]: 431 us against the chain's 495-560 since the arithmetic of the tile went two elements
+    // per instruction, round 6; 529 before, when the rule was 128); nothing measured beyond 256 - tests force those with flag 8
+    if (gp.Gs > ST_MAX_MEMBERS && !(flags & 8u)) return CNNQ_ENOTSUP;
     St1Args sa;
     sa.stats = stats;
     sa.mom = mom;
@@ -195,9 +194,26 @@ int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int n
         // short rows: row-piece tiles (k_stats_group), where they beat the chain (stats_group_pays: every one-channel-per-lane
         // shape, straddling rows only while the tensor is small)
         if (!(flags & 8u) && !stats_group_pays(gp, N, C, HW)) return CNNQ_ENOTSUP;
-        return launch_stats_group(x, gp, sa, gws, gws_bytes, flags & 1u, (hipStream_t)stream);
+        const int rc = launch_stats_group(x, gp, sa, gws, gws_bytes, flags & 1u, (hipStream_t)stream, nullptr, dry);
+        return (dry && rc == 0) ? 2 : rc;
     }
-    return launch_stats_flat(x, gp, sa, gws, flags & 1u, N * C * HW * 4 > NT_BYTES, (hipStream_t)stream);
+    const int rc = launch_stats_flat(x, gp, sa, gws, flags & 1u, N * C * HW * 4 > NT_BYTES, (hipStream_t)stream, nullptr, dry);
+    return (dry && rc == 0) ? 1 : rc;
+}
+
+int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* gws,
+                         size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream) {
+    if (!x || !stats || (gws && ((uintptr_t)gws & 127)) || ((uintptr_t)mom & 7)) return CNNQ_EINVAL;
+    if (!gws) return CNNQ_ENOTSUP;
+    return stats_single_impl(x, N, C, HW, need_b, need_kurt, need_relu, gws, gws_bytes, mom, stats, flags, stream, al16(x), false);
+}
+
+// Which route cnnq_pc_stats_single / _auto take for this geometry (nothing is launched): 1 - the flat-tile single launch, 2 - the
+// row-piece single launch, 0 - CNNQ_ENOTSUP there, i.e. the three-launch chain.  For accounting (bench.py prices config 4 at
+// the bytes its launches move) and for callers that want to size their expectations; negative: an error of the plan.
+int cnnq_pc_stats_route(int64_t N, int64_t C, int64_t HW, int aligned16, size_t gws_bytes, unsigned flags) {
+    const int rc = stats_single_impl(nullptr, N, C, HW, 1, 1, 1, nullptr, gws_bytes, nullptr, nullptr, flags, nullptr, aligned16 != 0, true);
+    return rc == CNNQ_ENOTSUP ? 0 : rc;
 }
 
 // cnnq_pc_stats_single when it applies, else cnnq_pc_stats: one call, the same ws
@@ -1143,7 +1159,7 @@ int cnnq_pc_midtread_fused_xrank(const float* x, float* y, int64_t N, int64_t C,
 
 // Config 4 of a batch shard: the seven statistics of the GLOBAL batch from ONE read of this rank's shard (k_stats_flat with the
 // cross-rank stage: both phases' folds exchanged inside the launch; eight slots per channel, 8 C <= cmax).  stats [CNNQ_NSTAT][C]
-// and mom [CNNQ_NMOM][C] are the global batch's on every rank.  A shard without a flat-tile plan (or with more than 128 tiles per
+// and mom [CNNQ_NMOM][C] are the global batch's on every rank.  A shard without a flat-tile plan (or with more than 256 tiles per
 // channel) runs the chain's two passes with their records made global by k_xr_moments / k_xr_devsums around the same slots -
 // four launches, no collective (ws: cnnq_pc_stats_workspace bytes).  ONE launch number per call.
 int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
@@ -1158,7 +1174,7 @@ int cnnq_pc_stats_xrank(const float* x, int64_t N, int64_t C, int64_t HW, int ne
     const int need_dev = (need_b || need_kurt) ? 1 : 0;
     GPlan gp;
     const bool planned = gws && plan_sums(N, C, HW, al16(x), &gp, 0) == 0 && gp.ws_bytes <= gws_bytes;
-    const bool single = planned && gp.flat && !gp.KL && (gp.Gs <= 128 || (flags & 8u)) &&
+    const bool single = planned && gp.flat && !gp.KL && (gp.Gs <= ST_MAX_MEMBERS || (flags & 8u)) &&
                         (size_t)gp.ngroups * gp.gstride * ST_LINE * 8 <= GRP_WS_SLOT_BYTES;
     St1Args sa;
     sa.stats = stats;

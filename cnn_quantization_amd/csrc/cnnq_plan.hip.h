@@ -587,11 +587,12 @@ int launch_fused(int mode, const float* x, float* y, const GPlan& p, const Fused
 
 // the single-read statistics kernel (cnnq_stats1.hip.h) on a flat plan and the workspace of launch_group
 int launch_stats_flat(const float* x, const GPlan& p, const St1Args& sa, void* ws, unsigned flags, bool ntl, hipStream_t st,
-                      const XRank* xrp = nullptr) {
+                      const XRank* xrp = nullptr, bool dry = false) {
     const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: both phases' folds exchanged inside the launch
     const XRank xr = xrank ? *xrp : XRank{};
     if (!p.flat || p.KL) return CNNQ_ENOTSUP;
     if ((size_t)p.ngroups * p.gstride * ST_LINE * 8 > GRP_WS_SLOT_BYTES) return CNNQ_ENOTSUP;
+    if (dry) return 0;                                 // cnnq_pc_stats_route: the checks alone
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);
@@ -628,7 +629,7 @@ inline bool stats_group_pays(const GPlan& p, int64_t N, int64_t C, int64_t HW) {
 }
 
 int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* ws, size_t ws_bytes, unsigned flags, hipStream_t st,
-                       const XRank* xrp = nullptr) {
+                       const XRank* xrp = nullptr, bool dry = false) {
     const bool xrank = xrp && xrp->world > 0;          // the batch is sharded: both phases' folds exchanged inside the launch
     const XRank xr = xrank ? *xrp : XRank{};
     if (p.flat) return CNNQ_ENOTSUP;
@@ -637,6 +638,8 @@ int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* 
     if (kk > MAXCH || words >= (int64_t)1 << 30) return CNNQ_ENOTSUP;
     const size_t bytes = (size_t)p.ngroups * (size_t)words * 8;
     if (bytes > GRP_WS_SLOT_BYTES || GRP_WS_PAIRS + bytes > ws_bytes) return CNNQ_ENOTSUP;
+    if (p.v.A == 4 && p.K == 32) return CNNQ_ENOTSUP;      // plan_sums never plans it (no such instance: it spilled)
+    if (dry) return 0;
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);
     w.cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + GRP_WS_HDR);

@@ -69,6 +69,80 @@ struct Mom {
             rss += (double)((r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3));
         }
     }
+    // EIGHT values of one channel (two float4 of a register tile; the single-read kernels of cnnq_stats1.hip.h): the 8-sums in
+    // fp32 TWO ELEMENTS PER INSTRUCTION (v_pk_add_f32 / v_pk_mul_f32: pairs (0,1) + (2,3) of a, then of b, the two halves added
+    // last), min / max as v_min3 / v_max3 on the raw registers (fminf makes the compiler canonicalise every loaded value first:
+    // one more instruction per element) - 6 instead of 9.5 instructions per element, which matters where a kernel has to hide
+    // its arithmetic behind 4 bytes per element.  add4p: a alone - the bits add8 gives with b absent.  (Only for fully unrolled
+    // tile loops: HIP treats inline asm as convergent, and a loop with a run-time trip count that contains it - the row loop of
+    // k_moments - is no longer unrolled.  add4 therefore keeps fminf / fmaxf.)
+    static __device__ __forceinline__ float min3_raw(float a, float b, float c) {
+        float r;
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    static __device__ __forceinline__ float max3_raw(float a, float b, float c) {
+        float r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    static __device__ __forceinline__ float relu_raw(float a) {      // fmaxf(a, 0.f): 0 for a NaN, as there
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+        return r;
+    }
+    // the two halves of a packed sum, one plain add (written out: left to itself the compiler packs the horizontal adds of two
+    // different sums into one v_pk_add_f32 behind three register moves)
+    template <class F2>
+    static __device__ __forceinline__ float hadd(const F2 p) {
+        float r;
+        asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(p.x), "v"(p.y));
+        return r;
+    }
+    static __device__ __forceinline__ float abs_add(float a, float b) {      // |a| + |b|, one instruction
+        float r;
+        asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void add8(const float (&a)[4], const float (&b)[4]) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        mn = min3_raw(min3_raw(mn, a[0], a[1]), a[2], a[3]);
+        mn = min3_raw(min3_raw(mn, b[0], b[1]), b[2], b[3]);
+        mx = max3_raw(max3_raw(mx, a[0], a[1]), a[2], a[3]);
+        mx = max3_raw(max3_raw(mx, b[0], b[1]), b[2], b[3]);
+        const f2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]}, b0 = {b[0], b[1]}, b1 = {b[2], b[3]};
+        const f2 ps = ((a0 + a1) + b0) + b1;
+        s += (double)hadd(ps);
+        const f2 pq = ((a0 * a0 + a1 * a1) + b0 * b0) + b1 * b1;
+        ss += (double)hadd(pq);
+        if constexpr (RELU) {
+            const f2 r0 = {relu_raw(a[0]), relu_raw(a[1])}, r1 = {relu_raw(a[2]), relu_raw(a[3])};
+            const f2 r2 = {relu_raw(b[0]), relu_raw(b[1])}, r3 = {relu_raw(b[2]), relu_raw(b[3])};
+            const f2 pr = ((r0 + r1) + r2) + r3;
+            rs += (double)hadd(pr);
+            const f2 pp = ((r0 * r0 + r1 * r1) + r2 * r2) + r3 * r3;
+            rss += (double)hadd(pp);
+        }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void add4p(const float (&a)[4]) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        mn = min3_raw(min3_raw(mn, a[0], a[1]), a[2], a[3]);
+        mx = max3_raw(max3_raw(mx, a[0], a[1]), a[2], a[3]);
+        const f2 a0 = {a[0], a[1]}, a1 = {a[2], a[3]};
+        const f2 ps = a0 + a1;
+        s += (double)hadd(ps);
+        const f2 pq = a0 * a0 + a1 * a1;
+        ss += (double)hadd(pq);
+        if constexpr (RELU) {
+            const f2 r0 = {relu_raw(a[0]), relu_raw(a[1])}, r1 = {relu_raw(a[2]), relu_raw(a[3])};
+            const f2 pr = r0 + r1;
+            rs += (double)hadd(pr);
+            const f2 pp = r0 * r0 + r1 * r1;
+            rss += (double)hadd(pp);
+        }
+    }
     template <bool RELU>
     __device__ __forceinline__ void merge(const Mom& o) {
         mn = pmin(mn, o.mn);

@@ -38,6 +38,7 @@ constexpr int ST_W2 = 2;     // phase-2 words: sum |x - mean|, sum z^4
 constexpr int ST_LINE = 8;   // words per member line (64 bytes: one store instruction of lanes 0..4 covers a phase's words)
 constexpr int ST_XW_COUNT = 5;   // cross-rank words of phase 1 (XR): 0..4 as above, 5 the rank's element count; phase 2: 6, 7
 constexpr int ST_XW = 8;         // slots per channel a sharded launch uses
+constexpr int ST_MAX_MEMBERS = 256;      // tiles per channel up to which the single launch is routed by default (cnnq_pc_stats_single)
 
 struct St1Args {
     float* stats;            // [CNNQ_NSTAT][C] out: every row
@@ -147,7 +148,7 @@ struct StWords {
     unsigned long long w[ST_W1];
 };
 
-// KR steps of the tile in registers, the first KL in LDS (LDS-DMA: no staging registers) - the 128 KB tile is 24 + 8: with
+// KR steps of the tile in registers, the last KL in LDS (LDS-DMA: no staging registers) - the 128 KB tile is 24 + 8: with
 // all 32 steps in registers next to the accumulators of two phases the allocator spilled six of them
 template <int KR, int KL, bool RELU, bool NTL, bool XR = false>
 __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_stats_flat(const float* __restrict__ x, const FGeo g, const GWs ws,
@@ -188,21 +189,22 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
     const unsigned long long lim64 = (unsigned long long)((unsigned)g.N - n_first) * g.rs;
     const unsigned lim = lim64 > 0xffffffffull ? 0xffffffffu : (unsigned)lim64;
     const char* xb = reinterpret_cast<const char*>(x) + ((size_t)n_first * (size_t)g.P + (size_t)c * (size_t)g.HW) * 4;
+    //      (round 6: the register steps FIRST - with LDS-DMA loads issued before them the compiler waits for vmcnt(0) at the first
+    //      use of any register step; behind them the pairs of phase 1 start as their own loads land)
     float v[KR][4];
-    if constexpr (KL > 0) {
-#pragma unroll
-        for (int l = 0; l < KL; ++l) {
-            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
-                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
-            w.step(g);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < KR; ++j) {
         const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
         ldv_sel<4, NTL>(reinterpret_cast<const float*>(xb + off), v[j]);
         w.step(g);
+    }
+    if constexpr (KL > 0) {
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+            lds_dma16_behind(xb, off, sh_x + (l * TPB + (tid & ~63)) * 4);
+            w.step(g);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     const int nvalid = u < g.total ? (int)((g.total - u + 255u) / 256u) : 0;
@@ -262,21 +264,26 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
     //      (the order of the additions does not depend on what landed first; the cold path does the same)
     Mom acc;
     acc.init();
+    //      Round 6: the steps go in PAIRS through Mom::add8 (two elements per instruction; a lone last step through add4p)
+    static_assert(KR % 2 == 0 && KL % 2 == 0, "steps in pairs");
 #pragma unroll
-    for (int j = 0; j < KR; ++j)
-        if (KL + j < nvalid) acc.template add4<RELU>(v[j]);
+    for (int j = 0; j < KR; j += 2) {
+        if (j + 1 < nvalid) acc.template add8<RELU>(v[j], v[j + 1]);
+        else if (j < nvalid) acc.template add4p<RELU>(v[j]);
+    }
     if constexpr (KL > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
         Mom al;
         al.init();
 #pragma unroll
-        for (int l = 0; l < KL; ++l) {
+        for (int l = 0; l < KL; l += 2) {
             const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
-            const float t[4] = {q.x, q.y, q.z, q.w};
-            if (l < nvalid) al.template add4<RELU>(t);
+            const float4 q1 = *reinterpret_cast<const float4*>(sh_x + ((l + 1) * TPB + tid) * 4);
+            const float t[4] = {q.x, q.y, q.z, q.w}, t1[4] = {q1.x, q1.y, q1.z, q1.w};
+            if (KR + l + 1 < nvalid) al.template add8<RELU>(t, t1);
+            else if (KR + l < nvalid) al.template add4p<RELU>(t);
         }
-        al.template merge<true>(acc);
-        acc = al;
+        acc.template merge<true>(al);
     }
     StWords sw;
     reduce1(acc, sw);
@@ -299,25 +306,29 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             Mom a2, al2;
             a2.init();
             al2.init();
-            for (int s = 0; s < K; ++s) {
-                float t[4];
-                bool in;
+            for (int s = 0; s < K; s += 2) {
+                float t[4], t1[4];
+                bool in, in1;
                 cold_load(m, s, t, in);
-                if (in) {
-                    if (s < KL) al2.template add4<RELU>(t);
-                    else a2.template add4<RELU>(t);
+                cold_load(m, s + 1, t1, in1);
+                if (in1) {
+                    if (s >= KR) al2.template add8<RELU>(t, t1);
+                    else a2.template add8<RELU>(t, t1);
+                } else if (in) {
+                    if (s >= KR) al2.template add4p<RELU>(t);
+                    else a2.template add4p<RELU>(t);
                 }
             }
-            if constexpr (KL > 0) {
-                al2.template merge<true>(a2);
-                a2 = al2;
-            }
+            if constexpr (KL > 0) a2.template merge<true>(al2);
             StWords s2;
             reduce1(a2, s2);
             st_fold_add(fold, m, s2.w, NW1, true);
         }
         st_fold_finish(fold, NW1, true, sh_out, sh_mm);
         __syncthreads();
+        // the tile is dead on this path (phase 2 recomputes too): say so, and its registers serve the loop above
+#pragma unroll
+        for (int j = 0; j < KR; ++j) { v[j][0] = 0.f; v[j][1] = 0.f; v[j][2] = 0.f; v[j][3] = 0.f; }
     }
     if constexpr (XR) {
         // the batch is sharded: lane w of wave 0 exchanges word w of the rank's fold with the other ranks (word 0: the pair; 1 ..
@@ -358,15 +369,26 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
     if (sa.need_dev) {
         // ---- phase 2 (k_absdev's arithmetic: fp32 difference, reciprocal of the std, fp64 sums)
         const float isd = sa.need_kurt ? 1.f / sd : 0.f;
-        auto dev4 = [&](const float (&t)[4], double& a, double& k4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = t[e] - mean;
-                a += (double)fabsf(d);
-                const float z = d * isd;
-                const float z2 = z * z;
-                k4 += (double)(z2 * z2);
-            }
+        // per element k_absdev's arithmetic; round 6: the sums of a pair of steps in fp32, two elements per instruction (as add8),
+        // one fp64 addition per eight elements and sum - 3.75 instead of 8 instructions per element
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 m2 = {mean, mean}, i2 = {isd, isd};
+        auto dev8 = [&](const float (&t)[4], const float (&t1)[4], double& a, double& k4) {
+            const f2 d0 = f2{t[0], t[1]} - m2, d1 = f2{t[2], t[3]} - m2, d2 = f2{t1[0], t1[1]} - m2, d3 = f2{t1[2], t1[3]} - m2;
+            const f2 ab = f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)} + f2{Mom::abs_add(d2.x, d2.y), Mom::abs_add(d3.x, d3.y)};
+            a += (double)Mom::hadd(ab);
+            f2 z0 = d0 * i2, z1 = d1 * i2, z2 = d2 * i2, z3 = d3 * i2;
+            z0 = z0 * z0; z1 = z1 * z1; z2 = z2 * z2; z3 = z3 * z3;
+            const f2 q = ((z0 * z0 + z1 * z1) + z2 * z2) + z3 * z3;
+            k4 += (double)Mom::hadd(q);
+        };
+        auto dev4p = [&](const float (&t)[4], double& a, double& k4) {
+            const f2 d0 = f2{t[0], t[1]} - m2, d1 = f2{t[2], t[3]} - m2;
+            a += (double)Mom::hadd(f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)});
+            f2 z0 = d0 * i2, z1 = d1 * i2;
+            z0 = z0 * z0; z1 = z1 * z1;
+            const f2 q = z0 * z0 + z1 * z1;
+            k4 += (double)Mom::hadd(q);
         };
         // Round 6: nobody WAITS for the second meeting any more.  A member publishes its two words and counts its arrival; whoever
         // arrives LAST - every other member's words are out by then - folds them (member order), exchanges them with the other
@@ -379,18 +401,22 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             // below like everybody's - so its registers are free there: the recompute code next to a live tile spilled it.)
             double da = 0., dk = 0.;
 #pragma unroll
-            for (int j = 0; j < KR; ++j)
-                if (KL + j < nvalid) dev4(v[j], da, dk);
+            for (int j = 0; j < KR; j += 2) {
+                if (j + 1 < nvalid) dev8(v[j], v[j + 1], da, dk);
+                else if (j < nvalid) dev4p(v[j], da, dk);
+            }
             if constexpr (KL > 0) {
                 double la = 0., lk = 0.;
 #pragma unroll
-                for (int l = 0; l < KL; ++l) {
+                for (int l = 0; l < KL; l += 2) {
                     const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
-                    const float t[4] = {q.x, q.y, q.z, q.w};
-                    if (l < nvalid) dev4(t, la, lk);
+                    const float4 q1 = *reinterpret_cast<const float4*>(sh_x + ((l + 1) * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w}, t1[4] = {q1.x, q1.y, q1.z, q1.w};
+                    if (KR + l + 1 < nvalid) dev8(t, t1, la, lk);
+                    else if (KR + l < nvalid) dev4p(t, la, lk);
                 }
-                da = la + da;
-                dk = lk + dk;
+                da = da + la;
+                dk = dk + lk;
             }
             reduce2(da, dk, sw);
             encode(sw, ST_W2, false);
@@ -401,18 +427,22 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
             fold.init();
             for (int m = 0; m < g.Gs; ++m) {
                 double a2 = 0., k2 = 0., la2 = 0., lk2 = 0.;
-                for (int s = 0; s < K; ++s) {
-                    float t[4];
-                    bool in;
+                for (int s = 0; s < K; s += 2) {
+                    float t[4], t1[4];
+                    bool in, in1;
                     cold_load(m, s, t, in);
-                    if (in) {
-                        if (s < KL) dev4(t, la2, lk2);
-                        else dev4(t, a2, k2);
+                    cold_load(m, s + 1, t1, in1);
+                    if (in1) {
+                        if (s >= KR) dev8(t, t1, la2, lk2);
+                        else dev8(t, t1, a2, k2);
+                    } else if (in) {
+                        if (s >= KR) dev4p(t, la2, lk2);
+                        else dev4p(t, a2, k2);
                     }
                 }
                 if constexpr (KL > 0) {
-                    a2 = la2 + a2;
-                    k2 = lk2 + k2;
+                    a2 = a2 + la2;
+                    k2 = k2 + lk2;
                 }
                 StWords s2;
                 reduce2(a2, k2, s2);

@@ -253,7 +253,7 @@ class XRankExchange:
             ok = ok and bool(torch.equal(ref, got))
         # ... and the SUMS (round 6): the seven statistics of the global batch through the windows (eight words per channel; a
         # flat-tile shard and one without a plan) against the chain around the collective - extrema and count exact, the sums
-        # within the tier of two orders of fp64 additions
+        # within the tier of fp32 sums of 8 (the single launch) against sums of 4 (the chain) accumulated in fp64
         from . import _lib as L
         for (n, c, h, w) in ((40, 6, 56, 56), (37, 24, 14, 14)):
             x = torch.randn((n, c, h, w), generator=g, device=self.device) * (1 + self.rank) - 0.3
@@ -266,7 +266,7 @@ class XRankExchange:
             mom_local, _ = ops.pc_combine(part, True)
             mom_ref, st_ref = ops.pc_combine(all_gather_records(mom_local, self.group), True)
             ok = ok and bool(torch.equal(st[:2], st_ref[:2])) and bool(torch.equal(mom[L.MOM_COUNT], mom_ref[L.MOM_COUNT]))
-            ok = ok and bool(torch.allclose(st[2:4], st_ref[2:4], rtol=1e-5, atol=1e-6)) and bool(torch.allclose(mom[2:4], mom_ref[2:4], rtol=1e-9, atol=1e-6))
+            ok = ok and bool(torch.allclose(st[2:4], st_ref[2:4], rtol=1e-5, atol=1e-6)) and bool(torch.allclose(mom[2:4], mom_ref[2:4], rtol=1e-6, atol=1e-3))
             ok = ok and bool(torch.isfinite(st[L.STAT_B]).all()) and bool((st[L.STAT_B] > 0).all())
         return self._all_agree(ok and self.healthy())
 

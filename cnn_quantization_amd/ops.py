@@ -346,7 +346,7 @@ def _mid_tread_qdq_xrank(x, N, C, HW, target, sym, tabs_mt, group, want_entropy,
 
 def pc_stats_single(x, N, C, HW, need_b=False, need_kurt=False, need_relu=False, flags=8):
     """The statistics table and the merged moment record from ONE launch that reads x once (cnnq_pc_stats_single), or None
-    when the shape has no flat-tile plan.  flags: bit 3 (default here) also takes channels of more than 128 tiles, which
+    when the shape has no flat-tile plan.  flags: bit 3 (default here) also takes channels of more than 256 tiles, which
     ops.pc_stats leaves to the chain; bit 0 forces the recompute path (tests)."""
     lib = L.load()
     x = _dev_f32(x, 'x')

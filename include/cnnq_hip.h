@@ -135,7 +135,7 @@ int cnnq_pc_absdev(const float* x, int64_t N, int64_t C, int64_t HW, const float
  * additions (round 6: nobody waits for the second exchange - the workgroup that arrives LAST folds it, writes the channel's row
  * and re-arms the slots; the others leave after publishing their words).  Flat-tile geometries (H*W % 4 == 0, H*W / 4 >= 128 and not a multiple of 256, 2 .. 512 tiles per channel), and
  * the row-piece tiles of cnnq_pc_minmax_qdq_group for shorter rows (k_stats_group).  CNNQ_ENOTSUP where the chain is faster:
- * more than 128 tiles per channel, row-piece geometries whose channels straddle the 16-byte loads (7x7) above 8 MB (flags
+ * more than 256 tiles per channel, row-piece geometries whose channels straddle the 16-byte loads (7x7) above 8 MB (flags
  * bit 3 lifts these two rules: tests), and where there is no 16-byte tiling at all.  (Round 6: every one-channel-per-lane
  * row-piece shape with a plan is taken - at a 64-sample shard the one launch of 20-45 us beats three launches and two merges.)
  * flags: 0 (tests: 1 = skip the waits and recompute).  cnnq_pc_stats_auto: this when it applies,
@@ -144,6 +144,10 @@ int cnnq_pc_stats_single(const float* x, int64_t N, int64_t C, int64_t HW, int n
                          size_t gws_bytes, double* mom, float* stats, unsigned flags, void* stream);
 int cnnq_pc_stats_auto(const float* x, int64_t N, int64_t C, int64_t HW, int need_b, int need_kurt, int need_relu, void* ws, void* gws,
                        size_t gws_bytes, double* mom, float* stats, void* stream);
+/* The route cnnq_pc_stats_single (flags as there) / cnnq_pc_stats_auto (flags 0) take for a geometry, without launching anything:
+ * 1 - the flat-tile single launch, 2 - the row-piece single launch, 0 - the three-launch chain (cnnq_pc_stats_single would answer
+ * CNNQ_ENOTSUP).  aligned16: x is 16-byte aligned; gws_bytes: the exchange workspace the caller holds (cnnq_pc_group_workspace). */
+int cnnq_pc_stats_route(int64_t N, int64_t C, int64_t HW, int aligned16, size_t gws_bytes, unsigned flags);
 
 /* Merge pass-B records; divides by the COUNT row of `mom` and writes stats rows B (and KURT).
  * `dev_out` (merged [CNNQ_NDEV][C] sums, for the cross-rank exchange) may be NULL, and

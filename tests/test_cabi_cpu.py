@@ -113,6 +113,24 @@ def test_geometry_plan_covers_resnet50_shapes():
             assert 0 < g <= 64 * 8192, (N, C, HW, al, g)
 
 
+def test_stats_route_names_the_kernel_family_without_a_device():
+    """cnnq_pc_stats_route (round 6): which of the three routes the seven statistics take for a geometry - the planner's answer,
+    no device needed.  ResNet-50 at batch 512: flat tiles up to 256 members per channel (112x112: 196), row pieces for
+    one-channel-per-lane rows (14x14), the chain for the large 7x7 tensors (at the 64-sample shard the small 7x7 one is a row-piece launch too) and for
+    shapes without a 16-byte tiling."""
+    from cnn_quantization_amd import _lib as L
+    lib = L.load()
+    ws = 18 << 20
+    want = {(512, 64, 112 * 112): 1, (512, 256, 56 * 56): 1, (512, 512, 28 * 28): 1, (512, 1024, 14 * 14): 2, (512, 256, 14 * 14): 2,
+            (512, 2048, 7 * 7): 0, (512, 512, 7 * 7): 0, (64, 512, 7 * 7): 2, (64, 2048, 7 * 7): 0, (512, 64, 224 * 224): 0,
+            (3, 16, 5 * 9): 2, (3, 5, 7 * 9): 0}
+    for (N, C, HW), r in want.items():
+        assert lib.cnnq_pc_stats_route(N, C, HW, 1, ws, 0) == r, (N, C, HW)
+    assert lib.cnnq_pc_stats_route(512, 512, 49, 1, ws, 8) == 2         # flags bit 3 (tests) lifts the size rule
+    assert lib.cnnq_pc_stats_route(512, 256, 56 * 56, 1, 1 << 20, 0) == 0     # a workspace too small for the plan: the chain
+    assert lib.cnnq_pc_stats_route(512, 256, 56 * 56, 0, ws, 0) == 0        # no 16-byte alignment, no 16-byte tiling
+
+
 def test_no_cpu_fallback():
     from cnn_quantization_amd import ops, int_quantization
     from cnn_quantization_amd._lib import CnnqError
