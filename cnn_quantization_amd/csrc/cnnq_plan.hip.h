@@ -639,6 +639,7 @@ int launch_stats_group(const float* x, const GPlan& p, const St1Args& sa, void* 
     const size_t bytes = (size_t)p.ngroups * (size_t)words * 8;
     if (bytes > GRP_WS_SLOT_BYTES || GRP_WS_PAIRS + bytes > ws_bytes) return CNNQ_ENOTSUP;
     if (p.v.A == 4 && p.K == 32) return CNNQ_ENOTSUP;      // plan_sums never plans it (no such instance: it spilled)
+    if (p.K == 32 && (int64_t)p.g.P * 4 * 32 >= ((int64_t)1 << 32)) return CNNQ_ENOTSUP;     // the LDS rows' 32-bit offsets from the tile's base
     if (dry) return 0;
     GWs w;
     w.status = reinterpret_cast<unsigned*>(ws);

@@ -530,8 +530,8 @@ struct SgAcc {
             if constexpr (RELU) { rs[a] = 0.; rss[a] = 0.; }
         }
     }
-    // one float4 of the lane's column: A == 1 - four values of one channel (Mom::add4: the 4-sums in fp32); A == 4 - one
-    // value for each of four accumulator sets (Mom::add)
+    // one float4 of the lane's column: A == 4 - one value for each of four accumulator sets (Mom::add); (A == 1 - four values of
+    // one channel as Mom::add4 - is no longer used by the kernel: its rows go in pairs, below)
     __device__ __forceinline__ void add(const float (&v)[4]) {
         if constexpr (A == 1) {
             mn[0] = fminf(fminf(mn[0], fminf(v[0], v[1])), fminf(v[2], v[3]));
@@ -557,6 +557,34 @@ struct SgAcc {
                     rss[e] = fma(r, r, rss[e]);
                 }
             }
+        }
+    }
+    // A == 1, round 6: a PAIR of float4 (two rows of the tile) as Mom::add8, a lone last row as Mom::add4p - two elements per
+    // instruction, one fp64 addition per eight elements and sum
+    __device__ __forceinline__ void add8(const float (&a)[4], const float (&b)[4]) {
+        static_assert(A == 1, "one channel per lane");
+        Mom m;
+        m.mn = mn[0]; m.mx = mx[0]; m.s = s[0]; m.ss = ss[0]; m.rs = RELU ? rs[0] : 0.; m.rss = RELU ? rss[0] : 0.;
+        m.template add8<RELU>(a, b);
+        mn[0] = m.mn; mx[0] = m.mx; s[0] = m.s; ss[0] = m.ss;
+        if constexpr (RELU) { rs[0] = m.rs; rss[0] = m.rss; }
+    }
+    __device__ __forceinline__ void add4p(const float (&a)[4]) {
+        static_assert(A == 1, "one channel per lane");
+        Mom m;
+        m.mn = mn[0]; m.mx = mx[0]; m.s = s[0]; m.ss = ss[0]; m.rs = RELU ? rs[0] : 0.; m.rss = RELU ? rss[0] : 0.;
+        m.template add4p<RELU>(a);
+        mn[0] = m.mn; mx[0] = m.mx; s[0] = m.s; ss[0] = m.ss;
+        if constexpr (RELU) { rs[0] = m.rs; rss[0] = m.rss; }
+    }
+    // rows r and r + 1 of a tile of nr rows (the pair is whole, or its first row is the tile's last, or it lies past the tile)
+    __device__ __forceinline__ void add_rows(const float (&t0)[4], const float (&t1)[4], int r, int nr) {
+        if constexpr (A == 1) {
+            if (r + 1 < nr) add8(t0, t1);
+            else if (r < nr) add4p(t0);
+        } else {
+            if (r < nr) add(t0);
+            if (r + 1 < nr) add(t1);
         }
     }
     __device__ __forceinline__ void poison() {          // A == 1: v_min / v_max dropped a NaN; the sum of squares tells
@@ -698,40 +726,41 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
     const int NPK = SG_NP * kk;
     if (tid == 0) sh_code = ((flags & MMQ_FLAG_TEST_HOOK) ? 2 : 0) | ((st0 & 1u) ? 4 : 0);
 
-    // ---- the tile: K 16-byte loads per lane back to back, the first KL of them straight into LDS
+    // ---- the tile: K 16-byte loads per lane back to back, the LAST KL of them straight into LDS (as asm behind the register
+    //      loads: lds_dma16_behind - the pairs of phase 1 start as their own loads land)
+    static_assert(KR % 2 == 0 && KL % 2 == 0, "rows in pairs");
     float v[KR][4];
-    if constexpr (KL > 0) {
-#pragma unroll
-        for (int l = 0; l < KL; ++l) {
-            const int r = l < nrows ? l : nrows - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + base + (size_t)r * (size_t)g.P),
-                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < KR; ++j) {
-        const int r = KL + j < nrows ? KL + j : nrows - 1;
+        const int r = j < nrows ? j : nrows - 1;
         ldv_nt<4>(x + base + (size_t)r * (size_t)g.P, v[j]);
+    }
+    if constexpr (KL > 0) {
+        // (tiles with LDS rows are one-channel-per-lane tiles of whole K-row splits or less: offsets fit 32 bits from the tile's base)
+        const char* xt = reinterpret_cast<const char*>(x + (size_t)b.n0 * (size_t)g.P);
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const int r = KR + l < nrows ? KR + l : nrows - 1;
+            lds_dma16_behind(xt, (unsigned)(((size_t)r * (size_t)g.P + (size_t)colc * 4) * 4), sh_x + (l * TPB + (tid & ~63)) * 4);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- phase 1, rows in order (LDS rows first: they were issued first)
+    // ---- phase 1, rows in order and in pairs (SgAcc::add_rows)
     SgAcc<A, RELU> ac;
     ac.init();
+#pragma unroll
+    for (int j = 0; j < KR; j += 2) ac.add_rows(v[j], v[j + 1], j, nrows);
     if constexpr (KL > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
 #pragma unroll
-        for (int l = 0; l < KL; ++l) {
-            if (l < nrows) {
-                const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
-                const float t[4] = {q.x, q.y, q.z, q.w};
-                ac.add(t);
-            }
+        for (int l = 0; l < KL; l += 2) {
+            const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+            const float4 q1 = *reinterpret_cast<const float4*>(sh_x + ((l + 1) * TPB + tid) * 4);
+            const float t[4] = {q.x, q.y, q.z, q.w}, t1[4] = {q1.x, q1.y, q1.z, q1.w};
+            ac.add_rows(t, t1, KR + l, nrows);
         }
     }
-#pragma unroll
-    for (int j = 0; j < KR; ++j)
-        if (KL + j < nrows) ac.add(v[j]);
     sg_reduce1<A, RELU>(g, b, ok, ac, l_a, sh_mn, sh_mx, sh_q);
 
     // a member's tile from x again (the cold path), with that member's own lane mapping
@@ -742,11 +771,12 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         const int mrows = mb.b.n1 - mb.b.n0;
         SgAcc<A, RELU> a2;
         a2.init();
-        for (int jj = 0; jj < K; ++jj) {
-            float t[4];
-            const int r = jj < mrows ? jj : mrows - 1;
+        for (int jj = 0; jj < K; jj += 2) {
+            float t[4], t1[4];
+            const int r = jj < mrows ? jj : mrows - 1, r1 = jj + 1 < mrows ? jj + 1 : mrows - 1;
             ldv<4>(x + ((size_t)(mb.b.n0 + r) * (size_t)g.P + (size_t)mcolc * 4), t);
-            if (jj < mrows) a2.add(t);
+            ldv<4>(x + ((size_t)(mb.b.n0 + r1) * (size_t)g.P + (size_t)mcolc * 4), t1);
+            a2.add_rows(t, t1, jj, mrows);
         }
         sg_reduce1<A, RELU>(g, mb.b, mok, a2, l_a, sh_mn, sh_mx, sh_q);
     };
@@ -855,6 +885,34 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 dk[a] += (double)(z2 * z2);
             }
         };
+        // rows r and r + 1 of a tile of nr rows: A == 1 - the pair's sums in fp32, two elements per instruction (k_stats_flat's
+        // dev8 / dev4p); A == 4 - row by row
+        auto dev_rows = [&](const float (&t0)[4], const float (&t1)[4], int r, int nr, const float (&mean)[A], const float (&isd)[A],
+                            double (&da)[A], double (&dk)[A]) {
+            if constexpr (A == 1) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 m2 = {mean[0], mean[0]}, i2 = {isd[0], isd[0]};
+                if (r + 1 < nr) {
+                    const f2 d0 = f2{t0[0], t0[1]} - m2, d1 = f2{t0[2], t0[3]} - m2, d2 = f2{t1[0], t1[1]} - m2, d3 = f2{t1[2], t1[3]} - m2;
+                    const f2 ab = f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)} + f2{Mom::abs_add(d2.x, d2.y), Mom::abs_add(d3.x, d3.y)};
+                    da[0] += (double)Mom::hadd(ab);
+                    f2 z0 = d0 * i2, z1 = d1 * i2, z2 = d2 * i2, z3 = d3 * i2;
+                    z0 = z0 * z0; z1 = z1 * z1; z2 = z2 * z2; z3 = z3 * z3;
+                    const f2 q = ((z0 * z0 + z1 * z1) + z2 * z2) + z3 * z3;
+                    dk[0] += (double)Mom::hadd(q);
+                } else if (r < nr) {
+                    const f2 d0 = f2{t0[0], t0[1]} - m2, d1 = f2{t0[2], t0[3]} - m2;
+                    da[0] += (double)Mom::hadd(f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)});
+                    f2 z0 = d0 * i2, z1 = d1 * i2;
+                    z0 = z0 * z0; z1 = z1 * z1;
+                    const f2 q = z0 * z0 + z1 * z1;
+                    dk[0] += (double)Mom::hadd(q);
+                }
+            } else {
+                if (r < nr) dev_add(t0, mean, isd, da, dk);
+                if (r + 1 < nr) dev_add(t1, mean, isd, da, dk);
+            }
+        };
         auto reduce2 = [&](const Blk& bb, bool bok, const double (&da)[A], const double (&dk)[A]) {
             wg_channel_sums<A>(g, bb, bok, da, l_a, sh_q);
             wg_channel_sums<A>(g, bb, bok, dk, l_a, sh_q + MAXCH);
@@ -877,19 +935,17 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 da[a] = 0.;
                 dk[a] = 0.;
             }
+#pragma unroll
+            for (int j = 0; j < KR; j += 2) dev_rows(v[j], v[j + 1], j, nrows, mean, isd, da, dk);
             if constexpr (KL > 0) {
 #pragma unroll
-                for (int l = 0; l < KL; ++l) {
-                    if (l < nrows) {
-                        const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
-                        const float t[4] = {q.x, q.y, q.z, q.w};
-                        dev_add(t, mean, isd, da, dk);
-                    }
+                for (int l = 0; l < KL; l += 2) {
+                    const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                    const float4 q1 = *reinterpret_cast<const float4*>(sh_x + ((l + 1) * TPB + tid) * 4);
+                    const float t[4] = {q.x, q.y, q.z, q.w}, t1[4] = {q1.x, q1.y, q1.z, q1.w};
+                    dev_rows(t, t1, KR + l, nrows, mean, isd, da, dk);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < KR; ++j)
-                if (KL + j < nrows) dev_add(v[j], mean, isd, da, dk);
             reduce2(b, ok, da, dk);
             emit(lines + (size_t)rb.member * NPK, 5, 2);
         } else {
@@ -909,11 +965,12 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                     da[a] = 0.;
                     dk[a] = 0.;
                 }
-                for (int jj = 0; jj < K; ++jj) {
-                    float t[4];
-                    const int r = jj < mrows ? jj : mrows - 1;
+                for (int jj = 0; jj < K; jj += 2) {
+                    float t[4], t1[4];
+                    const int r = jj < mrows ? jj : mrows - 1, r1 = jj + 1 < mrows ? jj + 1 : mrows - 1;
                     ldv<4>(x + ((size_t)(mb.b.n0 + r) * (size_t)g.P + (size_t)mcolc * 4), t);
-                    if (jj < mrows) dev_add(t, mean, isd, da, dk);
+                    ldv<4>(x + ((size_t)(mb.b.n0 + r1) * (size_t)g.P + (size_t)mcolc * 4), t1);
+                    dev_rows(t, t1, jj, mrows, mean, isd, da, dk);
                 }
                 reduce2(mb.b, mok, da, dk);
                 emit(tab + (size_t)m * NPK, 5, 2);

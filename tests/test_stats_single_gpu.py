@@ -151,7 +151,11 @@ def check_statistics(ops, shape, need):
     finally:
         ops.reload_switches()
     assert bits_equal(st[:2].cpu(), st0[:2].cpu())
-    np.testing.assert_allclose(st.cpu()[:, live], st0.cpu()[:, live], rtol=2e-6, atol=2e-6)
+    # (every row but the kurtosis at the tier of two summation orders; the kurtosis moves by ~4 ulp(std) * (kurt + 3) with the last
+    #  bit of the fp32 std it divides by - the single launch sums squares in fp32 groups of 8, the chain in groups of 4)
+    rows = [r for r in range(L.NSTAT) if r != L.STAT_KURT]
+    np.testing.assert_allclose(st.cpu()[rows][:, live], st0.cpu()[rows][:, live], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(st.cpu()[L.STAT_KURT][live], st0.cpu()[L.STAT_KURT][live], rtol=2e-5, atol=2e-5)
     assert ops.group_status(xd) == 0
 
 
