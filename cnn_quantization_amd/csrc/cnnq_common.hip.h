@@ -183,6 +183,40 @@ __device__ __host__ __forceinline__ float qmax_of(int num_bits) { return (float)
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
+// Instructions written out (round 6).  v_min3 / v_max3 / v_max on the RAW registers: fminf / fmaxf make the compiler canonicalise
+// every loaded value first (a v_max v, v, v per element); for numbers the results are the same, a quiet NaN operand is dropped
+// like fminf drops it, a signalling one comes out as a NaN that the next step drops - callers poison their extrema separately when
+// a NaN was seen, as they did with fminf.  HIP treats inline asm as convergent: use these in fully unrolled tile loops only - a
+// loop with a run-time trip count that contains one is no longer unrolled (k_moments' row loop keeps fminf).
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float relu_raw(float a) {      // fmaxf(a, 0.f): 0 for a NaN, as there
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+// the two halves of a packed sum, one plain add (written out: left to itself the compiler packs the horizontal adds of two
+// different sums into one v_pk_add_f32 behind three register moves)
+template <class F2>
+__device__ __forceinline__ float hadd(const F2 p) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(p.x), "v"(p.y));
+    return r;
+}
+__device__ __forceinline__ float abs_add(float a, float b) {      // |a| + |b|, one instruction
+    float r;
+    asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // One LDS-DMA load (16 bytes per lane: lane i of the wave lands at lds + 16 i) issued BEHIND the compiler's back.  With the
 // builtin in flight the compiler waits for vmcnt(0) before the first use of ANY loaded register (it does not count across the
 // two kinds of load), which serialises "the whole tile has landed" before the first addition.  Written as asm, issued AFTER the

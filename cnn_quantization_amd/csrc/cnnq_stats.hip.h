@@ -76,34 +76,6 @@ struct Mom {
     // its arithmetic behind 4 bytes per element.  add4p: a alone - the bits add8 gives with b absent.  (Only for fully unrolled
     // tile loops: HIP treats inline asm as convergent, and a loop with a run-time trip count that contains it - the row loop of
     // k_moments - is no longer unrolled.  add4 therefore keeps fminf / fmaxf.)
-    static __device__ __forceinline__ float min3_raw(float a, float b, float c) {
-        float r;
-        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-        return r;
-    }
-    static __device__ __forceinline__ float max3_raw(float a, float b, float c) {
-        float r;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-        return r;
-    }
-    static __device__ __forceinline__ float relu_raw(float a) {      // fmaxf(a, 0.f): 0 for a NaN, as there
-        float r;
-        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
-        return r;
-    }
-    // the two halves of a packed sum, one plain add (written out: left to itself the compiler packs the horizontal adds of two
-    // different sums into one v_pk_add_f32 behind three register moves)
-    template <class F2>
-    static __device__ __forceinline__ float hadd(const F2 p) {
-        float r;
-        asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(p.x), "v"(p.y));
-        return r;
-    }
-    static __device__ __forceinline__ float abs_add(float a, float b) {      // |a| + |b|, one instruction
-        float r;
-        asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-        return r;
-    }
     template <bool RELU>
     __device__ __forceinline__ void add8(const float (&a)[4], const float (&b)[4]) {
         typedef float f2 __attribute__((ext_vector_type(2)));

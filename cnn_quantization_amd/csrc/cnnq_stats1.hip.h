@@ -375,20 +375,20 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         const f2 m2 = {mean, mean}, i2 = {isd, isd};
         auto dev8 = [&](const float (&t)[4], const float (&t1)[4], double& a, double& k4) {
             const f2 d0 = f2{t[0], t[1]} - m2, d1 = f2{t[2], t[3]} - m2, d2 = f2{t1[0], t1[1]} - m2, d3 = f2{t1[2], t1[3]} - m2;
-            const f2 ab = f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)} + f2{Mom::abs_add(d2.x, d2.y), Mom::abs_add(d3.x, d3.y)};
-            a += (double)Mom::hadd(ab);
+            const f2 ab = f2{abs_add(d0.x, d0.y), abs_add(d1.x, d1.y)} + f2{abs_add(d2.x, d2.y), abs_add(d3.x, d3.y)};
+            a += (double)hadd(ab);
             f2 z0 = d0 * i2, z1 = d1 * i2, z2 = d2 * i2, z3 = d3 * i2;
             z0 = z0 * z0; z1 = z1 * z1; z2 = z2 * z2; z3 = z3 * z3;
             const f2 q = ((z0 * z0 + z1 * z1) + z2 * z2) + z3 * z3;
-            k4 += (double)Mom::hadd(q);
+            k4 += (double)hadd(q);
         };
         auto dev4p = [&](const float (&t)[4], double& a, double& k4) {
             const f2 d0 = f2{t[0], t[1]} - m2, d1 = f2{t[2], t[3]} - m2;
-            a += (double)Mom::hadd(f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)});
+            a += (double)hadd(f2{abs_add(d0.x, d0.y), abs_add(d1.x, d1.y)});
             f2 z0 = d0 * i2, z1 = d1 * i2;
             z0 = z0 * z0; z1 = z1 * z1;
             const f2 q = z0 * z0 + z1 * z1;
-            k4 += (double)Mom::hadd(q);
+            k4 += (double)hadd(q);
         };
         // Round 6: nobody WAITS for the second meeting any more.  A member publishes its two words and counts its arrival; whoever
         // arrives LAST - every other member's words are out by then - folds them (member order), exchanges them with the other
@@ -894,19 +894,19 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
                 const f2 m2 = {mean[0], mean[0]}, i2 = {isd[0], isd[0]};
                 if (r + 1 < nr) {
                     const f2 d0 = f2{t0[0], t0[1]} - m2, d1 = f2{t0[2], t0[3]} - m2, d2 = f2{t1[0], t1[1]} - m2, d3 = f2{t1[2], t1[3]} - m2;
-                    const f2 ab = f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)} + f2{Mom::abs_add(d2.x, d2.y), Mom::abs_add(d3.x, d3.y)};
-                    da[0] += (double)Mom::hadd(ab);
+                    const f2 ab = f2{abs_add(d0.x, d0.y), abs_add(d1.x, d1.y)} + f2{abs_add(d2.x, d2.y), abs_add(d3.x, d3.y)};
+                    da[0] += (double)hadd(ab);
                     f2 z0 = d0 * i2, z1 = d1 * i2, z2 = d2 * i2, z3 = d3 * i2;
                     z0 = z0 * z0; z1 = z1 * z1; z2 = z2 * z2; z3 = z3 * z3;
                     const f2 q = ((z0 * z0 + z1 * z1) + z2 * z2) + z3 * z3;
-                    dk[0] += (double)Mom::hadd(q);
+                    dk[0] += (double)hadd(q);
                 } else if (r < nr) {
                     const f2 d0 = f2{t0[0], t0[1]} - m2, d1 = f2{t0[2], t0[3]} - m2;
-                    da[0] += (double)Mom::hadd(f2{Mom::abs_add(d0.x, d0.y), Mom::abs_add(d1.x, d1.y)});
+                    da[0] += (double)hadd(f2{abs_add(d0.x, d0.y), abs_add(d1.x, d1.y)});
                     f2 z0 = d0 * i2, z1 = d1 * i2;
                     z0 = z0 * z0; z1 = z1 * z1;
                     const f2 q = z0 * z0 + z1 * z1;
-                    dk[0] += (double)Mom::hadd(q);
+                    dk[0] += (double)hadd(q);
                 }
             } else {
                 if (r < nr) dev_add(t0, mean, isd, da, dk);
