@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_fused_fl
 #pragma unroll
     for (int j = 0; j < K; ++j) absdev_step(v[j], vmean, j < nvalid, sa);
     if constexpr (KL > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+        lds_dma_landed(sa);
         double sl = 0.;
 #pragma unroll
         for (int l = 0; l < KL; ++l) {

@@ -223,12 +223,24 @@ __device__ __forceinline__ float abs_add(float a, float b) {      // |a| + |b|, 
 // register loads of the tile: the loads return in order, so the compiler's own counts for the register steps - it believes
 // fewer loads are in flight than there are - only ever wait longer than they must, never shorter; the reader of the LDS steps
 // waits for vmcnt(0) explicitly.  base: wave-uniform; lds: wave-uniform.
+// (m0 is a reserved register: the compiler sets it in front of each of its own uses; naming it in the clobber list documents the
+//  write and draws -Winline-asm)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void lds_dma16_behind(const char* base, unsigned off, const float* lds) {
     const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds);
     const unsigned long long b = (unsigned long long)base;
     const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
     const unsigned long long bs = (unsigned long long)blo | ((unsigned long long)bhi << 32);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(bs), "s"(l) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// ... and the wait of their reader: the LDS-DMA steps of this wave have landed (its lanes read only their own wave's slots).  `dep`:
+// a value the register steps produced - the wait is volatile, but arithmetic on registers may be scheduled across a volatile asm,
+// and a wait hoisted above the register steps would make all of them wait for the whole tile again
+template <class T>
+__device__ __forceinline__ void lds_dma_landed(T& dep) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dep) : : "memory");
 }
 
 }  // namespace

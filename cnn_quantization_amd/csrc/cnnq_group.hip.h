@@ -834,17 +834,6 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
     //      base's row start (an element of the same channel: harmless for the extrema, never stored)
     float v[K][4];
     FWalk w = w0;
-    if constexpr (KL > 0) {
-        // the tile's FIRST KL steps go straight into LDS (issued first: the compiler waits for every outstanding ordinary load
-        // before it issues an LDS-DMA, not the other way round): each wave's 64 x 16 bytes land lane-linear at its own 1 KB slot
-#pragma unroll
-        for (int l = 0; l < KL; ++l) {
-            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
-                                             (__attribute__((address_space(3))) void*)(sh_x + (l * TPB + (tid & ~63)) * 4), 16, 0, 0);
-            w.step(g);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
@@ -856,6 +845,17 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
 #endif
         w.step(g);
     }
+    if constexpr (KL > 0) {
+        // the tile's LAST KL steps go straight into LDS: each wave's 64 x 16 bytes land lane-linear at its own 1 KB slot.  Round 6:
+        // as asm behind the register loads (lds_dma16_behind, cnnq_common.hip.h) - with the builtin, which had to be issued
+        // FIRST, the compiler waited for vmcnt(0) before the first use of any register step
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            const unsigned off = w.ro < lim ? w.ro + w.co : 0u;
+            lds_dma16_behind(xb, off, sh_x + (l * TPB + (tid & ~63)) * 4);
+            w.step(g);
+        }
+    }
     // nothing that consumes a loaded value may be scheduled in between the loads (the scheduler otherwise folds the
     // first rows into the extrema while it still has loads to issue, and waits for them first)
     __builtin_amdgcn_sched_barrier(0);
@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
 #pragma unroll
     for (int j = 0; j < K; ++j) lane_acc<1>(v[j], mn, mx, nan);
     if constexpr (KL > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+        lds_dma_landed(mn[0]);
 #pragma unroll
         for (int l = 0; l < KL; ++l) {
             float t[4];
@@ -981,22 +981,6 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
         // the channel's values are inside qdq_fast_domain: the exact quotient without the divide, parameters in
         // scalar registers (one channel per workgroup)
         const float s_sc = uniform_f(sc), s_rs = uniform_f(1.0f / sc), s_zp = uniform_f(zp);
-        if constexpr (KL > 0) {
-#pragma unroll
-            for (int l = 0; l < KL; ++l) {
-                const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
-                const float t[4] = {q.x, q.y, q.z, q.w};
-                float o[4], cd[4];
-                qdq4_fast(t, s_sc, s_rs, s_zp, qm, o, cd);
-                if constexpr (OUT == 2) {
-                    if (pkl > 1) sh_pk[l * 256 + tid] = pack4_of(cd);
-                    else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-                } else {
-                    if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-                }
-                w.step(g);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             float o[4], cd[4];
@@ -1007,14 +991,43 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             qdq4_fast(v[j], s_sc, s_rs, s_zp, qm, o, cd);
 #endif
             if constexpr (OUT == 2) {
-                if (pkl > 1) sh_pk[(KL + j) * 256 + tid] = pack4_of(cd);
+                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
                 else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
             } else {
                 if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
             }
             w.step(g);
         }
+        if constexpr (KL > 0) {
+#pragma unroll
+            for (int l = 0; l < KL; ++l) {
+                const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
+                const float t[4] = {q.x, q.y, q.z, q.w};
+                float o[4], cd[4];
+                qdq4_fast(t, s_sc, s_rs, s_zp, qm, o, cd);
+                if constexpr (OUT == 2) {
+                    if (pkl > 1) sh_pk[(K + l) * 256 + tid] = pack4_of(cd);
+                    else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                } else {
+                    if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+                }
+                w.step(g);
+            }
+        }
     } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float o[4], cd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
+            if constexpr (OUT == 2) {
+                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
+                else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            } else {
+                if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
+            }
+            w.step(g);
+        }
         if constexpr (KL > 0) {
 #pragma unroll
             for (int l = 0; l < KL; ++l) {
@@ -1024,26 +1037,13 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = qdq1(t[e], sc, zp, qm, cd[e]);
                 if constexpr (OUT == 2) {
-                    if (pkl > 1) sh_pk[l * 256 + tid] = pack4_of(cd);
+                    if (pkl > 1) sh_pk[(K + l) * 256 + tid] = pack4_of(cd);
                     else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
                 } else {
                     if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
                 }
                 w.step(g);
             }
-        }
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            float o[4], cd[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = qdq1(v[j][e], sc, zp, qm, cd[e]);
-            if constexpr (OUT == 2) {
-                if (pkl > 1) sh_pk[(KL + j) * 256 + tid] = pack4_of(cd);
-                else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-            } else {
-                if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
-            }
-            w.step(g);
         }
     }
     if constexpr (OUT == 1) {

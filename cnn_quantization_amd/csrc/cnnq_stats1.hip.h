@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
         else if (j < nvalid) acc.template add4p<RELU>(v[j]);
     }
     if constexpr (KL > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+        lds_dma_landed(acc.mn);
         Mom al;
         al.init();
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(TPB, (KR + KL == 32 ? GRP_K32_WAVES : 1)) k_st
 #pragma unroll
     for (int j = 0; j < KR; j += 2) ac.add_rows(v[j], v[j + 1], j, nrows);
     if constexpr (KL > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of this wave has landed (its lanes read only their own wave's slots)
+        lds_dma_landed(ac.mn[0]);
 #pragma unroll
         for (int l = 0; l < KL; l += 2) {
             const float4 q = *reinterpret_cast<const float4*>(sh_x + (l * TPB + tid) * 4);
