@@ -45,7 +45,7 @@ for L in layers:
     classes.setdefault(tuple(L['x'].shape), []).append(L)
 t0 = report('as allocated')
 rejects = []
-for which in ('y', 'x'):
+for which in os.environ.get('WHICH', 'y,x').split(','):
     for shape, Ls in classes.items():
         ref = Ls[0]
         if which == 'y':
@@ -74,5 +74,7 @@ for which in ('y', 'x'):
                         continue                      # a tensor of the class already lives there: leave both where they are
                     new.copy_(old)
                     L['x'] = new
-        rejects += [c for i, c in enumerate(cands) if i not in keep]
+        if os.environ.get('HOLD', '1') == '1':
+            rejects += [c for i, c in enumerate(cands) if i not in keep]
+        del cands
     report('%s planned (n + %d candidates)' % ('outputs' if which == 'y' else 'outputs and inputs', M))
