@@ -991,7 +991,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
             qdq4_fast(v[j], s_sc, s_rs, s_zp, qm, o, cd);
 #endif
             if constexpr (OUT == 2) {
-                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_of(cd);
+                if (pkl > 1) sh_pk[j * 256 + tid] = pack4_fast(cd);
                 else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
             } else {
                 if (w.ro < lim FLAT_ABL_NOSTORE(o)) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(TPB, (K == 32 ? GRP_K32_WAVES : 1)) k_mmq_flat
                 float o[4], cd[4];
                 qdq4_fast(t, s_sc, s_rs, s_zp, qm, o, cd);
                 if constexpr (OUT == 2) {
-                    if (pkl > 1) sh_pk[(K + l) * 256 + tid] = pack4_of(cd);
+                    if (pkl > 1) sh_pk[(K + l) * 256 + tid] = pack4_fast(cd);
                     else if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);
                 } else {
                     if (w.ro < lim) xstore<OUT, 1>(xo, yb, cbb, pbb, w.ro + w.co, o, cd, sh_hist, zpa, nzp);

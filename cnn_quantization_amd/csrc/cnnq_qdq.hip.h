@@ -273,6 +273,14 @@ __device__ __forceinline__ uint16_t pack4_of(const float (&cd)[4]) {
     return (uint16_t)(((unsigned)cd[0] & 15u) | (((unsigned)cd[1] & 15u) << 4) | (((unsigned)cd[2] & 15u) << 8) |
                       (((unsigned)cd[3] & 15u) << 12));
 }
+// ... in the divide-free domain (qdq_fast_domain: the codes are integers 0 .. 15, no NaN): the word built in fp32 - c0 + 16 c1 +
+// 256 c2 + 4096 c3 is exact (< 2^16) - three fmas and ONE conversion instead of four conversions, masks, shifts and ors: the
+// same word in 4 instead of ~12 instructions (the packed output is a 4.5 B/elem launch: like config 4's statistics kernel it
+// is short of issue slots, DESIGN.md section 5 note 6)
+__device__ __forceinline__ uint16_t pack4_fast(const float (&cd)[4]) {
+    const float p = __builtin_fmaf(cd[3], 4096.f, __builtin_fmaf(cd[2], 256.f, __builtin_fmaf(cd[1], 16.f, cd[0])));
+    return (uint16_t)(unsigned)p;
+}
 // one float4 of results at byte offset `boff` (of the fp32 tensor) from the three bases: y, the codes (one byte per
 // element: boff / 4) and the packed nibbles (boff / 8).  OFF is size_t, or unsigned when the bases are per-workgroup
 // (uniform base + 32-bit lane offset is the addressing form the flat tiles load with)
