@@ -28,10 +28,13 @@ def timed(f, reps=3):
 
 
 ys = [torch.empty_like(x) for _ in range(K)]
-print(list(shape), 'us: single launch | copy_ | fill_ | read-only sum of y')
+print(list(shape), 'us: single launch | copy_ | fill_ | read-only sum of y | the three-launch chain of config 2 (CNNQ_RESIDENT=0)')
 for y in ys:
     a = timed(lambda: ops.act_qdq_per_channel(x, 4, out=y))
     b = timed(lambda: y.copy_(x))
     c = timed(lambda: y.fill_(1.0))
     d = timed(lambda: ops.pc_moments(y, shape[0], shape[1], shape[2] * shape[3], False))
-    print('%s  %7.1f | %7.1f | %7.1f | %7.1f' % (hex(y.data_ptr()), a, b, c, d), flush=True)
+    ops._RESIDENT = False
+    e = timed(lambda: ops.act_qdq_per_channel(x, 4, out=y))
+    ops.reload_switches()
+    print('%s  %7.1f | %7.1f | %7.1f | %7.1f | %7.1f' % (hex(y.data_ptr()), a, b, c, d, e), flush=True)
